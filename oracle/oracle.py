@@ -1,0 +1,194 @@
+"""ctypes wrapper over oracle/libssme_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+The product package (ssme_amd) never does.  See oracle/ssme_oracle.cpp for the reference
+file:line each function follows and for the "parity unpinned" statement.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libssme_oracle.so")
+
+MODEL_SVOL, MODEL_SVOL_LEVERAGE, MODEL_LIN_GAUSS = 0, 1, 2
+RESAMP_MULTINOMIAL, RESAMP_SYSTEMATIC, RESAMP_STRATIFIED, RESAMP_MULTINOMIAL_IID = 0, 1, 2, 3
+TILE = 2048
+ROW = 512
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "ssme_oracle.cpp")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        dp, u32p = C.POINTER(C.c_double), C.POINTER(C.c_uint32)
+        L.orc_philox4x32_10.argtypes = [u32p, u32p, u32p]
+        for f in (L.orc_exp, L.orc_log):
+            f.argtypes = [dp, dp, C.c_long]
+        L.orc_sincos2pi.argtypes = [dp, dp, dp, C.c_long]
+        L.orc_normals.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, dp]
+        L.orc_rows_scan.argtypes = [dp, C.c_int, dp, dp, dp]
+        L.orc_pf_create.restype = C.c_void_p
+        L.orc_pf_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, dp]
+        L.orc_pf_destroy.argtypes = [C.c_void_p]
+        L.orc_pf_reset.argtypes = [C.c_void_p]
+        L.orc_pf_step.restype = C.c_double
+        L.orc_pf_step.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_pf_loglik.restype = C.c_double
+        L.orc_pf_loglik.argtypes = [C.c_void_p]
+        L.orc_pf_run_series.restype = C.c_double
+        L.orc_pf_run_series.argtypes = [C.c_void_p, dp, dp, C.c_int, dp]
+        L.orc_pf_state.argtypes = [C.c_void_p, dp, dp, dp, u32p, dp, dp, dp]
+        L.orc_pf_expectation.restype = C.c_double
+        L.orc_pf_expectation.argtypes = [C.c_void_p, C.c_int]
+        L.orc_ref_run_series.restype = C.c_double
+        L.orc_ref_run_series.argtypes = [C.c_int, dp, C.c_int, dp, dp, C.c_int, C.c_uint32, C.c_int, C.c_int, dp]
+        L.orc_log_mean_exp.restype = C.c_double
+        L.orc_log_mean_exp.argtypes = [dp, C.c_int]
+        L.orc_inv_transform.restype = C.c_double
+        L.orc_inv_transform.argtypes = [C.c_int, C.c_double]
+        L.orc_log_jacobian.restype = C.c_double
+        L.orc_log_jacobian.argtypes = [C.c_int, C.c_double]
+        L.orc_kalman_loglik.restype = C.c_double
+        L.orc_kalman_loglik.argtypes = [C.c_double, C.c_double, C.c_double, dp, C.c_int, dp]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32)) if a is not None else None
+
+
+def philox(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    o = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(_u32p(c), _u32p(k), _u32p(o))
+    return o
+
+
+def _map1(fn, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    fn(_dp(x), _dp(y), x.size)
+    return y
+
+
+def exp(x):
+    return _map1(lib().orc_exp, x)
+
+
+def log(x):
+    return _map1(lib().orc_log, x)
+
+
+def sincos2pi(u):
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    s, c = np.empty_like(u), np.empty_like(u)
+    lib().orc_sincos2pi(_dp(u), _dp(s), _dp(c), u.size)
+    return s, c
+
+
+def normals(seed, rep, t, n):
+    out = np.empty(n, dtype=np.float64)
+    lib().orc_normals(seed, rep, t, n, _dp(out))
+    return out
+
+
+def rows_scan(v):
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    assert v.size % ROW == 0
+    incl, excl = np.empty_like(v), np.empty_like(v)
+    tot = np.zeros(1)
+    lib().orc_rows_scan(_dp(v), v.size // ROW, _dp(incl), _dp(excl), _dp(tot))
+    return incl, excl, float(tot[0])
+
+
+class Filter:
+    """Kernel-matched oracle filter (mode B), one replicate."""
+
+    def __init__(self, model, n, theta, seed, rep=0, resampler=RESAMP_MULTINOMIAL, resamp_sched=1):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        self.n = int(n)
+        self.nt = (self.n + TILE - 1) // TILE
+        self._h = lib().orc_pf_create(model, n, resampler, resamp_sched, seed, rep, _dp(th))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_pf_destroy(self._h)
+            self._h = None
+
+    def reset(self):
+        lib().orc_pf_reset(self._h)
+
+    def step(self, y, z=0.0):
+        return lib().orc_pf_step(self._h, float(y), float(z))
+
+    @property
+    def loglik(self):
+        return lib().orc_pf_loglik(self._h)
+
+    def run_series(self, y, z=None):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        z = None if z is None else np.ascontiguousarray(z, dtype=np.float64)
+        per = np.empty(y.size)
+        ll = lib().orc_pf_run_series(self._h, _dp(y), _dp(z), y.size, _dp(per))
+        return ll, per
+
+    def state(self):
+        n = self.n
+        x, lw, loc = np.empty(n), np.empty(n), np.empty(n)
+        anc = np.empty(n, dtype=np.uint32)
+        A, P, sc = np.empty(self.nt), np.empty(self.nt), np.empty(2)
+        lib().orc_pf_state(self._h, _dp(x), _dp(lw), _dp(loc), _u32p(anc), _dp(A), _dp(P), _dp(sc))
+        return dict(x=x, logw=lw, cdf=loc, anc=anc, A=A, P=P, m=sc[0], S=sc[1])
+
+    def expectation(self, kind):
+        return lib().orc_pf_expectation(self._h, kind)
+
+
+def ref_run_series(model, theta, n, y, z=None, seed=1, use_float=False, fast_resampler=False):
+    """Mode A: mt19937 / <random> reference-faithful filter. Returns (loglik, per-step)."""
+    th = np.ascontiguousarray(theta, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    z = None if z is None else np.ascontiguousarray(z, dtype=np.float64)
+    per = np.empty(y.size)
+    ll = lib().orc_ref_run_series(model, _dp(th), n, _dp(y), _dp(z), y.size, seed, int(use_float),
+                                  int(fast_resampler), _dp(per))
+    return ll, per
+
+
+def log_mean_exp(v):
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    return lib().orc_log_mean_exp(_dp(v), v.size)
+
+
+def inv_transform(kind, tp):
+    return lib().orc_inv_transform(kind, tp)
+
+
+def log_jacobian(kind, tp):
+    return lib().orc_log_jacobian(kind, tp)
+
+
+def kalman_loglik(phi, sigma, tau, y):
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    per = np.empty(y.size)
+    return lib().orc_kalman_loglik(phi, sigma, tau, _dp(y), y.size, _dp(per)), per

@@ -1,0 +1,634 @@
+// ssme_oracle.cpp -- CPU ORACLE for the bootstrap-particle-filter hot path.
+//
+// THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may load it.  The product path (ssme_amd/csrc, the
+// C-ABI in include/ssme_pf.h) never links, calls or falls back to anything in oracle/.
+//
+// PARITY STATUS: "parity unpinned".  The arithmetic of the path lives in the third-party
+// header-only library `pf` (github tbrown122387/pf, NO version pin: reference
+// CMakeLists.txt:12 `find_package(pf CONFIG REQUIRED)`), which is absent from
+// /root/reference, as are Eigen3 and Catch2; the reference cannot be compiled here and
+// none of its own tests pins a filter output (test/test_pswarm.cpp:251-252 and
+// test/test_liu_west.cpp:172,198-199 assert only loglike^2 > 0 and E[42] == 42 on
+// uninitialised inputs).  What IS pinned from the reference's own files:
+//   * param::pack inverse transforms / log-Jacobian KATs   test/test_parameters.cpp:114-145
+//   * log-mean-exp of replicates KAT                       test/test_thread_pool.cpp:39-46
+//   * constant-functional expectation == 42                test/test_pswarm.cpp:252
+// Independent anchors added by this repo: exact Kalman log-likelihood of a linear-Gaussian
+// model, agreement between the two RNG modes below, Random123 Philox4x32-10 KATs.
+//
+// Two modes restate the same algorithm:
+//  (A) "reference-faithful": std::mt19937 + std::normal_distribution +
+//      std::discrete_distribution, reference operation order in logGEv.  Used for the
+//      statistical cross-check and as bench.py's cpu_baseline ("port").
+//  (B) "kernel-matched": Philox4x32-10 counter RNG, libm-free fp64 math, and the
+//      canonical summation tree documented in DESIGN.md section 4.  The HIP kernels are
+//      compared BIT FOR BIT against this mode.
+//
+// Reference lines followed (all relative to /root/reference):
+//   model callbacks      example/univ_svol_bootstrap_filter.h:55-103   (svol_bs)
+//                        test/test_pswarm.cpp:80-134                    (svol_leverage)
+//   driver loop          example/estimate_univ_svol.h:108-131          (log_like_eval)
+//   SISR step, LSE, expectations, resample schedule (in-tree twin of the external
+//   pf::BSFilter::filter)  include/ssme/liu_west_filter.h:1608-1761
+//   multinomial resampling by sorted uniforms (exponential spacings), weight reset
+//                        include/ssme/liu_west_filter.h:91-145
+//   replicate aggregation (log-mean-exp)  include/ssme/thread_pool.h:263-268
+//   parameter transforms include/ssme/parameters.h:317-457
+// pf-internal details that cannot be read here are marked [pf-recollection].
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11; Random123).  Counter = {index, t, replicate, stream}
+// ---------------------------------------------------------------------------------------
+inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    const uint32_t n0 = hi1 ^ c[1] ^ k[0];
+    const uint32_t n2 = hi0 ^ c[3] ^ k[1];
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+}
+
+inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    uint32_t k[2] = {key[0], key[1]};
+    for (int r = 0; r < 10; ++r) {
+        if (r) { k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u; }
+        philox_round(c, k);
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+// 53 random bits from two words -> [0,1) and (0,1]
+inline uint64_t bits53(uint32_t a, uint32_t b) { return ((uint64_t)a << 21) | (uint64_t)(b >> 11); }
+inline double u01_co(uint32_t a, uint32_t b) { return (double)bits53(a, b) * 0x1.0p-53; }          // [0,1)
+inline double u01_oc(uint32_t a, uint32_t b) { return (double)(bits53(a, b) + 1) * 0x1.0p-53; }    // (0,1]
+
+enum { STREAM_PROP = 0, STREAM_RESAMP = 1, STREAM_RESAMP_EXTRA = 2 };
+
+// ---------------------------------------------------------------------------------------
+// libm-free fp64 math.  Only + - * fma, IEEE sqrt and division, and integer bit moves, so
+// that the device implementation (ssme_amd/csrc/device_math.h) yields identical bits.
+// Built with -ffp-contract=off.  Algorithms: exp = Cody-Waite reduction + Taylor-13;
+// log = fdlibm e_log.c main path; sin/cos = fdlibm k_sin.c / k_cos.c kernels on r*pi/2.
+// ---------------------------------------------------------------------------------------
+inline double bits_to_double(uint64_t u) { double d; std::memcpy(&d, &u, 8); return d; }
+inline uint64_t double_to_bits(double d) { uint64_t u; std::memcpy(&u, &d, 8); return u; }
+inline double pow2i(int n) { return bits_to_double((uint64_t)(n + 1023) << 52); }   // n in [-1022,1023]
+
+double o_exp(double x) {
+    if (x != x) return x;
+    if (x > 709.782712893384) return std::numeric_limits<double>::infinity();
+    if (x < -745.1332191019412) return 0.0;
+    const double LOG2E = 1.4426950408889634074;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double SH = 6755399441055744.0;  // 1.5 * 2^52
+    const double kf = (x * LOG2E + SH) - SH;
+    const int k = (int)kf;
+    double r = std::fma(-kf, LN2_HI, x);
+    r = std::fma(-kf, LN2_LO, r);
+    // q = sum_{n=2..13} r^(n-2)/n!
+    double q = 1.6059043836821613e-10;            // 1/13!
+    q = std::fma(q, r, 2.08767569878681e-09);     // 1/12!
+    q = std::fma(q, r, 2.505210838544172e-08);    // 1/11!
+    q = std::fma(q, r, 2.755731922398589e-07);    // 1/10!
+    q = std::fma(q, r, 2.7557319223985893e-06);   // 1/9!
+    q = std::fma(q, r, 2.48015873015873e-05);     // 1/8!
+    q = std::fma(q, r, 0.0001984126984126984);    // 1/7!
+    q = std::fma(q, r, 0.001388888888888889);     // 1/6!
+    q = std::fma(q, r, 0.008333333333333333);     // 1/5!
+    q = std::fma(q, r, 0.041666666666666664);     // 1/4!
+    q = std::fma(q, r, 0.16666666666666666);      // 1/3!
+    q = std::fma(q, r, 0.5);                      // 1/2!
+    const double e = std::fma(r * r, q, r);
+    const double p = 1.0 + e;
+    const int k1 = k / 2, k2 = k - k1;
+    return (p * pow2i(k1)) * pow2i(k2);
+}
+
+double o_log(double x) {
+    if (x != x) return x;
+    if (x < 0.0) return std::numeric_limits<double>::quiet_NaN();
+    if (x == 0.0) return -std::numeric_limits<double>::infinity();
+    if (x == std::numeric_limits<double>::infinity()) return x;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    int k = 0;
+    uint64_t ux = double_to_bits(x);
+    if ((ux >> 52) == 0) { x = x * 0x1.0p54; k -= 54; ux = double_to_bits(x); }
+    uint32_t hx = (uint32_t)(ux >> 32);
+    k += (int)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    const uint32_t i = (hx + 0x95f64u) & 0x100000u;
+    ux = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffull);
+    k += (int)(i >> 20);
+    const double m = bits_to_double(ux);          // in [sqrt(2)/2, sqrt(2))
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double hfsq = (0.5 * f) * f;
+    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+
+// sin(2*pi*u), cos(2*pi*u) for u in [0,1)
+void o_sincos2pi(double u, double* sn, double* cs) {
+    const double SH = 6755399441055744.0;
+    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double t = 4.0 * u;
+    const double qf = (t + SH) - SH;
+    const int q = (int)qf;
+    const double r = t - qf;                      // exact, in [-0.5, 0.5]
+    const double a = r * PIO2_HI;
+    const double al = std::fma(r, PIO2_HI, -a) + r * PIO2_LO;
+    const double z = a * a;
+    // sine kernel
+    const double v = z * a;
+    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double s0 = a - ((z * (0.5 * al - v * rs) - al) - v * S1);
+    // cosine kernel
+    const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double hz = 0.5 * z;
+    const double wv = 1.0 - hz;
+    const double c0 = wv + (((1.0 - wv) - hz) + (z * rc - a * al));
+    switch (q & 3) {
+        case 0: *sn = s0;  *cs = c0;  break;
+        case 1: *sn = c0;  *cs = -s0; break;
+        case 2: *sn = -s0; *cs = -c0; break;
+        default: *sn = -c0; *cs = s0; break;
+    }
+}
+
+const double HALF_LOG_2PI = 0.91893853320467274178;
+const double NEG_INF = -std::numeric_limits<double>::infinity();
+const double POS_INF = std::numeric_limits<double>::infinity();
+
+// ---------------------------------------------------------------------------------------
+// Models (kernel-matched form).  theta is UNTRANSFORMED, as the reference's model ctors
+// receive it after pack::get_untrans_params (univ_svol_bootstrap_filter.h:55-61).
+// ---------------------------------------------------------------------------------------
+enum { MODEL_SVOL = 0, MODEL_SVOL_LEVERAGE = 1, MODEL_LIN_GAUSS = 2 };
+enum { RESAMP_MULTINOMIAL = 0, RESAMP_SYSTEMATIC = 1, RESAMP_STRATIFIED = 2, RESAMP_MULTINOMIAL_IID = 3 };
+
+struct ModelConst {          // derived once per replicate on the host, in this op order
+    int model;
+    double a0, a1, a2, a3, a4, a5;  // meaning depends on model, see derive()
+    int bad;                        // 1 -> logG == -inf (e.g. beta <= 0)
+};
+
+ModelConst derive(int model, const double* th) {
+    ModelConst c{};
+    c.model = model;
+    if (model == MODEL_SVOL) {          // th = (beta, phi, sigma)
+        const double beta = th[0], phi = th[1], sigma = th[2];
+        c.a0 = phi;                                   // phi
+        c.a1 = sigma;                                 // sigma
+        c.a2 = sigma / std::sqrt(1.0 - phi * phi);    // stationary sd (q1Samp, :65-70)
+        c.a3 = o_log(beta);                           // log beta
+        c.a4 = 1.0 / (beta * beta);                   // beta^-2
+        c.bad = !(beta > 0.0);
+    } else if (model == MODEL_SVOL_LEVERAGE) {   // th = (phi, mu, sigma, rho)
+        const double phi = th[0], mu = th[1], sigma = th[2], rho = th[3];
+        c.a0 = phi; c.a1 = mu;
+        c.a2 = sigma / std::sqrt(1.0 - phi * phi);    // stationary sd (test_pswarm.cpp:80-86)
+        c.a3 = sigma * std::sqrt(1.0 - phi * phi);    // transition sd (:95)
+        c.a4 = rho * sigma;                           // leverage coefficient (:94)
+        c.bad = 0;
+    } else {                              // linear Gaussian: th = (phi, sigma, tau)
+        const double phi = th[0], sigma = th[1], tau = th[2];
+        c.a0 = phi; c.a1 = sigma;
+        c.a2 = sigma / std::sqrt(1.0 - phi * phi);
+        c.a3 = o_log(tau);
+        c.a4 = 1.0 / tau;
+        c.bad = !(tau > 0.0);
+    }
+    return c;
+}
+
+// q1Samp: stationary draw (univ_svol_bootstrap_filter.h:65-70, test_pswarm.cpp:80-86)
+inline double m_init(const ModelConst& c, double zn) { return zn * c.a2; }
+
+// fSamp (univ_svol_bootstrap_filter.h:74-79; test_pswarm.cpp:90-97)
+inline double m_prop(const ModelConst& c, double x, double zn, double zcov) {
+    if (c.model == MODEL_SVOL_LEVERAGE) {
+        const double e = o_exp(-0.5 * x);
+        const double mean = (c.a1 + c.a0 * (x - c.a1)) + (c.a4 * zcov) * e;
+        return mean + zn * c.a3;
+    }
+    return c.a0 * x + zn * c.a1;
+}
+
+// logGEv (univ_svol_bootstrap_filter.h:83-86; test_pswarm.cpp:101-108).  Kernel form of
+// evalUnivNorm(y, 0, s, log=true) with s = beta*exp(x/2):
+//   -log s - 0.5 log 2pi - 0.5 (y/s)^2  =  -(log beta + x/2) - 0.5 log 2pi - 0.5 y^2 beta^-2 e^-x
+// evalUnivNorm returns -inf when s <= 0 [pf-recollection]; mirrored by `bad` and by the
+// underflow guard (s == 0 in fp64 when log s < -745.13).
+inline double m_logg(const ModelConst& c, double y, double x) {
+    if (c.model == MODEL_LIN_GAUSS) {
+        if (c.bad) return NEG_INF;
+        const double d = (y - x) * c.a4;
+        return (-c.a3 - HALF_LOG_2PI) - 0.5 * (d * d);
+    }
+    double logb = 0.0, ib2 = 1.0;
+    if (c.model == MODEL_SVOL) { if (c.bad) return NEG_INF; logb = c.a3; ib2 = c.a4; }
+    const double hl = logb + 0.5 * x;
+    if (hl < -745.1332191019412) return NEG_INF;
+    const double e = o_exp(-x);
+    const double q = (y * y) * ib2;
+    return (-hl - HALF_LOG_2PI) - 0.5 * (q * e);
+}
+
+// ---------------------------------------------------------------------------------------
+// Canonical summation tree.  A "row" is 512 values owned by 256
+// threads x 2 consecutive values; 4 waves of 64 lanes.  Up to 4 rows form a tile (2048).
+// ---------------------------------------------------------------------------------------
+constexpr int ROW = 512, TILE = 2048, THREADS = 256, WAVE = 64;
+
+struct RowScan { double base[THREADS]; double s0[THREADS]; double s1[THREADS]; double total; };
+
+// scan one row: base[tid] = O_w + exc_lane ; value(c) = base + s_c ; total = O_3 + W_3
+void row_scan(const double* v, RowScan& rs) {
+    double inc[THREADS];
+    for (int tid = 0; tid < THREADS; ++tid) {
+        rs.s0[tid] = v[2 * tid];
+        rs.s1[tid] = rs.s0[tid] + v[2 * tid + 1];
+        inc[tid] = rs.s1[tid];
+    }
+    for (int w = 0; w < THREADS / WAVE; ++w) {                 // Kogge-Stone inside each wave
+        double* p = inc + w * WAVE;
+        for (int d = 1; d < WAVE; d <<= 1) {
+            double nxt[WAVE];
+            for (int l = 0; l < WAVE; ++l) nxt[l] = (l >= d) ? p[l] + p[l - d] : p[l];
+            std::memcpy(p, nxt, sizeof(nxt));
+        }
+    }
+    double O[4];
+    O[0] = 0.0;
+    for (int w = 1; w < 4; ++w) O[w] = O[w - 1] + inc[(w - 1) * WAVE + WAVE - 1];
+    rs.total = O[3] + inc[3 * WAVE + WAVE - 1];
+    for (int tid = 0; tid < THREADS; ++tid) {
+        const int w = tid / WAVE, l = tid % WAVE;
+        const double exc = l ? inc[tid - 1] : 0.0;
+        rs.base[tid] = O[w] + exc;
+    }
+}
+
+// multi-row structure over n = nrows*512 values: inclusive loc[], exclusive ex[], total
+void rows_scan(const double* v, int nrows, double* incl, double* excl, double* total) {
+    std::vector<RowScan> rs(nrows);
+    for (int k = 0; k < nrows; ++k) row_scan(v + k * ROW, rs[k]);
+    std::vector<double> Q(nrows);
+    Q[0] = 0.0;
+    for (int k = 1; k < nrows; ++k) Q[k] = Q[k - 1] + rs[k - 1].total;
+    for (int k = 0; k < nrows; ++k)
+        for (int tid = 0; tid < THREADS; ++tid) {
+            const double b = Q[k] + rs[k].base[tid];
+            if (incl) { incl[k * ROW + 2 * tid] = b + rs[k].s0[tid]; incl[k * ROW + 2 * tid + 1] = b + rs[k].s1[tid]; }
+            if (excl) { excl[k * ROW + 2 * tid] = b; excl[k * ROW + 2 * tid + 1] = b + rs[k].s0[tid]; }
+        }
+    *total = Q[nrows - 1] + rs[nrows - 1].total;
+}
+
+inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+// fixed-probe lower bound over n = 2^k values produced by get(j); returns [0, n-1]
+template <class F>
+inline int lower_bound_pow2(int n, double target, F get) {
+    int pos = 0;
+    for (int step = n >> 1; step >= 1; step >>= 1)
+        if (get(pos + step - 1) < target) pos += step;
+    return pos;
+}
+
+// ---------------------------------------------------------------------------------------
+// Kernel-matched filter (mode B), one replicate.
+// ---------------------------------------------------------------------------------------
+struct Filter {
+    int model, N, resamp, rs;
+    uint32_t key[2];
+    uint32_t rep;
+    ModelConst mc;
+    int B, Npad, nrows2;
+    int t;
+    std::vector<double> x, xprev, logw, loc, A, P, Tend, AE;
+    std::vector<uint32_t> anc;
+    double m, S, prev, loglik, last_ll, G;
+    bool have_resamp_tables;
+
+    void init(int model_, int N_, int resamp_, int rs_, uint64_t seed, uint32_t rep_, const double* th) {
+        model = model_; N = N_; resamp = resamp_; rs = rs_ < 1 ? 1 : rs_;
+        key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32); rep = rep_;
+        mc = derive(model, th);
+        B = (N + TILE - 1) / TILE; Npad = B * TILE;
+        nrows2 = (B + ROW - 1) / ROW;
+        x.assign(Npad, 0.0); xprev.assign(Npad, 0.0); logw.assign(Npad, 0.0); loc.assign(Npad, 0.0);
+        A.assign(nrows2 * ROW, 0.0); P.assign(nrows2 * ROW, 0.0); Tend.assign(nrows2 * ROW, 0.0);
+        AE.assign(nrows2 * ROW, 0.0);
+        anc.assign(Npad, 0u);
+        reset();
+    }
+    void reset() { t = 0; loglik = 0.0; last_ll = 0.0; prev = o_log((double)N); m = 0; S = 0; G = 0; have_resamp_tables = false; }
+
+    // standard normal for particle i at time tt (Box-Muller on the pair i>>1)
+    double normal(int i, int tt) const {
+        const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, STREAM_PROP};
+        uint32_t o[4]; philox4x32_10(ctr, key, o);
+        const double u1 = u01_oc(o[0], o[1]), u2 = u01_co(o[2], o[3]);
+        const double rad = std::sqrt(-2.0 * o_log(u1));
+        double sn, cs; o_sincos2pi(u2, &sn, &cs);
+        return (i & 1) ? rad * sn : rad * cs;
+    }
+    // per-particle resampling uniform at consuming time tt: [0,1) or (0,1]
+    void resamp_words(int i, int tt, uint32_t* a, uint32_t* b) const {
+        const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, STREAM_RESAMP};
+        uint32_t o[4]; philox4x32_10(ctr, key, o);
+        *a = o[2 * (i & 1)]; *b = o[2 * (i & 1) + 1];
+    }
+    void extra_words(int tt, uint32_t o[4]) const {
+        const uint32_t ctr[4] = {0u, (uint32_t)tt, rep, STREAM_RESAMP_EXTRA};
+        philox4x32_10(ctr, key, o);
+    }
+
+    // targets for the ancestors consumed at time tt (drawn against the cdf of step tt-1)
+    void targets(int tt, std::vector<double>& tau) const {
+        tau.assign(Npad, 0.0);
+        if (resamp == RESAMP_MULTINOMIAL) {
+            // exponential spacings (liu_west_filter.h:105-139): U_(i) = sum_{j<=i} E_j / G
+            std::vector<double> E(Npad, 0.0), locE(Npad), AEv(nrows2 * ROW, 0.0), PE(nrows2 * ROW);
+            for (int i = 0; i < N; ++i) { uint32_t a, b; resamp_words(i, tt, &a, &b); E[i] = -o_log(u01_oc(a, b)); }
+            for (int b = 0; b < B; ++b) rows_scan(&E[b * TILE], 4, &locE[b * TILE], nullptr, &AEv[b]);
+            double Etot; rows_scan(AEv.data(), nrows2, nullptr, PE.data(), &Etot);
+            uint32_t o[4]; extra_words(tt, o);
+            const double Gv = Etot + (-o_log(u01_oc(o[0], o[1])));
+            const double scale = S / Gv;
+            for (int i = 0; i < N; ++i) tau[i] = (PE[i / TILE] + locE[i]) * scale;
+        } else if (resamp == RESAMP_SYSTEMATIC) {
+            uint32_t o[4]; extra_words(tt, o);
+            const double u0 = u01_co(o[0], o[1]);
+            const double scale = S / (double)N;
+            for (int i = 0; i < N; ++i) tau[i] = ((double)i + u0) * scale;
+        } else if (resamp == RESAMP_STRATIFIED) {
+            const double scale = S / (double)N;
+            for (int i = 0; i < N; ++i) { uint32_t a, b; resamp_words(i, tt, &a, &b); tau[i] = ((double)i + u01_co(a, b)) * scale; }
+        } else {
+            for (int i = 0; i < N; ++i) { uint32_t a, b; resamp_words(i, tt, &a, &b); tau[i] = u01_co(a, b) * S; }
+        }
+    }
+
+    int search(double target) const {
+        const int Bp = next_pow2(B);
+        const int b = lower_bound_pow2(Bp, target, [&](int j) { return j < B ? Tend[j] : POS_INF; });
+        const int bb = std::min(b, B - 1);
+        const double Pb = P[bb];
+        const int j = lower_bound_pow2(TILE, target, [&](int q) { return Pb + loc[bb * TILE + q]; });
+        return std::min(bb * TILE + j, N - 1);
+    }
+
+    double step(double y, double zcov) {
+        const bool resampled_prev = (t > 0) && (t % rs == 0);
+        std::vector<double> lw_old(N, 0.0);
+        if (t == 0) {
+            for (int i = 0; i < N; ++i) x[i] = m_init(mc, normal(i, 0));
+        } else {
+            xprev.swap(x);
+            if (resampled_prev) {
+                std::vector<double> tau; targets(t, tau);
+                for (int i = 0; i < N; ++i) { anc[i] = (uint32_t)search(tau[i]); }
+                for (int i = 0; i < N; ++i) x[i] = m_prop(mc, xprev[anc[i]], normal(i, t), zcov);
+            } else {
+                for (int i = 0; i < N; ++i) { lw_old[i] = logw[i]; x[i] = m_prop(mc, xprev[i], normal(i, t), zcov); }
+            }
+        }
+        for (int i = 0; i < N; ++i) logw[i] = lw_old[i] + m_logg(mc, y, x[i]);
+        // max: fold of fmax from -inf (NaN-ignoring)
+        double mx = NEG_INF;
+        for (int i = 0; i < N; ++i) if (logw[i] > mx) mx = logw[i];
+        m = mx;
+        std::vector<double> w(Npad, 0.0);
+        for (int i = 0; i < N; ++i) w[i] = o_exp(logw[i] - m);
+        for (int b = 0; b < B; ++b) rows_scan(&w[b * TILE], 4, &loc[b * TILE], nullptr, &A[b]);
+        rows_scan(A.data(), nrows2, nullptr, P.data(), &S);
+        for (int b = 0; b < B; ++b) Tend[b] = P[b] + A[b];
+        const double lse = m + o_log(S);
+        last_ll = lse - prev;
+        loglik += last_ll;
+        const bool resample_now = ((t + 1) % rs == 0);
+        prev = resample_now ? o_log((double)N) : lse;
+        ++t;
+        return last_ll;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Mode A: reference-faithful scalar filter (mt19937, <random>), templated on float type.
+// Follows liu_west_filter.h:1608-1761 (SISR step) with the model callbacks of
+// univ_svol_bootstrap_filter.h:55-103 / test_pswarm.cpp:80-134; resampler =
+// std::discrete_distribution multinomial [pf-recollection of pf::resamplers::mn_resampler]
+// or the in-tree sorted-uniform resampler (liu_west_filter.h:91-145) when fast != 0.
+// Heap storage (the reference's std::array-on-stack pattern overflows at N >= 2^18).
+// ---------------------------------------------------------------------------------------
+template <typename F>
+F evalUnivNormLog(F x, F mu, F sigma) {     // pf::rveval::evalUnivNorm(...,true) [pf-recollection]
+    if (sigma > F(0)) {
+        const F d = (x - mu) / sigma;
+        return -std::log(sigma) - F(HALF_LOG_2PI) - F(0.5) * d * d;
+    }
+    return -std::numeric_limits<F>::infinity();
+}
+
+template <typename F>
+double ref_run(int model, const double* th, int N, const double* y, const double* zc, int T,
+               uint32_t seed, int fast, double* per_step) {
+    std::mt19937 gen(seed), rgen(seed ^ 0x9E3779B9u);
+    std::normal_distribution<F> nd(F(0), F(1));
+    std::uniform_real_distribution<F> ud(F(0), F(1));
+    std::vector<F> x(N), xn(N), lw(N, F(0)), w(N);
+    F loglik = 0;
+    const F p0 = (F)th[0], p1 = (F)th[1], p2 = (F)th[2], p3 = (F)(model == MODEL_SVOL_LEVERAGE ? th[3] : 0.0);
+    for (int t = 0; t < T; ++t) {
+        const F yt = (F)y[t];
+        const F zt = zc ? (F)zc[t] : F(0);
+        std::vector<F> old = lw;
+        F mold = *std::max_element(old.begin(), old.end());
+        for (int i = 0; i < N; ++i) {
+            F xs, lg;
+            if (model == MODEL_SVOL) {               // th = beta, phi, sigma
+                if (t == 0) xs = nd(gen) * p2 / std::sqrt(F(1) - p1 * p1);
+                else        xs = p1 * x[i] + nd(gen) * p2;
+                lg = evalUnivNormLog<F>(yt, F(0), p0 * std::exp(F(0.5) * xs));
+            } else if (model == MODEL_SVOL_LEVERAGE) {   // th = phi, mu, sigma, rho
+                if (t == 0) xs = nd(gen) * p2 / std::sqrt(F(1) - p0 * p0);
+                else {
+                    const F mean = p1 + p0 * (x[i] - p1) + p3 * p2 * zt * std::exp(F(-0.5) * x[i]);
+                    xs = mean + nd(gen) * p2 * std::sqrt(F(1) - p0 * p0);
+                }
+                lg = evalUnivNormLog<F>(yt, F(0), std::exp(F(0.5) * xs));
+            } else {                                 // th = phi, sigma, tau
+                if (t == 0) xs = nd(gen) * p1 / std::sqrt(F(1) - p0 * p0);
+                else        xs = p0 * x[i] + nd(gen) * p1;
+                lg = evalUnivNormLog<F>(yt, xs, p2);
+            }
+            x[i] = xs;
+            lw[i] += lg;          // t == 0: logMu - logQ1 cancel identically for these models
+        }
+        const F mx = *std::max_element(lw.begin(), lw.end());
+        F s1 = 0, s2 = 0;
+        for (int i = 0; i < N; ++i) { w[i] = std::exp(lw[i] - mx); s1 += w[i]; s2 += std::exp(old[i] - mold); }
+        const F ll = (t == 0) ? (-std::log((F)N) + mx + std::log(s1))
+                              : (mx + std::log(s1) - mold - std::log(s2));
+        if (per_step) per_step[t] = (double)ll;
+        loglik += ll;
+        // resample every step (default schedule)
+        if (!fast) {
+            std::discrete_distribution<int> dd(w.begin(), w.end());
+            for (int i = 0; i < N; ++i) xn[i] = x[dd(rgen)];
+        } else {
+            std::vector<F> E(N);
+            F G = 0;
+            for (int i = 0; i < N; ++i) { E[i] = -std::log(ud(rgen)); G += E[i]; }
+            G -= std::log(ud(rgen));
+            F uos = 0, run = w[0] / s1, less = 0;
+            int idx = 0;
+            for (int i = 0; i < N; ++i) {
+                uos += E[i] / G;
+                while (!((less < uos) && (uos <= run)) && idx < N - 1) {
+                    ++idx; run += w[idx] / s1; less += w[idx - 1] / s1;
+                }
+                xn[i] = x[idx];
+            }
+        }
+        x.swap(xn);
+        std::fill(lw.begin(), lw.end(), F(0));
+    }
+    return (double)loglik;
+}
+
+}  // namespace
+
+// =======================================================================================
+// C entry points (ctypes)
+// =======================================================================================
+extern "C" {
+
+void orc_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { philox4x32_10(ctr, key, out); }
+void orc_exp(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_exp(x[i]); }
+void orc_log(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_log(x[i]); }
+void orc_sincos2pi(const double* u, double* s, double* c, long n) { for (long i = 0; i < n; ++i) o_sincos2pi(u[i], s + i, c + i); }
+void orc_normals(uint64_t seed, uint32_t rep, int t, int n, double* out) {
+    Filter f; double th[3] = {1.0, 0.5, 0.1}; f.init(MODEL_SVOL, n, 0, 1, seed, rep, th);
+    for (int i = 0; i < n; ++i) out[i] = f.normal(i, t);
+}
+// scan tree exposed for direct unit tests: n = nrows*512
+void orc_rows_scan(const double* v, int nrows, double* incl, double* excl, double* total) { rows_scan(v, nrows, incl, excl, total); }
+
+void* orc_pf_create(int model, int N, int resamp, int rs, uint64_t seed, uint32_t rep, const double* theta) {
+    Filter* f = new Filter(); f->init(model, N, resamp, rs, seed, rep, theta); return f;
+}
+void orc_pf_destroy(void* h) { delete (Filter*)h; }
+void orc_pf_reset(void* h) { ((Filter*)h)->reset(); }
+double orc_pf_step(void* h, double y, double z) { return ((Filter*)h)->step(y, z); }
+double orc_pf_loglik(void* h) { return ((Filter*)h)->loglik; }
+double orc_pf_run_series(void* h, const double* y, const double* z, int T, double* per_step) {
+    Filter* f = (Filter*)h; f->reset();
+    for (int t = 0; t < T; ++t) { const double l = f->step(y[t], z ? z[t] : 0.0); if (per_step) per_step[t] = l; }
+    return f->loglik;
+}
+// state after the last step: particles (pre-resampling), log-weights, tile-local cdf,
+// ancestors used by the last step, tile aggregates / prefixes, scalars {m, S}
+void orc_pf_state(void* h, double* x, double* logw, double* loc, uint32_t* anc, double* A, double* P, double* scal) {
+    Filter* f = (Filter*)h;
+    if (x) std::memcpy(x, f->x.data(), sizeof(double) * f->N);
+    if (logw) std::memcpy(logw, f->logw.data(), sizeof(double) * f->N);
+    if (loc) std::memcpy(loc, f->loc.data(), sizeof(double) * f->N);
+    if (anc) std::memcpy(anc, f->anc.data(), sizeof(uint32_t) * f->N);
+    if (A) std::memcpy(A, f->A.data(), sizeof(double) * f->B);
+    if (P) std::memcpy(P, f->P.data(), sizeof(double) * f->B);
+    if (scal) { scal[0] = f->m; scal[1] = f->S; }
+}
+// weighted expectation of a built-in functional, pre-resampling (liu_west_filter.h:1662-1683)
+// kind: 0 = x, 1 = x^2, 2 = exp(x/2) (volatility), 3 = constant 42 (test_pswarm.cpp:252 KAT)
+double orc_pf_expectation(void* h, int kind) {
+    Filter* f = (Filter*)h;
+    double num = 0, den = 0;
+    for (int i = 0; i < f->N; ++i) {
+        const double w = o_exp(f->logw[i] - f->m);
+        const double xv = f->x[i];
+        const double hv = kind == 0 ? xv : kind == 1 ? xv * xv : kind == 2 ? o_exp(0.5 * xv) : 42.0;
+        num += hv * w; den += w;
+    }
+    return num / den;
+}
+
+double orc_ref_run_series(int model, const double* theta, int N, const double* y, const double* z, int T,
+                          uint32_t seed, int use_float, int fast_resampler, double* per_step) {
+    return use_float ? ref_run<float>(model, theta, N, y, z, T, seed, fast_resampler, per_step)
+                     : ref_run<double>(model, theta, N, y, z, T, seed, fast_resampler, per_step);
+}
+
+// replicate aggregation, thread_pool.h:263-268
+double orc_log_mean_exp(const double* v, int n) {
+    double mx = *std::max_element(v, v + n), s = 0;
+    for (int i = 0; i < n; ++i) s += std::exp(v[i] - mx);
+    return mx + std::log(s) - std::log((double)n);
+}
+
+// param::transform inverse transforms + log-Jacobians, parameters.h:317-457
+// kind: 0 null, 1 twice_fisher, 2 logit, 3 log  (enum order of parameters.h:27)
+double orc_inv_transform(int kind, double tp) {
+    switch (kind) {
+        case 0: return tp;
+        case 1: return (tp > 0) ? 2.0 / (1.0 + std::exp(-tp)) - 1.0 : 1.0 - 2.0 / (1.0 + std::exp(tp));
+        case 2: return (tp > 0) ? 1.0 / (1.0 + std::exp(-tp)) : std::exp(tp) / (1.0 + std::exp(tp));
+        default: return std::exp(tp);
+    }
+}
+double orc_log_jacobian(int kind, double tp) {
+    switch (kind) {
+        case 0: return 0.0;
+        case 1: return std::log(2.0) + tp - 2.0 * std::log(1.0 + std::exp(tp));
+        case 2: return -tp - 2.0 * std::log(1.0 + std::exp(-tp));
+        default: return tp;
+    }
+}
+
+// exact log-likelihood of the linear-Gaussian model by the Kalman filter (independent anchor)
+double orc_kalman_loglik(double phi, double sigma, double tau, const double* y, int T, double* per_step) {
+    double mean = 0.0, var = sigma * sigma / (1.0 - phi * phi), ll = 0.0;
+    for (int t = 0; t < T; ++t) {
+        if (t > 0) { mean = phi * mean; var = phi * phi * var + sigma * sigma; }
+        const double Sv = var + tau * tau;
+        const double l = -0.5 * std::log(2.0 * M_PI * Sv) - 0.5 * (y[t] - mean) * (y[t] - mean) / Sv;
+        if (per_step) per_step[t] = l;
+        ll += l;
+        const double K = var / Sv;
+        mean = mean + K * (y[t] - mean);
+        var = (1.0 - K) * var;
+    }
+    return ll;
+}
+
+}  // extern "C"
