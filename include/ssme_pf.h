@@ -1,0 +1,152 @@
+/* ssme_pf.h -- C ABI of the MI355X-native bootstrap-particle-filter core.
+ *
+ * Drop-in boundary for the hot path behind ssme's BSFilter<>::filter() step.  In the
+ * reference this boundary is compile-time C++ inheritance from the external `pf` library
+ * (no FFI exists): a model derives from pf::filters::BSFilter<nparts,dimx,dimy,resampT,
+ * float_t> (example/univ_svol_bootstrap_filter.h:18) and callers use
+ *     mod.filter(y_t);  logLike += mod.getLogCondLike();     example/estimate_univ_svol.h:124-125
+ *     mods[i].filter(y_t, z_t, fs); getExpectations(); getLogCondLike();
+ *                                                             include/ssme/pswarm_filter.h:86-92,380-388
+ * Host virtual callbacks cannot run per particle on a GPU, so the model is selected by
+ * enum and compiled into the kernels.  Plain pointers and sizes only; no C++/torch types.
+ * Every function returns an int status (0 = ok); nothing throws across this boundary.
+ * NaN / -inf log-likelihoods are VALUES, not errors (reference: ada_pmmh_mvn.h:349,357).
+ *
+ * Threading: re-entrant, no global mutable state.  One handle = one HIP stream; distinct
+ * handles may be used concurrently from distinct host threads (as thread_pool.h:242-245
+ * calls log_like_eval concurrently on distinct model objects); a single handle is not
+ * thread-safe (same as one BSFilter object).
+ */
+#ifndef SSME_PF_H
+#define SSME_PF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes */
+enum {
+    SSME_OK = 0,
+    SSME_ERR_INVALID_ARG = 1,   /* reference: std::invalid_argument                     */
+    SSME_ERR_LENGTH = 2,        /* reference: std::length_error (empty data, :113)      */
+    SSME_ERR_UNSUPPORTED = 3,   /* valid request this build does not implement          */
+    SSME_ERR_HIP = 4,           /* HIP runtime failure; text via ssme_pf_last_error     */
+    SSME_ERR_STATE = 5          /* call order (e.g. step before set_params)             */
+};
+
+/* models: per-particle callbacks compiled into the kernels */
+enum {
+    SSME_MODEL_SVOL = 0,          /* svol_bs, example/univ_svol_bootstrap_filter.h:55-103;
+                                     theta = (beta, phi, sigma)  [sigma = sqrt(ss), :58-60] */
+    SSME_MODEL_SVOL_LEVERAGE = 1, /* svol_leverage, test/test_pswarm.cpp:80-134;
+                                     theta = (phi, mu, sigma, rho); covariate z_t = y_{t-1} */
+    SSME_MODEL_LIN_GAUSS = 2      /* x' = phi x + sigma e, y ~ N(x, tau^2); theta = (phi, sigma, tau).
+                                     Not in the reference: exact-Kalman correctness anchor.  */
+};
+
+/* resamplers (pf::resamplers::*, in-tree twin include/ssme/liu_west_filter.h:91-145) */
+enum {
+    SSME_RESAMP_MULTINOMIAL = 0,     /* multinomial by sorted uniforms (exponential spacings),
+                                        the algorithm of liu_west_filter.h:105-139 / mn_resamp_fast1 */
+    SSME_RESAMP_SYSTEMATIC = 1,
+    SSME_RESAMP_STRATIFIED = 2,
+    SSME_RESAMP_MULTINOMIAL_IID = 3  /* multinomial with unsorted iid uniforms (mn_resampler form) */
+};
+
+enum { SSME_F64 = 0, SSME_F32 = 1 };
+
+/* built-in functionals h(x) for weighted expectations (std::function cannot run on device) */
+enum { SSME_H_X = 0, SSME_H_X2 = 1, SSME_H_VOL = 2 /* exp(x/2) */, SSME_H_CONST42 = 3 };
+
+typedef struct ssme_pf_s* ssme_pf_handle;
+
+typedef struct ssme_pf_config {
+    int32_t  model;            /* SSME_MODEL_*                                               */
+    int32_t  n_particles;      /* N per filter (reference: template parameter nparts)        */
+    int32_t  n_filters;        /* R independent filters/replicates held by this handle:
+                                  thread_pool's num_pfilters (thread_pool.h:189-215) or the
+                                  swarm's nparamparts (pswarm_filter.h:280-304)              */
+    int32_t  dtype;            /* SSME_F64                                                   */
+    int32_t  resampler;        /* SSME_RESAMP_*                                              */
+    int32_t  resamp_sched;     /* resample every k-th step; 1 = reference default            */
+    uint64_t seed;             /* Philox4x32-10 key (reference RNGs are clock-seeded)        */
+    int32_t  device;           /* HIP device ordinal                                         */
+    uint32_t first_filter_id;  /* global id of filter 0 of this handle; enters the Philox
+                                  counter, so sharding R over GPUs keeps every stream        */
+} ssme_pf_config;
+
+/* Allocates device state for R filters of N particles.  Replaces construction of the
+ * model object (estimate_univ_svol.h:119), but the handle is reusable across theta. */
+int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out);
+int ssme_pf_destroy(ssme_pf_handle h);
+
+/* UNTRANSFORMED parameters, as the reference's model ctors receive them from
+ * pack::get_untrans_params (univ_svol_bootstrap_filter.h:55-61).  theta is
+ * [n_rows][n_theta]; n_rows = 1 broadcasts one theta to all filters (PMMH replicates),
+ * n_rows = n_filters gives each filter its own row (swarm).  Also resets time to 0. */
+int ssme_pf_set_params(ssme_pf_handle h, const double* theta, int32_t n_theta, int32_t n_rows);
+
+/* Back to t = 0 with the current parameters (a fresh model object in the reference). */
+int ssme_pf_reset(ssme_pf_handle h);
+
+/* One filter() call on every filter of the handle: BSFilter::filter(y_t) /
+ * BSFilterWC::filter(y_t, z_t).  y: 1 value; z: 1 value or NULL.  logcondlike_out (R
+ * values, nullable) receives getLogCondLike() of each filter. */
+int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* logcondlike_out);
+
+/* The whole log_like_eval loop (estimate_univ_svol.h:121-127) for all R filters in one
+ * call: reset, T steps, sum of log p(y_t | y_{1:t-1}).  loglik_out: R values. */
+int ssme_pf_run_series(ssme_pf_handle h, const double* y, const double* z, int32_t T, double* loglik_out);
+
+/* Per-step log conditional likelihoods of the last run_series: out[r*T + t]. */
+int ssme_pf_get_per_step(ssme_pf_handle h, double* out, int32_t T);
+
+/* Accumulated log-likelihood since the last reset: R values. */
+int ssme_pf_get_loglik(ssme_pf_handle h, double* out);
+
+/* E[h(x_t) | y_{1:t}] with the pre-resampling weights of the last step
+ * (getExpectations(); twin liu_west_filter.h:1662-1683).  out: R values. */
+int ssme_pf_get_expectations(ssme_pf_handle h, int32_t functional, double* out);
+
+/* Replicate aggregation of thread_pool.h:263-268: log-mean-exp of the R log-likelihoods. */
+int ssme_pf_log_mean_exp(ssme_pf_handle h, double* out);
+
+/* Parity/debug: state of one filter after the last step.  Any pointer may be NULL.
+ * x, logw: N pre-resampling particles and log-weights; cdf: N tile-local inclusive
+ * weight sums; ancestors: N indices used by the last step (requires set_debug(1)). */
+int ssme_pf_download_state(ssme_pf_handle h, int32_t filter, double* x, double* logw, double* cdf,
+                           uint32_t* ancestors);
+int ssme_pf_download_scalars(ssme_pf_handle h, int32_t filter, double* max_logw, double* sum_w,
+                             double* tile_sums, double* tile_prefix);
+int ssme_pf_set_debug(ssme_pf_handle h, int32_t record_ancestors);
+
+/* Execution policy of run_series: 0 = eager launches, 1 = one hipGraph per series (default). */
+int ssme_pf_set_graph_mode(ssme_pf_handle h, int32_t mode);
+
+/* HIP-event time (ms) of the last run_series on the handle's stream (kernels only, the
+ * 8*T-byte upload of y and the 8*R-byte download of the result excluded). */
+int ssme_pf_last_elapsed_ms(ssme_pf_handle h, float* ms);
+
+/* Measurement aid for bench.py: runs a T-step series eagerly with a HIP event pair around
+ * every launch of each kernel; returns the mean launch duration (microseconds) and launch
+ * count per kernel.  kernel ids: 0 = propagate_weight (KA), 1 = normalize_scan (KR). */
+int ssme_pf_profile_series(ssme_pf_handle h, const double* y, const double* z, int32_t T,
+                           double* mean_us_out /*2*/, int32_t* launches_out /*2*/);
+
+/* Device-side primitives exposed for bit-parity tests against the oracle (n values). */
+int ssme_pf_test_math(int32_t device, int32_t fn /*0 exp,1 log,2 sin2pi,3 cos2pi,4 sqrt*/, const double* in,
+                      double* out, int64_t n);
+int ssme_pf_test_philox(int32_t device, const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4);
+int ssme_pf_test_rows_scan(int32_t device, const double* in, int32_t nrows, double* incl, double* excl,
+                           double* total);
+
+const char* ssme_pf_strerror(int status);
+const char* ssme_pf_last_error(ssme_pf_handle h);
+int ssme_pf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSME_PF_H */

@@ -1,0 +1,106 @@
+"""ctypes binding of the C ABI in include/ssme_pf.h (ssme_amd/libssme_pf.so).
+
+The library is the product; there is no CPU fallback.  If the shared object is missing or a
+HIP device is absent, calls raise (SsmeError / OSError) -- nothing routes through oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libssme_pf.so")
+
+# enums of include/ssme_pf.h
+OK, ERR_INVALID_ARG, ERR_LENGTH, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE = range(6)
+MODEL_SVOL, MODEL_SVOL_LEVERAGE, MODEL_LIN_GAUSS = 0, 1, 2
+RESAMP_MULTINOMIAL, RESAMP_SYSTEMATIC, RESAMP_STRATIFIED, RESAMP_MULTINOMIAL_IID = 0, 1, 2, 3
+F64, F32 = 0, 1
+H_X, H_X2, H_VOL, H_CONST42 = 0, 1, 2, 3
+
+EXPORTS = [
+    "ssme_pf_create", "ssme_pf_destroy", "ssme_pf_set_params", "ssme_pf_reset", "ssme_pf_step",
+    "ssme_pf_run_series", "ssme_pf_get_per_step", "ssme_pf_get_loglik", "ssme_pf_get_expectations",
+    "ssme_pf_log_mean_exp", "ssme_pf_download_state", "ssme_pf_download_scalars", "ssme_pf_set_debug",
+    "ssme_pf_set_graph_mode", "ssme_pf_last_elapsed_ms", "ssme_pf_profile_series", "ssme_pf_test_math",
+    "ssme_pf_test_philox", "ssme_pf_test_rows_scan", "ssme_pf_strerror", "ssme_pf_last_error",
+    "ssme_pf_version",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("n_particles", C.c_int32), ("n_filters", C.c_int32), ("dtype", C.c_int32),
+        ("resampler", C.c_int32), ("resamp_sched", C.c_int32), ("seed", C.c_uint64), ("device", C.c_int32),
+        ("first_filter_id", C.c_uint32),
+    ]
+
+
+class SsmeError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"ssme_pf status {status}: {msg}")
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise OSError(f"{SO_PATH} not built: run `python -m ssme_amd.build` (hipcc --offload-arch=gfx950); "
+                          "there is no CPU fallback")
+        L = C.CDLL(SO_PATH)
+        dp, u32p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
+        H = C.c_void_p
+        L.ssme_pf_create.argtypes = [C.POINTER(Config), C.POINTER(H)]
+        L.ssme_pf_destroy.argtypes = [H]
+        L.ssme_pf_set_params.argtypes = [H, dp, C.c_int32, C.c_int32]
+        L.ssme_pf_reset.argtypes = [H]
+        L.ssme_pf_step.argtypes = [H, dp, dp, dp]
+        L.ssme_pf_run_series.argtypes = [H, dp, dp, C.c_int32, dp]
+        L.ssme_pf_get_per_step.argtypes = [H, dp, C.c_int32]
+        L.ssme_pf_get_loglik.argtypes = [H, dp]
+        L.ssme_pf_get_expectations.argtypes = [H, C.c_int32, dp]
+        L.ssme_pf_log_mean_exp.argtypes = [H, dp]
+        L.ssme_pf_download_state.argtypes = [H, C.c_int32, dp, dp, dp, u32p]
+        L.ssme_pf_download_scalars.argtypes = [H, C.c_int32, dp, dp, dp, dp]
+        L.ssme_pf_set_debug.argtypes = [H, C.c_int32]
+        L.ssme_pf_set_graph_mode.argtypes = [H, C.c_int32]
+        L.ssme_pf_last_elapsed_ms.argtypes = [H, C.POINTER(C.c_float)]
+        L.ssme_pf_profile_series.argtypes = [H, dp, dp, C.c_int32, dp, i32p]
+        L.ssme_pf_test_math.argtypes = [C.c_int32, C.c_int32, dp, dp, C.c_int64]
+        L.ssme_pf_test_philox.argtypes = [C.c_int32, u32p, u32p, u32p]
+        L.ssme_pf_test_rows_scan.argtypes = [C.c_int32, dp, C.c_int32, dp, dp, dp]
+        L.ssme_pf_strerror.restype = C.c_char_p
+        L.ssme_pf_strerror.argtypes = [C.c_int]
+        L.ssme_pf_last_error.restype = C.c_char_p
+        L.ssme_pf_last_error.argtypes = [H]
+        L.ssme_pf_version.restype = C.c_int
+        for name in EXPORTS:
+            if name not in ("ssme_pf_strerror", "ssme_pf_last_error", "ssme_pf_version"):
+                getattr(L, name).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def u32ptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def check(status, handle=None):
+    if status != OK:
+        L = lib()
+        msg = L.ssme_pf_strerror(status).decode()
+        if handle is not None and status == ERR_HIP:
+            msg += " (" + L.ssme_pf_last_error(handle).decode() + ")"
+        raise SsmeError(status, msg)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

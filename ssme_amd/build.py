@@ -1,0 +1,43 @@
+"""Builds ssme_amd/libssme_pf.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libssme_pf.so")
+SOURCES = [os.path.join(CSRC, "pf_api.hip")]
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("pf_kernels.h", "ssme_math.h")] + [
+    os.path.join(os.path.dirname(HERE), "include", "ssme_pf.h")]
+
+# -ffp-contract=off: the libm-free math is a fixed IEEE operation sequence (explicit fma only)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False, extra=()):
+    if not force and not needs_build():
+        return SO
+    cmd = [hipcc()] + FLAGS + list(extra) + SOURCES + ["-o", SO]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,565 @@
+// pf_api.hip -- extern "C" boundary (include/ssme_pf.h) over the gfx950 kernels.
+// Host side of the drop-in: owns device buffers, the HIP stream, hipGraph of a series.
+// No torch types; no CPU fallback: without a HIP device every call fails with SSME_ERR_HIP.
+#include "../../include/ssme_pf.h"
+#include "pf_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace ssme;
+
+struct ssme_pf_s {
+    ssme_pf_config cfg;
+    int N, R, Npad, B, Bs, nrows2, Bpow2;
+    int t;                   // next time index
+    bool params_set;
+    bool last_step_finalized;
+    int debug_anc;
+    int graph_mode;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    float last_ms;
+    // device
+    double *xa, *xb, *logw, *cdf, *tile_sum, *tile_esum, *tile_max, *ybuf, *zbuf, *per_step, *scratchR;
+    uint32_t* anc;
+    FilterScalars* scal;
+    ModelConst* mc;
+    int cur;                 // which of xa/xb holds the latest particles
+    int ycap, tcap;
+    // graph cache
+    hipGraphExec_t gexec;
+    int g_T, g_has_z, g_debug;
+    std::vector<ModelConst> h_mc;
+    std::string err;
+};
+
+static int fail(ssme_pf_handle h, int code, const char* what, hipError_t e) {
+    if (h) { h->err = std::string(what) + ": " + hipGetErrorString(e); }
+    return code;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, SSME_ERR_HIP, #call, e_); } while (0)
+
+static int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+// Derived constants; operation order mirrors oracle/ssme_oracle.cpp derive().
+static ModelConst derive(int model, const double* th) {
+    ModelConst c{};
+    if (model == SSME_MODEL_SVOL) {            // (beta, phi, sigma)
+        const double beta = th[0], phi = th[1], sigma = th[2];
+        c.a0 = phi; c.a1 = sigma;
+        c.a2 = sigma / dsqrt(1.0 - phi * phi);
+        c.a3 = dlog(beta);
+        c.a4 = 1.0 / (beta * beta);
+        c.bad = !(beta > 0.0);
+    } else if (model == SSME_MODEL_SVOL_LEVERAGE) {   // (phi, mu, sigma, rho)
+        const double phi = th[0], mu = th[1], sigma = th[2], rho = th[3];
+        c.a0 = phi; c.a1 = mu;
+        c.a2 = sigma / dsqrt(1.0 - phi * phi);
+        c.a3 = sigma * dsqrt(1.0 - phi * phi);
+        c.a4 = rho * sigma;
+        c.bad = 0;
+    } else {                                    // (phi, sigma, tau)
+        const double phi = th[0], sigma = th[1], tau = th[2];
+        c.a0 = phi; c.a1 = sigma;
+        c.a2 = sigma / dsqrt(1.0 - phi * phi);
+        c.a3 = dlog(tau);
+        c.a4 = 1.0 / tau;
+        c.bad = !(tau > 0.0);
+    }
+    return c;
+}
+
+static int n_theta_of(int model) { return model == SSME_MODEL_SVOL_LEVERAGE ? 4 : 3; }
+
+static StepArgs base_args(ssme_pf_handle h) {
+    StepArgs a{};
+    a.logw = h->logw; a.cdf = h->cdf; a.anc = h->debug_anc ? h->anc : nullptr;
+    a.tile_sum = h->tile_sum; a.tile_esum = h->tile_esum; a.tile_max = h->tile_max;
+    a.scal = h->scal; a.mc = h->mc; a.y = h->ybuf; a.z = nullptr; a.per_step = nullptr;
+    a.N = h->N; a.Npad = h->Npad; a.B = h->B; a.Bs = h->Bs; a.nrows2 = h->nrows2; a.Bpow2 = h->Bpow2;
+    a.Tcap = h->tcap;
+    a.model = h->cfg.model; a.resampler = h->cfg.resampler; a.resamp_sched = h->cfg.resamp_sched;
+    a.key0 = (uint32_t)h->cfg.seed; a.key1 = (uint32_t)(h->cfg.seed >> 32); a.first_filter = h->cfg.first_filter_id;
+    a.logN = dlog((double)h->N);
+    return a;
+}
+
+static void launch_ka(ssme_pf_handle h, const StepArgs& a) {
+    dim3 grid(h->B, h->R), block(kThreads);
+    switch (h->cfg.model) {
+        case SSME_MODEL_SVOL: hipLaunchKernelGGL(ka_propagate_weight<MODEL_SVOL>, grid, block, 0, h->stream, a); break;
+        case SSME_MODEL_SVOL_LEVERAGE: hipLaunchKernelGGL(ka_propagate_weight<MODEL_SVOL_LEVERAGE>, grid, block, 0, h->stream, a); break;
+        default: hipLaunchKernelGGL(ka_propagate_weight<MODEL_LIN_GAUSS>, grid, block, 0, h->stream, a); break;
+    }
+}
+static void launch_kr(ssme_pf_handle h, const StepArgs& a) {
+    hipLaunchKernelGGL(kr_normalize_scan, dim3(h->B, h->R), dim3(kThreads), 0, h->stream, a);
+}
+static void launch_kf(ssme_pf_handle h, const StepArgs& a) {
+    hipLaunchKernelGGL(kf_finalize, dim3(h->R), dim3(kThreads), 0, h->stream, a);
+}
+
+// enqueue one filter step (KA, KR) at time index t reading y[yi]
+static void enqueue_step(ssme_pf_handle h, int t, int yi, bool has_z, bool finalize_prev, bool record_per_step) {
+    StepArgs a = base_args(h);
+    a.x_in = h->cur ? h->xb : h->xa;
+    a.x_out = h->cur ? h->xa : h->xb;
+    a.z = has_z ? h->zbuf : nullptr;
+    a.per_step = record_per_step ? h->per_step : nullptr;
+    a.t = t; a.yi = yi; a.finalize_prev = finalize_prev ? 1 : 0;
+    launch_ka(h, a);
+    launch_kr(h, a);
+    h->cur ^= 1;
+}
+
+static int ensure_series_capacity(ssme_pf_handle h, int T) {
+    if (T > h->ycap) {
+        if (h->ybuf) hipFree(h->ybuf);
+        if (h->zbuf) hipFree(h->zbuf);
+        h->ybuf = h->zbuf = nullptr;
+        HIPCHK(hipMalloc(&h->ybuf, sizeof(double) * T));
+        HIPCHK(hipMalloc(&h->zbuf, sizeof(double) * T));
+        h->ycap = T;
+        if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+    }
+    if (T > h->tcap) {
+        if (h->per_step) hipFree(h->per_step);
+        h->per_step = nullptr;
+        HIPCHK(hipMalloc(&h->per_step, sizeof(double) * (size_t)T * h->R));
+        h->tcap = T;
+        if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+    }
+    return SSME_OK;
+}
+
+static int do_reset(ssme_pf_handle h) {
+    std::vector<FilterScalars> sc(h->R);
+    const double logN = dlog((double)h->N);
+    for (auto& s : sc) { std::memset(&s, 0, sizeof(s)); s.prev = logN; }
+    HIPCHK(hipMemcpyAsync(h->scal, sc.data(), sizeof(FilterScalars) * h->R, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));   // sc is a stack/heap temporary
+    h->t = 0; h->cur = 0; h->last_step_finalized = true;
+    return SSME_OK;
+}
+
+extern "C" {
+
+int ssme_pf_version(void) { return 100; }
+
+const char* ssme_pf_strerror(int s) {
+    switch (s) {
+        case SSME_OK: return "ok";
+        case SSME_ERR_INVALID_ARG: return "invalid argument";
+        case SSME_ERR_LENGTH: return "length error (empty data)";
+        case SSME_ERR_UNSUPPORTED: return "unsupported configuration";
+        case SSME_ERR_HIP: return "HIP runtime error";
+        case SSME_ERR_STATE: return "invalid call order";
+        default: return "unknown status";
+    }
+}
+const char* ssme_pf_last_error(ssme_pf_handle h) { return h ? h->err.c_str() : ""; }
+
+int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) {
+    if (!cfg || !out) return SSME_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->n_particles < 1 || cfg->n_filters < 1 || cfg->n_filters > 65535) return SSME_ERR_INVALID_ARG;
+    if (cfg->model < 0 || cfg->model > SSME_MODEL_LIN_GAUSS) return SSME_ERR_INVALID_ARG;
+    if (cfg->resampler < 0 || cfg->resampler > SSME_RESAMP_MULTINOMIAL_IID) return SSME_ERR_INVALID_ARG;
+    if (cfg->resamp_sched < 1) return SSME_ERR_INVALID_ARG;
+    if (cfg->dtype != SSME_F64) return SSME_ERR_UNSUPPORTED;
+    const int B = (cfg->n_particles + kTile - 1) / kTile;
+    if (B > kMaxTilesPerFilter) return SSME_ERR_UNSUPPORTED;   // N <= 2^22 per filter per GPU
+    ssme_pf_handle h = new (std::nothrow) ssme_pf_s();
+    if (!h) return SSME_ERR_INVALID_ARG;
+    h->cfg = *cfg;
+    h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * kTile;
+    h->nrows2 = (B + kRow - 1) / kRow; h->Bs = h->nrows2 * kRow; h->Bpow2 = next_pow2(B);
+    h->graph_mode = 1;
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) { delete h; return SSME_ERR_HIP; }
+    int rc = [&]() -> int {
+        HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&h->ev0));
+        HIPCHK(hipEventCreate(&h->ev1));
+        const size_t np = (size_t)h->R * h->Npad, nb = (size_t)h->R * h->Bs;
+        HIPCHK(hipMalloc(&h->xa, sizeof(double) * np));
+        HIPCHK(hipMalloc(&h->xb, sizeof(double) * np));
+        HIPCHK(hipMalloc(&h->logw, sizeof(double) * np));
+        HIPCHK(hipMalloc(&h->cdf, sizeof(double) * np));
+        HIPCHK(hipMalloc(&h->tile_sum, sizeof(double) * nb));
+        HIPCHK(hipMalloc(&h->tile_esum, sizeof(double) * nb));
+        HIPCHK(hipMalloc(&h->tile_max, sizeof(double) * nb));
+        HIPCHK(hipMalloc(&h->scal, sizeof(FilterScalars) * h->R));
+        HIPCHK(hipMalloc(&h->mc, sizeof(ModelConst) * h->R));
+        HIPCHK(hipMalloc(&h->scratchR, sizeof(double) * h->R));
+        HIPCHK(hipMemset(h->xa, 0, sizeof(double) * np));
+        HIPCHK(hipMemset(h->xb, 0, sizeof(double) * np));
+        HIPCHK(hipMemset(h->logw, 0, sizeof(double) * np));
+        HIPCHK(hipMemset(h->cdf, 0, sizeof(double) * np));
+        HIPCHK(hipMemset(h->tile_sum, 0, sizeof(double) * nb));
+        HIPCHK(hipMemset(h->tile_esum, 0, sizeof(double) * nb));
+        HIPCHK(hipMemset(h->tile_max, 0, sizeof(double) * nb));
+        return ensure_series_capacity(h, 1);
+    }();
+    if (rc != SSME_OK) { ssme_pf_destroy(h); return rc; }
+    *out = h;
+    return SSME_OK;
+}
+
+int ssme_pf_destroy(ssme_pf_handle h) {
+    if (!h) return SSME_ERR_INVALID_ARG;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->gexec) hipGraphExecDestroy(h->gexec);
+    void* bufs[] = {h->xa, h->xb, h->logw, h->cdf, h->tile_sum, h->tile_esum, h->tile_max, h->ybuf, h->zbuf,
+                    h->per_step, h->scratchR, h->anc, h->scal, h->mc};
+    for (void* p : bufs) if (p) hipFree(p);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return SSME_OK;
+}
+
+int ssme_pf_set_params(ssme_pf_handle h, const double* theta, int32_t n_theta, int32_t n_rows) {
+    if (!h || !theta) return SSME_ERR_INVALID_ARG;
+    if (n_theta != n_theta_of(h->cfg.model)) return SSME_ERR_INVALID_ARG;
+    if (n_rows != 1 && n_rows != h->R) return SSME_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    h->h_mc.resize(h->R);
+    for (int r = 0; r < h->R; ++r) h->h_mc[r] = derive(h->cfg.model, theta + (size_t)(n_rows == 1 ? 0 : r) * n_theta);
+    HIPCHK(hipMemcpyAsync(h->mc, h->h_mc.data(), sizeof(ModelConst) * h->R, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->params_set = true;
+    return do_reset(h);
+}
+
+int ssme_pf_reset(ssme_pf_handle h) {
+    if (!h) return SSME_ERR_INVALID_ARG;
+    if (!h->params_set) return SSME_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    return do_reset(h);
+}
+
+int ssme_pf_set_debug(ssme_pf_handle h, int32_t record_ancestors) {
+    if (!h) return SSME_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (record_ancestors && !h->anc) {
+        HIPCHK(hipMalloc(&h->anc, sizeof(uint32_t) * (size_t)h->R * h->Npad));
+        HIPCHK(hipMemset(h->anc, 0, sizeof(uint32_t) * (size_t)h->R * h->Npad));
+    }
+    h->debug_anc = record_ancestors ? 1 : 0;
+    return SSME_OK;
+}
+
+int ssme_pf_set_graph_mode(ssme_pf_handle h, int32_t mode) {
+    if (!h || mode < 0 || mode > 1) return SSME_ERR_INVALID_ARG;
+    h->graph_mode = mode;
+    return SSME_OK;
+}
+
+int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out) {
+    if (!h || !y) return SSME_ERR_INVALID_ARG;
+    if (!h->params_set) return SSME_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (z) HIPCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    enqueue_step(h, h->t, 0, z != nullptr, /*finalize_prev=*/false, /*per_step=*/false);
+    StepArgs a = base_args(h);
+    a.t = h->t;
+    launch_kf(h, a);
+    HIPCHK(hipGetLastError());
+    h->t += 1;
+    if (out) {
+        std::vector<FilterScalars> sc(h->R);
+        HIPCHK(hipMemcpyAsync(sc.data(), h->scal, sizeof(FilterScalars) * h->R, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int r = 0; r < h->R; ++r) out[r] = sc[r].last_ll;
+    } else {
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return SSME_OK;
+}
+
+static void enqueue_series(ssme_pf_handle h, int T, bool has_z) {
+    for (int t = 0; t < T; ++t) enqueue_step(h, t, t, has_z, /*finalize_prev=*/t > 0, /*per_step=*/true);
+    StepArgs a = base_args(h);
+    a.t = T - 1; a.per_step = h->per_step;
+    launch_kf(h, a);
+}
+
+int ssme_pf_run_series(ssme_pf_handle h, const double* y, const double* z, int32_t T, double* loglik_out) {
+    if (!h || !y) return SSME_ERR_INVALID_ARG;
+    if (T < 1) return SSME_ERR_LENGTH;
+    if (!h->params_set) return SSME_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = ensure_series_capacity(h, T);
+    if (rc != SSME_OK) return rc;
+    HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    if (z) HIPCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    rc = do_reset(h);
+    if (rc != SSME_OK) return rc;
+    const bool has_z = z != nullptr;
+    if (h->graph_mode) {
+        if (!h->gexec || h->g_T != T || h->g_has_z != (int)has_z || h->g_debug != h->debug_anc) {
+            if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            h->cur = 0;
+            enqueue_series(h, T, has_z);
+            HIPCHK(hipStreamEndCapture(h->stream, &g));
+            HIPCHK(hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0));
+            HIPCHK(hipGraphDestroy(g));
+            h->g_T = T; h->g_has_z = has_z; h->g_debug = h->debug_anc;
+        }
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        HIPCHK(hipGraphLaunch(h->gexec, h->stream));
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        h->cur = (T & 1);
+    } else {
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        h->cur = 0;
+        enqueue_series(h, T, has_z);
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+    }
+    HIPCHK(hipGetLastError());
+    h->t = T;
+    std::vector<FilterScalars> sc(h->R);
+    HIPCHK(hipMemcpyAsync(sc.data(), h->scal, sizeof(FilterScalars) * h->R, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    if (loglik_out) for (int r = 0; r < h->R; ++r) loglik_out[r] = sc[r].loglik;
+    return SSME_OK;
+}
+
+int ssme_pf_get_per_step(ssme_pf_handle h, double* out, int32_t T) {
+    if (!h || !out || T < 1 || T > h->tcap) return SSME_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    // device layout is [R][tcap]; return [R][T]
+    for (int r = 0; r < h->R; ++r)
+        HIPCHK(hipMemcpyAsync(out + (size_t)r * T, h->per_step + (size_t)r * h->tcap, sizeof(double) * T,
+                              hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SSME_OK;
+}
+
+int ssme_pf_get_loglik(ssme_pf_handle h, double* out) {
+    if (!h || !out) return SSME_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    std::vector<FilterScalars> sc(h->R);
+    HIPCHK(hipMemcpyAsync(sc.data(), h->scal, sizeof(FilterScalars) * h->R, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int r = 0; r < h->R; ++r) out[r] = sc[r].loglik;
+    return SSME_OK;
+}
+
+int ssme_pf_log_mean_exp(ssme_pf_handle h, double* out) {
+    if (!h || !out) return SSME_ERR_INVALID_ARG;
+    std::vector<double> ll(h->R);
+    int rc = ssme_pf_get_loglik(h, ll.data());
+    if (rc != SSME_OK) return rc;
+    // thread_pool.h:263-268, host side (R is small): m + log(sum exp(v - m)) - log R
+    double m = ll[0];
+    for (double v : ll) if (v > m) m = v;
+    double s = 0.0;
+    for (double v : ll) s += std::exp(v - m);
+    *out = m + std::log(s) - std::log((double)h->R);
+    return SSME_OK;
+}
+
+int ssme_pf_get_expectations(ssme_pf_handle h, int32_t functional, double* out) {
+    if (!h || !out || functional < 0 || functional > SSME_H_CONST42) return SSME_ERR_INVALID_ARG;
+    if (h->t < 1) return SSME_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const double* x = h->cur ? h->xb : h->xa;
+    hipLaunchKernelGGL(k_expectation, dim3(h->R), dim3(kThreads), 0, h->stream, x, h->logw, h->scal, h->N, h->Npad,
+                       functional, h->scratchR);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, h->scratchR, sizeof(double) * h->R, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SSME_OK;
+}
+
+int ssme_pf_download_state(ssme_pf_handle h, int32_t f, double* x, double* logw, double* cdf, uint32_t* anc) {
+    if (!h || f < 0 || f >= h->R) return SSME_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const double* xs = h->cur ? h->xb : h->xa;
+    const size_t off = (size_t)f * h->Npad;
+    if (x) HIPCHK(hipMemcpyAsync(x, xs + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (logw) HIPCHK(hipMemcpyAsync(logw, h->logw + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (cdf) HIPCHK(hipMemcpyAsync(cdf, h->cdf + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (anc) {
+        if (!h->anc) return SSME_ERR_STATE;
+        HIPCHK(hipMemcpyAsync(anc, h->anc + off, sizeof(uint32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SSME_OK;
+}
+
+// tile_prefix (exclusive level-2 prefixes) is recomputed on the host with the canonical tree
+// only for parity inspection; pass NULL to skip.
+int ssme_pf_download_scalars(ssme_pf_handle h, int32_t f, double* max_logw, double* sum_w, double* tile_sums,
+                             double* tile_prefix) {
+    if (!h || f < 0 || f >= h->R) return SSME_ERR_INVALID_ARG;
+    if (tile_prefix) return SSME_ERR_UNSUPPORTED;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    FilterScalars sc;
+    HIPCHK(hipMemcpyAsync(&sc, h->scal + f, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
+    if (tile_sums) HIPCHK(hipMemcpyAsync(tile_sums, h->tile_sum + (size_t)f * h->Bs, sizeof(double) * h->B,
+                                         hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (max_logw) *max_logw = sc.m;
+    if (sum_w) *sum_w = sc.S;
+    return SSME_OK;
+}
+
+int ssme_pf_last_elapsed_ms(ssme_pf_handle h, float* ms) {
+    if (!h || !ms) return SSME_ERR_INVALID_ARG;
+    *ms = h->last_ms;
+    return SSME_OK;
+}
+
+int ssme_pf_profile_series(ssme_pf_handle h, const double* y, const double* z, int32_t T, double* mean_us,
+                           int32_t* launches) {
+    if (!h || !y || !mean_us || !launches) return SSME_ERR_INVALID_ARG;
+    if (T < 1) return SSME_ERR_LENGTH;
+    if (!h->params_set) return SSME_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = ensure_series_capacity(h, T);
+    if (rc != SSME_OK) return rc;
+    HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    if (z) HIPCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    rc = do_reset(h);
+    if (rc != SSME_OK) return rc;
+    std::vector<hipEvent_t> ev((size_t)3 * T);
+    for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+    const bool has_z = z != nullptr;
+    h->cur = 0;
+    for (int t = 0; t < T; ++t) {
+        StepArgs a = base_args(h);
+        a.x_in = h->cur ? h->xb : h->xa;
+        a.x_out = h->cur ? h->xa : h->xb;
+        a.z = has_z ? h->zbuf : nullptr;
+        a.t = t; a.yi = t; a.finalize_prev = t > 0;
+        HIPCHK(hipEventRecord(ev[3 * t + 0], h->stream));
+        launch_ka(h, a);
+        HIPCHK(hipEventRecord(ev[3 * t + 1], h->stream));
+        launch_kr(h, a);
+        HIPCHK(hipEventRecord(ev[3 * t + 2], h->stream));
+        h->cur ^= 1;
+    }
+    StepArgs a = base_args(h);
+    a.t = T - 1;
+    launch_kf(h, a);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double sa = 0, sr = 0;
+    for (int t = 0; t < T; ++t) {
+        float m1 = 0, m2 = 0;
+        HIPCHK(hipEventElapsedTime(&m1, ev[3 * t], ev[3 * t + 1]));
+        HIPCHK(hipEventElapsedTime(&m2, ev[3 * t + 1], ev[3 * t + 2]));
+        sa += m1; sr += m2;
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    mean_us[0] = sa * 1000.0 / T; mean_us[1] = sr * 1000.0 / T;
+    launches[0] = T; launches[1] = T;
+    h->t = T;
+    return SSME_OK;
+}
+
+// ---- device primitives for bit-parity tests ------------------------------------------------
+__global__ void k_test_math(int fn, const double* in, double* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = in[i];
+    double r, s, c;
+    switch (fn) {
+        case 0: r = dexp(x); break;
+        case 1: r = dlog(x); break;
+        case 2: dsincos2pi(x, &s, &c); r = s; break;
+        case 3: dsincos2pi(x, &s, &c); r = c; break;
+        default: r = dsqrt(x); break;
+    }
+    out[i] = r;
+}
+__global__ void k_test_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+    const u32x4 o = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    out[0] = o.v0; out[1] = o.v1; out[2] = o.v2; out[3] = o.v3;
+}
+__global__ __launch_bounds__(kThreads) void k_test_rows_scan(const double* in, int nrows, double* incl, double* excl, double* total) {
+    __shared__ double lds_w[16];
+    const int tid = threadIdx.x;
+    double v[4][2];
+    for (int k = 0; k < 4; ++k) {
+        v[k][0] = k < nrows ? in[k * kRow + 2 * tid] : 0.0;
+        v[k][1] = k < nrows ? in[k * kRow + 2 * tid + 1] : 0.0;
+    }
+    Rows2 rs;
+    block_rows_scan_rt(v, nrows, rs, lds_w);
+    for (int k = 0; k < nrows; ++k) {
+        incl[k * kRow + 2 * tid] = rs.base[k] + rs.s0[k];
+        incl[k * kRow + 2 * tid + 1] = rs.base[k] + rs.s1[k];
+        excl[k * kRow + 2 * tid] = rs.base[k];
+        excl[k * kRow + 2 * tid + 1] = rs.base[k] + rs.s0[k];
+    }
+    if (tid == 0) *total = rs.total;
+}
+
+#define HIPCHK0(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = SSME_ERR_HIP; goto done; } } while (0)
+
+int ssme_pf_test_math(int32_t device, int32_t fn, const double* in, double* out, int64_t n) {
+    if (!in || !out || n < 1) return SSME_ERR_INVALID_ARG;
+    int rc = SSME_OK;
+    double *din = nullptr, *dout = nullptr;
+    HIPCHK0(hipSetDevice(device));
+    HIPCHK0(hipMalloc(&din, sizeof(double) * n));
+    HIPCHK0(hipMalloc(&dout, sizeof(double) * n));
+    HIPCHK0(hipMemcpy(din, in, sizeof(double) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, fn, din, dout, (long)n);
+    HIPCHK0(hipGetLastError());
+    HIPCHK0(hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost));
+done:
+    if (din) hipFree(din);
+    if (dout) hipFree(dout);
+    return rc;
+}
+
+int ssme_pf_test_philox(int32_t device, const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4) {
+    if (!ctr4 || !key2 || !out4) return SSME_ERR_INVALID_ARG;
+    int rc = SSME_OK;
+    uint32_t* d = nullptr;
+    HIPCHK0(hipSetDevice(device));
+    HIPCHK0(hipMalloc(&d, sizeof(uint32_t) * 10));
+    HIPCHK0(hipMemcpy(d, ctr4, 16, hipMemcpyHostToDevice));
+    HIPCHK0(hipMemcpy(d + 4, key2, 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_philox, dim3(1), dim3(1), 0, 0, d, d + 4, d + 6);
+    HIPCHK0(hipGetLastError());
+    HIPCHK0(hipMemcpy(out4, d + 6, 16, hipMemcpyDeviceToHost));
+done:
+    if (d) hipFree(d);
+    return rc;
+}
+
+int ssme_pf_test_rows_scan(int32_t device, const double* in, int32_t nrows, double* incl, double* excl, double* total) {
+    if (!in || !incl || !excl || !total || nrows < 1 || nrows > 4) return SSME_ERR_INVALID_ARG;
+    int rc = SSME_OK;
+    const size_t n = (size_t)nrows * kRow;
+    double* d = nullptr;
+    HIPCHK0(hipSetDevice(device));
+    HIPCHK0(hipMalloc(&d, sizeof(double) * (3 * n + 1)));
+    HIPCHK0(hipMemcpy(d, in, sizeof(double) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_rows_scan, dim3(1), dim3(kThreads), 0, 0, d, nrows, d + n, d + 2 * n, d + 3 * n);
+    HIPCHK0(hipGetLastError());
+    HIPCHK0(hipMemcpy(incl, d + n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK0(hipMemcpy(excl, d + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK0(hipMemcpy(total, d + 3 * n, sizeof(double), hipMemcpyDeviceToHost));
+done:
+    if (d) hipFree(d);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+// ssme_math.h -- Philox4x32-10 and libm-free fp64 elementary functions for gfx950.
+//
+// Every function is a fixed sequence of IEEE-754 binary64 operations (+ - * fma, correctly
+// rounded sqrt and division) plus integer bit moves, so the same source gives the same bits
+// in device code and in this library's host code (derived model constants).  The operation
+// order is the specification; build with -ffp-contract=off.
+//   exp   : Cody-Waite reduction by ln2 (hi/lo), Taylor degree 13 on |r| <= ln2/2
+//   log   : frexp to [sqrt(1/2), sqrt(2)), s = f/(2+f), degree-7 even polynomial (fdlibm form)
+//   sincos: exact octant reduction of 4u, then the fdlibm sine/cosine kernels on r*pi/2
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SSME_HD __host__ __device__ __forceinline__
+
+namespace ssme {
+
+SSME_HD double bits2d(uint64_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __longlong_as_double((long long)u);
+#else
+    double d; __builtin_memcpy(&d, &u, 8); return d;
+#endif
+}
+SSME_HD uint64_t d2bits(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint64_t)__double_as_longlong(d);
+#else
+    uint64_t u; __builtin_memcpy(&u, &d, 8); return u;
+#endif
+}
+SSME_HD double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+SSME_HD double dinf() { return bits2d(0x7ff0000000000000ull); }
+SSME_HD double dnan() { return bits2d(0x7ff8000000000000ull); }
+SSME_HD double pow2i(int n) { return bits2d((uint64_t)(n + 1023) << 52); }
+
+// ---- Philox4x32-10 -------------------------------------------------------------------
+struct u32x4 { uint32_t v0, v1, v2, v3; };
+
+SSME_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+SSME_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        if (r) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+SSME_HD uint64_t bits53(uint32_t a, uint32_t b) { return ((uint64_t)a << 21) | (uint64_t)(b >> 11); }
+SSME_HD double u01_co(uint32_t a, uint32_t b) { return (double)bits53(a, b) * 0x1.0p-53; }        // [0,1)
+SSME_HD double u01_oc(uint32_t a, uint32_t b) { return (double)(bits53(a, b) + 1) * 0x1.0p-53; }  // (0,1]
+
+enum { STREAM_PROP = 0, STREAM_RESAMP = 1, STREAM_RESAMP_EXTRA = 2 };
+
+// ---- exp -----------------------------------------------------------------------------
+SSME_HD double dexp(double x) {
+    const double LOG2E = 1.4426950408889634074;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double SH = 6755399441055744.0;  // 1.5 * 2^52
+    // clamp keeps k in range; the true range checks are applied at the end
+    const double xc = x > 710.0 ? 710.0 : (x < -746.0 ? -746.0 : x);
+    const double kf = (xc * LOG2E + SH) - SH;
+    const int k = (int)kf;
+    double r = dfma(-kf, LN2_HI, xc);
+    r = dfma(-kf, LN2_LO, r);
+    double q = 1.6059043836821613e-10;
+    q = dfma(q, r, 2.08767569878681e-09);
+    q = dfma(q, r, 2.505210838544172e-08);
+    q = dfma(q, r, 2.755731922398589e-07);
+    q = dfma(q, r, 2.7557319223985893e-06);
+    q = dfma(q, r, 2.48015873015873e-05);
+    q = dfma(q, r, 0.0001984126984126984);
+    q = dfma(q, r, 0.001388888888888889);
+    q = dfma(q, r, 0.008333333333333333);
+    q = dfma(q, r, 0.041666666666666664);
+    q = dfma(q, r, 0.16666666666666666);
+    q = dfma(q, r, 0.5);
+    const double e = dfma(r * r, q, r);
+    const double p = 1.0 + e;
+    const int k1 = k / 2, k2 = k - k1;
+    double res = (p * pow2i(k1)) * pow2i(k2);
+    if (x > 709.782712893384) res = dinf();
+    if (x < -745.1332191019412) res = 0.0;
+    if (x != x) res = x;
+    return res;
+}
+
+// ---- log -----------------------------------------------------------------------------
+SSME_HD double dlog(double x) {
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    int k = 0;
+    double xs = x;
+    uint64_t ux = d2bits(xs);
+    if ((ux >> 52) == 0) { xs = xs * 0x1.0p54; k -= 54; ux = d2bits(xs); }   // subnormal (or +0)
+    uint32_t hx = (uint32_t)(ux >> 32);
+    k += (int)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    const uint32_t i = (hx + 0x95f64u) & 0x100000u;
+    ux = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffull);
+    k += (int)(i >> 20);
+    const double m = bits2d(ux);
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double hfsq = (0.5 * f) * f;
+    double res = dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+    if (x == dinf()) res = x;
+    if (x == 0.0) res = -dinf();
+    if (x < 0.0) res = dnan();
+    if (x != x) res = x;
+    return res;
+}
+
+// ---- sin(2 pi u), cos(2 pi u), u in [0,1) -----------------------------------------------
+SSME_HD void dsincos2pi(double u, double* sn, double* cs) {
+    const double SH = 6755399441055744.0;
+    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double t = 4.0 * u;
+    const double qf = (t + SH) - SH;
+    const int q = (int)qf;
+    const double r = t - qf;
+    const double a = r * PIO2_HI;
+    const double al = dfma(r, PIO2_HI, -a) + r * PIO2_LO;
+    const double z = a * a;
+    const double v = z * a;
+    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double s0 = a - ((z * (0.5 * al - v * rs) - al) - v * S1);
+    const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double hz = 0.5 * z;
+    const double wv = 1.0 - hz;
+    const double c0 = wv + (((1.0 - wv) - hz) + (z * rc - a * al));
+    const int qq = q & 3;
+    const double ss = (qq & 1) ? c0 : s0;
+    const double cc = (qq & 1) ? s0 : c0;
+    *sn = (qq & 2) ? -ss : ss;
+    *cs = ((qq + 1) & 2) ? -cc : cc;
+}
+
+SSME_HD double dsqrt(double x) { return __builtin_sqrt(x); }
+
+}  // namespace ssme

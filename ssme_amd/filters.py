@@ -1,0 +1,203 @@
+"""Host-side mirror of the reference's filter interface for the GPU core.
+
+Names and argument meaning follow the reference so that parity tests read like its own:
+  svol_bs(phi, beta, sigma) / svol_bs.from_pack(pp)      example/univ_svol_bootstrap_filter.h:34-35,46-61
+  .filter(y) / .getLogCondLike()                         example/estimate_univ_svol.h:124-125
+  svol_leverage(phi, mu, sigma, rho).filter(y, z)        test/test_pswarm.cpp:33-76
+  .getExpectations()                                     include/ssme/pswarm_filter.h:87-89
+  log_like_eval(theta, data)                             example/estimate_univ_svol.h:108-131
+Every call goes through the C ABI (include/ssme_pf.h); there is no CPU path in this package.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import (MODEL_LIN_GAUSS, MODEL_SVOL, MODEL_SVOL_LEVERAGE, RESAMP_MULTINOMIAL, RESAMP_MULTINOMIAL_IID,
+                    RESAMP_STRATIFIED, RESAMP_SYSTEMATIC, SsmeError)
+
+__all__ = ["ParticleFilterBank", "svol_bs", "svol_leverage", "lin_gauss_bs", "log_like_eval",
+           "MODEL_SVOL", "MODEL_SVOL_LEVERAGE", "MODEL_LIN_GAUSS", "RESAMP_MULTINOMIAL", "RESAMP_SYSTEMATIC",
+           "RESAMP_STRATIFIED", "RESAMP_MULTINOMIAL_IID", "SsmeError"]
+
+
+class ParticleFilterBank:
+    """R independent bootstrap filters of N particles on one GPU (one C-ABI handle).
+
+    R plays the role of thread_pool's num_pfilters (include/ssme/thread_pool.h:189-215) or of
+    the swarm's nparamparts (include/ssme/pswarm_filter.h:280-304).
+    """
+
+    def __init__(self, model, n_particles, n_filters=1, seed=0, resampler=RESAMP_MULTINOMIAL, resamp_sched=1,
+                 device=0, first_filter_id=0):
+        self._h = C.c_void_p()
+        self.model, self.n, self.r = int(model), int(n_particles), int(n_filters)
+        self._last_T = 0
+        cfg = capi.Config(model=model, n_particles=n_particles, n_filters=n_filters, dtype=capi.F64,
+                          resampler=resampler, resamp_sched=resamp_sched, seed=seed, device=device,
+                          first_filter_id=first_filter_id)
+        capi.check(capi.lib().ssme_pf_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            capi.lib().ssme_pf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _chk(self, status):
+        capi.check(status, self._h)
+
+    def set_params(self, theta):
+        """theta: (n_theta,) shared by all filters or (R, n_theta); untransformed parameters."""
+        th = capi.as_f64(theta)
+        rows = 1 if th.ndim == 1 else th.shape[0]
+        self._chk(capi.lib().ssme_pf_set_params(self._h, capi.dptr(th), th.shape[-1], rows))
+
+    def reset(self):
+        self._chk(capi.lib().ssme_pf_reset(self._h))
+
+    def set_debug(self, record_ancestors=True):
+        self._chk(capi.lib().ssme_pf_set_debug(self._h, int(record_ancestors)))
+
+    def set_graph_mode(self, on=True):
+        self._chk(capi.lib().ssme_pf_set_graph_mode(self._h, int(on)))
+
+    def step(self, y, z=None):
+        """One filter(y[, z]) on every filter; returns the R log conditional likelihoods."""
+        yv = np.array([y], dtype=np.float64)
+        zv = None if z is None else np.array([z], dtype=np.float64)
+        out = np.empty(self.r)
+        self._chk(capi.lib().ssme_pf_step(self._h, capi.dptr(yv), capi.dptr(zv), capi.dptr(out)))
+        return out
+
+    def run_series(self, y, z=None):
+        """The log_like_eval loop for all R filters; returns R log-likelihoods."""
+        yv = capi.as_f64(y)
+        zv = None if z is None else capi.as_f64(z)
+        out = np.empty(self.r)
+        self._chk(capi.lib().ssme_pf_run_series(self._h, capi.dptr(yv), capi.dptr(zv), yv.size, capi.dptr(out)))
+        self._last_T = yv.size
+        return out
+
+    def per_step(self):
+        T = self._last_T
+        out = np.empty((self.r, T))
+        self._chk(capi.lib().ssme_pf_get_per_step(self._h, capi.dptr(out), T))
+        return out
+
+    def loglik(self):
+        out = np.empty(self.r)
+        self._chk(capi.lib().ssme_pf_get_loglik(self._h, capi.dptr(out)))
+        return out
+
+    def log_mean_exp(self):
+        out = np.empty(1)
+        self._chk(capi.lib().ssme_pf_log_mean_exp(self._h, capi.dptr(out)))
+        return float(out[0])
+
+    def expectations(self, functional):
+        out = np.empty(self.r)
+        self._chk(capi.lib().ssme_pf_get_expectations(self._h, functional, capi.dptr(out)))
+        return out
+
+    def state(self, f=0, ancestors=False):
+        n = self.n
+        x, lw, cdf = np.empty(n), np.empty(n), np.empty(n)
+        anc = np.empty(n, dtype=np.uint32) if ancestors else None
+        self._chk(capi.lib().ssme_pf_download_state(self._h, f, capi.dptr(x), capi.dptr(lw), capi.dptr(cdf),
+                                                    capi.u32ptr(anc)))
+        nt = (n + 2047) // 2048
+        m, s, A = np.empty(1), np.empty(1), np.empty(nt)
+        self._chk(capi.lib().ssme_pf_download_scalars(self._h, f, capi.dptr(m), capi.dptr(s), capi.dptr(A), None))
+        return dict(x=x, logw=lw, cdf=cdf, anc=anc, m=float(m[0]), S=float(s[0]), A=A)
+
+    def last_elapsed_ms(self):
+        ms = C.c_float()
+        self._chk(capi.lib().ssme_pf_last_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def profile_series(self, y, z=None):
+        yv = capi.as_f64(y)
+        zv = None if z is None else capi.as_f64(z)
+        us = np.empty(2)
+        cnt = np.zeros(2, dtype=np.int32)
+        self._chk(capi.lib().ssme_pf_profile_series(self._h, capi.dptr(yv), capi.dptr(zv), yv.size, capi.dptr(us),
+                                                    cnt.ctypes.data_as(C.POINTER(C.c_int32))))
+        return {"propagate_weight_us": float(us[0]), "normalize_scan_us": float(us[1]), "launches": int(cnt[0])}
+
+
+class _SingleFilter:
+    """One model object with the reference's call surface: filter(), getLogCondLike()."""
+    _model = None
+
+    def __init__(self, theta, nparts, seed=0, resampler=RESAMP_MULTINOMIAL, rs=1, device=0):
+        self._bank = ParticleFilterBank(self._model, nparts, 1, seed, resampler, rs, device)
+        self._bank.set_params(theta)
+        self._last = 0.0
+        self._fs = ()
+
+    def filter(self, y, z=None, fs=()):
+        self._fs = tuple(fs)
+        self._last = float(self._bank.step(float(np.ravel(y)[0]), None if z is None else float(np.ravel(z)[0]))[0])
+
+    def getLogCondLike(self):
+        return self._last
+
+    def getExpectations(self):
+        """fs given to filter() are SSME_H_* enums (std::function cannot run on device)."""
+        return [float(self._bank.expectations(f)[0]) for f in self._fs]
+
+    @property
+    def bank(self):
+        return self._bank
+
+
+class svol_bs(_SingleFilter):
+    """example/univ_svol_bootstrap_filter.h:17-103. Ctor order (phi, beta, sigma) as :34."""
+    _model = MODEL_SVOL
+
+    def __init__(self, phi, beta, sigma, nparts=500, **kw):
+        super().__init__([beta, phi, sigma], nparts, **kw)
+
+    @classmethod
+    def from_pack(cls, untrans_params, nparts=500, **kw):
+        """param::pack ctor, order beta, phi, ss with sigma = sqrt(ss) (:55-61)."""
+        beta, phi, ss = (float(v) for v in untrans_params)
+        return cls(phi, beta, float(np.sqrt(ss)), nparts, **kw)
+
+
+class svol_leverage(_SingleFilter):
+    """test/test_pswarm.cpp:32-141. Ctor order (phi, mu, sigma, rho)."""
+    _model = MODEL_SVOL_LEVERAGE
+
+    def __init__(self, phi, mu, sigma, rho, nparts=500, **kw):
+        super().__init__([phi, mu, sigma, rho], nparts, **kw)
+
+
+class lin_gauss_bs(_SingleFilter):
+    """Linear-Gaussian anchor model (not in the reference): exact Kalman log-lik known."""
+    _model = MODEL_LIN_GAUSS
+
+    def __init__(self, phi, sigma, tau, nparts=500, **kw):
+        super().__init__([phi, sigma, tau], nparts, **kw)
+
+
+def log_like_eval(untrans_theta, data, nparts=500, num_pfilters=1, seed=0, resampler=RESAMP_MULTINOMIAL, device=0,
+                  bank=None):
+    """estimate_univ_svol.h:108-131 with thread_pool's replicate aggregation (thread_pool.h:263-268):
+    num_pfilters independent filters at the same theta, log-mean-exp of their log-likelihoods."""
+    data = capi.as_f64(data)
+    if data.size == 0:
+        raise ValueError("can't read in data")   # std::length_error in the reference (:112-113)
+    beta, phi, ss = (float(v) for v in untrans_theta)
+    own = bank is None
+    if own:
+        bank = ParticleFilterBank(MODEL_SVOL, nparts, num_pfilters, seed, resampler, 1, device)
+    try:
+        bank.set_params([beta, phi, float(np.sqrt(ss))])
+        bank.run_series(data)
+        return bank.log_mean_exp()
+    finally:
+        if own:
+            bank.close()

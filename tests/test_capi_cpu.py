@@ -1,0 +1,77 @@
+"""CPU suite: the C-ABI library builds, loads and exports every symbol include/ssme_pf.h declares;
+host-side argument validation; the product path fails loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "ssme_pf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ssme_pf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    from ssme_amd import build, _capi
+    so = build.build()
+    assert os.path.exists(so)
+    L = C.CDLL(so)
+    names = _header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/ssme_pf.h but not exported"
+    assert sorted(_capi.EXPORTS) == names
+    assert _capi.lib().ssme_pf_version() >= 100
+
+
+def test_strerror_and_null_handling():
+    from ssme_amd import _capi
+    L = _capi.lib()
+    assert L.ssme_pf_strerror(0) == b"ok"
+    assert b"invalid" in L.ssme_pf_strerror(_capi.ERR_INVALID_ARG)
+    assert L.ssme_pf_create(None, None) == _capi.ERR_INVALID_ARG
+    assert L.ssme_pf_destroy(None) == _capi.ERR_INVALID_ARG
+    assert L.ssme_pf_reset(None) == _capi.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("field,value,status", [
+    ("n_particles", 0, 1), ("n_filters", 0, 1), ("model", 9, 1), ("resampler", 7, 1), ("resamp_sched", 0, 1),
+    ("dtype", 1, 3), ("n_particles", (1 << 22) + 2048 + 1, 3),
+])
+def test_create_validates_config(field, value, status):
+    from ssme_amd import _capi
+    cfg = _capi.Config(model=0, n_particles=100, n_filters=1, dtype=0, resampler=0, resamp_sched=1, seed=1,
+                       device=0, first_filter_id=0)
+    setattr(cfg, field, value)
+    h = C.c_void_p()
+    assert _capi.lib().ssme_pf_create(C.byref(cfg), C.byref(h)) == status
+    assert not h.value
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a HIP device the product path must raise, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import ssme_amd
+    with pytest.raises(ssme_amd.SsmeError) as e:
+        ssme_amd.ParticleFilterBank(ssme_amd.MODEL_SVOL, 128)
+    assert e.value.status == 4
+    with pytest.raises(ssme_amd.SsmeError):
+        ssme_amd.log_like_eval([1.0, 0.5, 2e-4], np.ones(4), nparts=64)
+
+
+def test_product_never_imports_oracle():
+    import subprocess
+    import sys
+    code = "import sys, ssme_amd, ssme_amd._capi; assert not any(m.startswith('oracle') for m in sys.modules), sys.modules.keys()"
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+    for fn in ("_capi.py", "filters.py", "__init__.py", "build.py", "csrc/pf_api.hip", "csrc/pf_kernels.h",
+               "csrc/ssme_math.h"):
+        text = open(os.path.join(ROOT, "ssme_amd", fn)).read()
+        assert "import oracle" not in text and "from oracle" not in text and "libssme_oracle" not in text

@@ -1,0 +1,204 @@
+"""CPU suite: pins the oracle (oracle/) against every known-answer value the reference's own
+files hold for this path, against independent anchors, and against the committed golden vectors."""
+import numpy as np
+import pytest
+
+
+# ---- Philox4x32-10: Random123 known-answer vectors -------------------------------------------------
+@pytest.mark.parametrize("ctr,key,exp", [
+    ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+])
+def test_philox_kat(oracle, ctr, key, exp):
+    assert [int(v) for v in oracle.philox(ctr, key)] == exp
+
+
+# ---- libm-free math vs glibc -------------------------------------------------------------------------
+def _ulp(a, b):
+    return np.max(np.abs(a - b) / np.spacing(np.abs(b)))
+
+
+def test_math_accuracy(oracle):
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-700, 700, 100000)
+    assert _ulp(oracle.exp(x), np.exp(x)) <= 1.0
+    x = rng.uniform(-3, 3, 100000)
+    assert _ulp(oracle.exp(x), np.exp(x)) <= 1.0
+    u = rng.uniform(0, 1, 100000)
+    assert _ulp(oracle.log(u), np.log(u)) <= 1.0
+    x = np.exp(rng.uniform(-700, 700, 100000))
+    assert _ulp(oracle.log(x), np.log(x)) <= 1.0
+    s, c = oracle.sincos2pi(u)
+    # libm sin(2*pi*u) carries the rounding of 2*pi*u; compare absolutely
+    assert np.max(np.abs(s - np.sin(2 * np.pi * u))) < 2e-15
+    assert np.max(np.abs(c - np.cos(2 * np.pi * u))) < 2e-15
+    assert np.max(np.abs(s * s + c * c - 1)) < 5e-16
+    mpmath = pytest.importorskip("mpmath")
+    mpmath.mp.dps = 40
+    for uv, sv, cv in zip(u[:1500], s[:1500], c[:1500]):
+        a = 2 * mpmath.pi * mpmath.mpf(float(uv))
+        ts, tc = mpmath.sin(a), mpmath.cos(a)
+        assert abs(ts - mpmath.mpf(float(sv))) <= mpmath.mpf(float(np.spacing(abs(float(ts)))))
+        assert abs(tc - mpmath.mpf(float(cv))) <= mpmath.mpf(float(np.spacing(abs(float(tc)))))
+
+
+def test_math_special_values(oracle):
+    with np.errstate(all="ignore"):
+        x = np.array([-745.2, -745.0, -720.0, 709.7, 709.9, 0.0, np.inf, -np.inf])
+        np.testing.assert_array_equal(oracle.exp(x), np.exp(x))
+        assert np.isnan(oracle.exp(np.array([np.nan])))[0]
+        x = np.array([0.0, 1.0, 5e-324, 1e-310, np.inf])
+        np.testing.assert_allclose(oracle.log(x), np.log(x), rtol=2e-16)
+        assert np.isnan(oracle.log(np.array([-1.0, np.nan]))).all()
+    s, c = oracle.sincos2pi(np.array([0.0, 0.25, 0.5, 0.75]))
+    np.testing.assert_array_equal(s, [0.0, 1.0, -0.0, -1.0])
+    np.testing.assert_array_equal(c, [1.0, -0.0, -1.0, 0.0])
+
+
+def test_normals_moments(oracle):
+    z = oracle.normals(7, 0, 3, 400000)
+    assert abs(z.mean()) < 5e-3 and abs(z.var() - 1) < 1e-2
+    assert abs(((z - z.mean()) ** 4).mean() / z.var() ** 2 - 3) < 0.05
+
+
+# ---- reference KATs ------------------------------------------------------------------------------------
+def test_pack_transform_kats(oracle):
+    """test/test_parameters.cpp:114-120,141-145: trans {1.0,-1.3,9.5,.89} x {null,log,logit,twice_fisher}."""
+    NULL, TF, LOGIT, LOG = 0, 1, 2, 3
+    got = [oracle.inv_transform(NULL, 1.0), oracle.inv_transform(LOG, -1.3), oracle.inv_transform(LOGIT, 9.5),
+           oracle.inv_transform(TF, 0.89)]
+    np.testing.assert_allclose(got, [1.0, 0.2725318, 0.9999252, 0.4177803], atol=1e-4)
+    lj = (oracle.log_jacobian(NULL, 1.0) + oracle.log_jacobian(LOG, -1.3) + oracle.log_jacobian(LOGIT, 9.5)
+          + oracle.log_jacobian(TF, 0.89))
+    assert abs(lj - (-11.6851)) < 1e-4
+
+
+def test_log_mean_exp_kat(oracle):
+    """test/test_thread_pool.cpp:39-46: 10^4 results of 3.0 -> 3.0 +- 1e-3."""
+    assert abs(oracle.log_mean_exp(np.full(10000, 3.0)) - 3.0) < 1e-3
+
+
+def test_chain_start_point(oracle):
+    """estimate_univ_svol.h:153-155: theta_trans = (1, twiceFisher(.5), log 2e-4) -> beta 1, phi .5, ss 2e-4."""
+    tf = np.log(1.5) - np.log(0.5)
+    assert abs(oracle.inv_transform(1, tf) - 0.5) < 1e-12
+    assert abs(oracle.inv_transform(3, np.log(2e-4)) - 2e-4) < 1e-15
+
+
+def test_constant_functional_is_42(oracle, spy):
+    """test/test_pswarm.cpp:252: expectation of the constant 42 is 42."""
+    f = oracle.Filter(oracle.MODEL_SVOL_LEVERAGE, 10, [0.9, 0.0, 1.0, -0.1], 1)
+    f.step(spy[0], 0.0)
+    assert abs(f.expectation(3) - 42.0) < 1e-4
+    assert f.loglik ** 2 > 0       # :251
+
+
+# ---- canonical scan tree ---------------------------------------------------------------------------------
+def test_rows_scan_matches_exact_sum(oracle):
+    rng = np.random.default_rng(3)
+    for nrows in (1, 2, 4):
+        v = rng.uniform(0, 1, nrows * 512)
+        incl, excl, tot = oracle.rows_scan(v)
+        ref = np.cumsum(v)
+        np.testing.assert_allclose(incl, ref, rtol=1e-13)
+        np.testing.assert_allclose(excl[1:], ref[:-1], rtol=1e-13)
+        assert excl[0] == 0.0 and abs(tot - ref[-1]) < 1e-10
+    # integers are summed exactly whatever the tree
+    v = np.arange(2048, dtype=np.float64)
+    incl, _, tot = oracle.rows_scan(v)
+    np.testing.assert_array_equal(incl, np.cumsum(v))
+
+
+# ---- estimator anchors -----------------------------------------------------------------------------------
+def _lg_data(T=150, phi=0.9, sig=0.5, tau=0.7, seed=5):
+    rng = np.random.default_rng(seed)
+    x = np.zeros(T)
+    x[0] = rng.normal() * sig / np.sqrt(1 - phi ** 2)
+    for t in range(1, T):
+        x[t] = phi * x[t - 1] + sig * rng.normal()
+    return x + tau * rng.normal(size=T), (phi, sig, tau)
+
+
+@pytest.mark.parametrize("resampler", [0, 1, 2, 3])
+def test_kalman_anchor(oracle, resampler):
+    """The particle estimate of the log-likelihood of a linear-Gaussian model is within MC error of Kalman."""
+    y, th = _lg_data()
+    exact, _ = oracle.kalman_loglik(*th, y)
+    lls = np.array([oracle.Filter(oracle.MODEL_LIN_GAUSS, 4096, th, s, resampler=resampler).run_series(y)[0]
+                    for s in range(8)])
+    se = lls.std(ddof=1) / np.sqrt(len(lls))
+    assert abs(lls.mean() - exact) < 4 * se + 0.15
+
+
+def test_mode_a_vs_mode_b(oracle, spy):
+    """Reference-faithful mt19937 mode and kernel-matched Philox mode agree statistically."""
+    th = [1.0, 0.95, 0.25]
+    y = spy[:300]
+    a = np.array([oracle.ref_run_series(oracle.MODEL_SVOL, th, 500, y, seed=s)[0] for s in range(24)])
+    b = np.array([oracle.Filter(oracle.MODEL_SVOL, 500, th, s).run_series(y)[0] for s in range(24)])
+    se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
+    assert abs(a.mean() - b.mean()) < 4 * se
+    af = np.array([oracle.ref_run_series(oracle.MODEL_SVOL, th, 500, y, seed=s, fast_resampler=True)[0]
+                   for s in range(24)])
+    assert abs(a.mean() - af.mean()) < 4 * np.sqrt(a.var(ddof=1) / 24 + af.var(ddof=1) / 24)
+
+
+def test_variance_scales_with_n(oracle, spy):
+    th = [1.0, 0.95, 0.25]
+    y = spy[:200]
+    v = []
+    for n in (128, 2048):
+        v.append(np.var([oracle.Filter(oracle.MODEL_SVOL, n, th, s).run_series(y)[0] for s in range(16)], ddof=1))
+    assert v[1] < v[0]
+
+
+def test_resample_schedule_and_replicates(oracle, spy):
+    th = [1.0, 0.95, 0.25]
+    f = oracle.Filter(oracle.MODEL_SVOL, 300, th, 1, resamp_sched=3)
+    ll, per = f.run_series(spy[:50])
+    assert np.isfinite(ll) and abs(per.sum() - ll) < 1e-9
+    a = oracle.Filter(oracle.MODEL_SVOL, 300, th, 1, rep=0).run_series(spy[:50])[0]
+    b = oracle.Filter(oracle.MODEL_SVOL, 300, th, 1, rep=1).run_series(spy[:50])[0]
+    assert a != b
+
+
+def test_degenerate_inputs(oracle):
+    # beta <= 0 -> logG = -inf for every particle -> NaN log-lik (reference: PMMH rejects, ada_pmmh_mvn.h:349)
+    f = oracle.Filter(oracle.MODEL_SVOL, 64, [-1.0, 0.5, 0.1], 1)
+    assert np.isnan(f.step(0.3))
+    # |phi| >= 1 -> stationary sd NaN -> NaN
+    f = oracle.Filter(oracle.MODEL_SVOL, 64, [1.0, 1.5, 0.1], 1)
+    assert np.isnan(f.step(0.3))
+    # y = 0 is legal (11 exact zeros in spy_returns.csv)
+    f = oracle.Filter(oracle.MODEL_SVOL, 64, [1.0, 0.5, 0.1], 1)
+    assert np.isfinite(f.step(0.0))
+    # N = 1 and N not a multiple of anything
+    for n in (1, 3, 2047, 2049):
+        f = oracle.Filter(oracle.MODEL_SVOL, n, [1.0, 0.9, 0.2], 2)
+        assert np.isfinite(f.run_series(np.array([0.1, -0.2, 0.3]))[0])
+
+
+# ---- golden vectors ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tname", ["start", "real"])
+@pytest.mark.parametrize("n", [64, 500, 4096])
+@pytest.mark.parametrize("rs", [("mn", 0), ("sys", 1)])
+def test_oracle_reproduces_golden(oracle, golden, spy, tname, n, rs):
+    th = golden[f"theta_{tname}"]
+    f = oracle.Filter(oracle.MODEL_SVOL, n, th, int(golden["seed"][0]), resampler=rs[1])
+    lls = [f.step(spy[t]) for t in range(8)]
+    k = f"svol_{tname}_n{n}_{rs[0]}"
+    np.testing.assert_array_equal(np.array(lls), golden[k + "_ll"])
+    st = f.state()
+    for name in ("x", "logw", "cdf", "anc"):
+        np.testing.assert_array_equal(st[name], golden[k + "_" + name])
+
+
+def test_oracle_full_series_golden(oracle, golden, spy):
+    for tname in ("start", "real"):
+        f = oracle.Filter(oracle.MODEL_SVOL, 500, golden[f"theta_{tname}"], int(golden["seed"][0]))
+        ll, per = f.run_series(spy)
+        assert ll == golden[f"svol_{tname}_n500_full_ll"][0]
+        np.testing.assert_array_equal(per, golden[f"svol_{tname}_n500_full_per"])
+    assert len(spy) == 3084

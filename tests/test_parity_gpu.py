@@ -1,0 +1,343 @@
+"""GPU parity suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs and against the committed golden vectors.
+
+Bar: particles, log-weights, tile-local cdf and ANCESTOR INDICES bit-exact;
+per-step and series log-likelihood |delta| <= 1e-9 (observed 0: the device math mirrors the oracle's
+IEEE operation sequence).  At BASELINE sizes: size-independent properties (Kalman anchor, replicate
+independence, graph == eager, step API == series API)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_LL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import ssme_amd
+    from ssme_amd import _capi
+    assert _capi.lib() is not None        # the in-tree HIP library is what runs
+    return ssme_amd
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bits_equal(a, b, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    nan_a, nan_b = np.isnan(a), np.isnan(b)
+    assert np.array_equal(nan_a, nan_b), f"{what}: NaN pattern differs"
+    bad = (_bits(a) != _bits(b)) & ~nan_a
+    assert not bad.any(), f"{what}: {bad.sum()} of {a.size} values differ, first at {np.argmax(bad)}: " \
+                          f"{a.flat[np.argmax(bad)]!r} vs {b.flat[np.argmax(bad)]!r}"
+
+
+# ---- device primitives ----------------------------------------------------------------------------
+def test_device_philox_kat(sa, oracle):
+    from ssme_amd import _capi
+    for ctr, key in (([0, 0, 0, 0], [0, 0]), ([0xffffffff] * 4, [0xffffffff] * 2),
+                     ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]),
+                     ([5, 77, 3, 1], [20260101, 9])):
+        c, k, o = np.array(ctr, dtype=np.uint32), np.array(key, dtype=np.uint32), np.zeros(4, dtype=np.uint32)
+        _capi.check(_capi.lib().ssme_pf_test_philox(0, _capi.u32ptr(c), _capi.u32ptr(k), _capi.u32ptr(o)))
+        np.testing.assert_array_equal(o, oracle.philox(ctr, key))
+
+
+def _dev_math(fn, x):
+    from ssme_amd import _capi
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    _capi.check(_capi.lib().ssme_pf_test_math(0, fn, _capi.dptr(x), _capi.dptr(out), x.size))
+    return out
+
+
+def test_device_math_bit_exact(sa, oracle):
+    rng = np.random.default_rng(11)
+    with np.errstate(all="ignore"):
+        x = np.concatenate([rng.uniform(-750, 715, 200000), rng.uniform(-40, 40, 200000),
+                            [0.0, -0.0, np.inf, -np.inf, np.nan, 709.782712893384, -745.1332191019412, 1e-320]])
+        assert_bits_equal(_dev_math(0, x), oracle.exp(x), "exp")
+        u = np.concatenate([rng.uniform(0, 1, 200000), np.exp(rng.uniform(-740, 700, 200000)),
+                            (np.arange(1, 4097) * 2.0 ** -53), [1.0, 0.0, np.inf, 5e-324, 1e-310, -1.0, np.nan]])
+        assert_bits_equal(_dev_math(1, u), oracle.log(u), "log")
+        v = np.concatenate([rng.uniform(0, 1, 400000), np.arange(0, 4096) * 2.0 ** -53, 1 - np.arange(1, 4097) * 2.0 ** -53,
+                            [0.0, 0.125, 0.25, 0.5, 0.75, 0.875]])
+        s, c = oracle.sincos2pi(v)
+        assert_bits_equal(_dev_math(2, v), s, "sin2pi")
+        assert_bits_equal(_dev_math(3, v), c, "cos2pi")
+        w = np.concatenate([rng.uniform(0, 100, 200000), np.exp(rng.uniform(-700, 700, 100000)), [0.0, 4.0, 2.0, 1e-320]])
+        assert_bits_equal(_dev_math(4, w), np.sqrt(w), "sqrt (IEEE, correctly rounded)")
+
+
+@pytest.mark.parametrize("nrows", [1, 2, 3, 4])
+def test_device_rows_scan_bit_exact(sa, oracle, nrows):
+    from ssme_amd import _capi
+    rng = np.random.default_rng(nrows)
+    v = np.exp(rng.uniform(-30, 3, nrows * 512))
+    v[rng.integers(0, v.size, 40)] = 0.0
+    incl, excl, tot = np.empty_like(v), np.empty_like(v), np.empty(1)
+    _capi.check(_capi.lib().ssme_pf_test_rows_scan(0, _capi.dptr(v), nrows, _capi.dptr(incl), _capi.dptr(excl),
+                                                   _capi.dptr(tot)))
+    oi, oe, ot = oracle.rows_scan(v)
+    assert_bits_equal(incl, oi, "inclusive")
+    assert_bits_equal(excl, oe, "exclusive")
+    assert_bits_equal(tot, [ot], "total")
+
+
+# ---- filter parity vs oracle ------------------------------------------------------------------------
+def _compare_state(bank, of, what):
+    g = bank.state(0, ancestors=True)
+    o = of.state()
+    assert_bits_equal(g["x"], o["x"], what + " particles")
+    assert_bits_equal(g["logw"], o["logw"], what + " log-weights")
+    assert_bits_equal(g["cdf"], o["cdf"], what + " tile-local cdf")
+    assert_bits_equal(g["A"], o["A"], what + " tile sums")
+    assert_bits_equal([g["m"]], [o["m"]], what + " max log-weight")
+    return g, o
+
+
+@pytest.mark.parametrize("n", [1, 3, 64, 100, 500, 2047, 2048, 2049, 4096, 5000])
+@pytest.mark.parametrize("resampler", [0, 1])
+def test_step_parity_small(sa, oracle, spy, n, resampler):
+    th = [1.0, 0.95, 0.25]
+    seed = 20260101 + n
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, seed, resampler)
+    bank.set_debug(True)
+    bank.set_params(th)
+    of = oracle.Filter(oracle.MODEL_SVOL, n, th, seed, resampler=resampler)
+    for t in range(6):
+        lg = bank.step(spy[t])[0]
+        lo = of.step(spy[t])
+        assert abs(lg - lo) <= TOL_LL and lg == lo, (t, lg, lo)
+        g, o = _compare_state(bank, of, f"n={n} t={t}")
+        if t > 0:
+            np.testing.assert_array_equal(g["anc"], o["anc"], err_msg=f"ancestors n={n} t={t}")
+            assert g["anc"].max() < n
+    assert abs(bank.loglik()[0] - of.loglik) <= TOL_LL
+    bank.close()
+
+
+@pytest.mark.parametrize("resampler", [0, 1, 2, 3])
+@pytest.mark.parametrize("model", [0, 1, 2])
+def test_models_and_resamplers(sa, oracle, spy, model, resampler):
+    th = {0: [1.0, 0.95, 0.25], 1: [0.9, 0.0, 1.0, -0.1], 2: [0.9, 0.5, 0.7]}[model]
+    n, seed = 3000, 77
+    z = np.concatenate([[0.0], spy[:-1]])
+    bank = sa.ParticleFilterBank(model, n, 1, seed, resampler)
+    bank.set_debug(True)
+    bank.set_params(th)
+    of = oracle.Filter(model, n, th, seed, resampler=resampler)
+    for t in range(5):
+        zt = z[t] if model == 1 else None
+        lg = bank.step(spy[t], zt)[0]
+        lo = of.step(spy[t], 0.0 if zt is None else zt)
+        assert lg == lo, (model, resampler, t, lg, lo)
+    g, o = _compare_state(bank, of, f"model={model} rs={resampler}")
+    np.testing.assert_array_equal(g["anc"], o["anc"])
+    bank.close()
+
+
+def test_series_matches_oracle_and_step_api(sa, oracle, spy):
+    th = [1.0, 0.95, 0.25]
+    n, seed, T = 5000, 5, 200
+    of = oracle.Filter(oracle.MODEL_SVOL, n, th, seed)
+    ll_o, per_o = of.run_series(spy[:T])
+    for graph in (False, True):
+        bank = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, seed)
+        bank.set_graph_mode(graph)
+        bank.set_params(th)
+        ll = bank.run_series(spy[:T])[0]
+        assert ll == ll_o and abs(ll - ll_o) <= TOL_LL
+        assert_bits_equal(bank.per_step()[0], per_o, "per-step log-lik")
+        # a second run on the same handle (graph replay) reproduces it
+        assert bank.run_series(spy[:T])[0] == ll_o
+        _compare_state(bank, of, "after series")
+        bank.close()
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, seed)
+    bank.set_params(th)
+    s = 0.0
+    for t in range(T):
+        s += bank.step(spy[t])[0]
+    assert bank.loglik()[0] == ll_o
+    bank.close()
+
+
+def test_resample_schedule(sa, oracle, spy):
+    th = [1.0, 0.95, 0.25]
+    for rs in (2, 3):
+        bank = sa.ParticleFilterBank(sa.MODEL_SVOL, 3000, 1, 9, sa.RESAMP_MULTINOMIAL, rs)
+        bank.set_params(th)
+        of = oracle.Filter(oracle.MODEL_SVOL, 3000, th, 9, resamp_sched=rs)
+        ll_o, per_o = of.run_series(spy[:40])
+        assert bank.run_series(spy[:40])[0] == ll_o
+        assert_bits_equal(bank.per_step()[0], per_o, f"per-step rs={rs}")
+        bank.close()
+
+
+def test_replicates_and_filter_ids(sa, oracle, spy):
+    """R filters in one handle == R oracle filters with replicate ids first_filter_id + r
+    (thread_pool num_pfilters / swarm nparamparts); per-filter theta rows (pswarm)."""
+    n, seed, T, R = 2500, 31, 30, 5
+    z = np.concatenate([[0.0], spy[:-1]])
+    rng = np.random.default_rng(2)
+    thetas = np.stack([rng.uniform(.8, .99, R), rng.uniform(-.1, .1, R), rng.uniform(.01, .1, R),
+                       rng.uniform(-.5, -.01, R)], axis=1)       # prior of test_pswarm.cpp:244
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL_LEVERAGE, n, R, seed, sa.RESAMP_MULTINOMIAL, 1, 0, first_filter_id=10)
+    bank.set_params(thetas)
+    ll = bank.run_series(spy[:T], z[:T])
+    for r in range(R):
+        of = oracle.Filter(oracle.MODEL_SVOL_LEVERAGE, n, thetas[r], seed, rep=10 + r)
+        assert ll[r] == of.run_series(spy[:T], z[:T])[0]
+    # shared theta (PMMH replicates) + log-mean-exp aggregation (thread_pool.h:263-268)
+    bank.set_params(thetas[0])
+    ll = bank.run_series(spy[:T], z[:T])
+    assert len(set(ll.tolist())) == R
+    assert abs(bank.log_mean_exp() - oracle.log_mean_exp(ll)) < 1e-12
+    bank.close()
+
+
+def test_expectations(sa, oracle, spy):
+    th = [0.9, 0.0, 1.0, -0.1]
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL_LEVERAGE, 1000, 2, 3)
+    bank.set_params(th)
+    ofs = [oracle.Filter(oracle.MODEL_SVOL_LEVERAGE, 1000, th, 3, rep=r) for r in range(2)]
+    for t in range(3):
+        bank.step(spy[t], 0.0 if t == 0 else spy[t - 1])
+        for of in ofs:
+            of.step(spy[t], 0.0 if t == 0 else spy[t - 1])
+    np.testing.assert_allclose(bank.expectations(3), 42.0, atol=1e-4)     # test_pswarm.cpp:252
+    for kind in (0, 1, 2):
+        np.testing.assert_allclose(bank.expectations(kind), [of.expectation(kind) for of in ofs], rtol=1e-12)
+    bank.close()
+
+
+def test_reference_style_interface(sa, oracle, spy):
+    """Reads like the reference's caller: mod.filter(y); logLike += mod.getLogCondLike() (estimate_univ_svol.h:121-127)."""
+    mod = sa.svol_bs.from_pack([1.0, 0.5, 2.0e-4], nparts=500, seed=4)
+    of = oracle.Filter(oracle.MODEL_SVOL, 500, [1.0, 0.5, float(np.sqrt(2.0e-4))], 4)
+    logLike = 0.0
+    for row in range(20):
+        mod.filter(spy[row])
+        logLike += mod.getLogCondLike()
+        assert mod.getLogCondLike() == of.step(spy[row])
+    assert logLike ** 2 > 0      # the reference's own assertion, test_pswarm.cpp:251
+    lev = sa.svol_leverage(0.9, 0.0, 1.0, -0.1, nparts=10, seed=1)
+    lev.filter(spy[0], 0.0, fs=[3])
+    assert abs(lev.getExpectations()[0] - 42.0) < 1e-4 and lev.getLogCondLike() ** 2 > 0
+    with pytest.raises(ValueError):
+        sa.log_like_eval([1.0, .5, 2e-4], np.array([]))
+    v = sa.log_like_eval([1.0, 0.95, 0.0625], spy[:50], nparts=500, num_pfilters=4, seed=8)
+    assert np.isfinite(v)
+
+
+def test_degenerate_inputs(sa, oracle):
+    for th in ([-1.0, 0.5, 0.1], [1.0, 1.5, 0.1]):
+        bank = sa.ParticleFilterBank(sa.MODEL_SVOL, 300, 1, 1)
+        bank.set_params(th)
+        assert np.isnan(bank.step(0.3)[0])
+        assert np.isnan(bank.step(0.1)[0])          # the search must not hang or fault on NaN weights
+        bank.close()
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL, 300, 1, 1)
+    bank.set_params([1.0, 0.5, 0.1])
+    of = oracle.Filter(oracle.MODEL_SVOL, 300, [1.0, 0.5, 0.1], 1)
+    for y in (0.0, 0.0, 13.56, -10.36, 0.0):        # exact zeros and the extremes of spy_returns.csv
+        assert bank.step(y)[0] == of.step(y)
+    bank.close()
+    with pytest.raises(sa.SsmeError):
+        sa.ParticleFilterBank(sa.MODEL_SVOL, 300, 1, 1).set_params([1.0, 0.5])      # wrong theta length
+
+
+# ---- golden vectors -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tname", ["start", "real"])
+@pytest.mark.parametrize("n", [64, 500, 4096])
+@pytest.mark.parametrize("rs", [("mn", 0), ("sys", 1)])
+def test_gpu_reproduces_golden(sa, golden, spy, tname, n, rs):
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, int(golden["seed"][0]), rs[1])
+    bank.set_debug(True)
+    bank.set_params(golden[f"theta_{tname}"])
+    lls = [bank.step(spy[t])[0] for t in range(8)]
+    k = f"svol_{tname}_n{n}_{rs[0]}"
+    assert_bits_equal(lls, golden[k + "_ll"], k + " ll")
+    st = bank.state(0, ancestors=True)
+    for name in ("x", "logw", "cdf"):
+        assert_bits_equal(st[name], golden[k + "_" + name], k + " " + name)
+    np.testing.assert_array_equal(st["anc"], golden[k + "_anc"])
+    bank.close()
+
+
+def test_gpu_full_series_golden(sa, golden, spy):
+    """Full spy_returns.csv series (T = 3084): N = 500 (shipped example size) and N = 2^16 (config 3)."""
+    seed = int(golden["seed"][0])
+    for tname in ("start", "real"):
+        bank = sa.ParticleFilterBank(sa.MODEL_SVOL, 500, 1, seed)
+        bank.set_params(golden[f"theta_{tname}"])
+        assert bank.run_series(spy)[0] == golden[f"svol_{tname}_n500_full_ll"][0]
+        assert_bits_equal(bank.per_step()[0], golden[f"svol_{tname}_n500_full_per"], "per-step")
+        bank.close()
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL, 1 << 16, 1, seed)
+    bank.set_params(golden["theta_real"])
+    ll = bank.run_series(spy)[0]
+    assert abs(ll - golden["svol_real_n65536_full_ll"][0]) <= TOL_LL and ll == golden["svol_real_n65536_full_ll"][0]
+    assert_bits_equal(bank.per_step()[0], golden["svol_real_n65536_full_per"], "per-step 2^16")
+    bank.close()
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL_LEVERAGE, 4096, 1, seed, first_filter_id=3)
+    bank.set_debug(True)
+    bank.set_params([0.9, 0.0, 1.0, -0.1])
+    z = np.concatenate([[0.0], spy[:-1]])
+    lls = [bank.step(spy[t], z[t])[0] for t in range(8)]
+    assert_bits_equal(lls, golden["lev_n4096_ll"], "leverage ll")
+    st = bank.state(0, ancestors=True)
+    for name in ("x", "logw", "cdf"):
+        assert_bits_equal(st[name], golden["lev_n4096_" + name], "leverage " + name)
+    np.testing.assert_array_equal(st["anc"], golden["lev_n4096_anc"])
+    bank.close()
+
+
+# ---- BASELINE sizes: size-independent properties -------------------------------------------------------
+def test_full_size_properties(sa, oracle, spy):
+    """N = 2^20 (config 2): first steps bit-exact vs oracle; Kalman anchor at 2^20; graph == eager."""
+    n, seed = 1 << 20, 20260101
+    th = [1.0, 0.95, 0.25]
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, seed)
+    bank.set_debug(True)
+    bank.set_params(th)
+    of = oracle.Filter(oracle.MODEL_SVOL, n, th, seed)
+    for t in range(3):
+        assert bank.step(spy[t])[0] == of.step(spy[t])
+    g, o = _compare_state(bank, of, "N=2^20")
+    np.testing.assert_array_equal(g["anc"], o["anc"])
+    a = bank.run_series(spy[:400])[0]
+    bank.set_graph_mode(False)
+    assert bank.run_series(spy[:400])[0] == a
+    bank.close()
+    # linear-Gaussian: at N = 2^20 the estimate is within 0.05 of the exact Kalman log-likelihood
+    rng = np.random.default_rng(5)
+    T, phi, sig, tau = 200, 0.9, 0.5, 0.7
+    x = np.zeros(T)
+    x[0] = rng.normal() * sig / np.sqrt(1 - phi ** 2)
+    for t in range(1, T):
+        x[t] = phi * x[t - 1] + sig * rng.normal()
+    y = x + tau * rng.normal(size=T)
+    exact, _ = oracle.kalman_loglik(phi, sig, tau, y)
+    for rs in (0, 1):
+        bank = sa.ParticleFilterBank(sa.MODEL_LIN_GAUSS, n, 1, 3, rs)
+        bank.set_params([phi, sig, tau])
+        assert abs(bank.run_series(y)[0] - exact) < 0.05
+        bank.close()
+
+
+def test_max_tiles_per_filter(sa, spy):
+    """Largest supported filter (2048 tiles = 2^22 particles): runs, finite, ancestors in range."""
+    n = 1 << 22
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, 1, sa.RESAMP_SYSTEMATIC)
+    bank.set_debug(True)
+    bank.set_params([1.0, 0.95, 0.25])
+    ll = bank.run_series(spy[:4])[0]
+    assert np.isfinite(ll)
+    st = bank.state(0, ancestors=True)
+    assert st["anc"].max() < n and (np.diff(st["anc"].astype(np.int64)) >= 0).all()   # systematic: sorted
+    bank.close()
