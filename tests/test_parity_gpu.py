@@ -89,8 +89,8 @@ def test_device_rows_scan_bit_exact(sa, oracle, nrows):
 
 
 # ---- filter parity vs oracle ------------------------------------------------------------------------
-def _compare_state(bank, of, what):
-    g = bank.state(0, ancestors=True)
+def _compare_state(bank, of, what, ancestors=True):
+    g = bank.state(0, ancestors=ancestors)
     o = of.state()
     assert_bits_equal(g["x"], o["x"], what + " particles")
     assert_bits_equal(g["logw"], o["logw"], what + " log-weights")
@@ -155,7 +155,7 @@ def test_series_matches_oracle_and_step_api(sa, oracle, spy):
         assert_bits_equal(bank.per_step()[0], per_o, "per-step log-lik")
         # a second run on the same handle (graph replay) reproduces it
         assert bank.run_series(spy[:T])[0] == ll_o
-        _compare_state(bank, of, "after series")
+        _compare_state(bank, of, "after series", ancestors=False)
         bank.close()
     bank = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, seed)
     bank.set_params(th)
