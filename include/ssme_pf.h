@@ -114,12 +114,15 @@ int ssme_pf_get_expectations(ssme_pf_handle h, int32_t functional, double* out);
 int ssme_pf_log_mean_exp(ssme_pf_handle h, double* out);
 
 /* Parity/debug: state of one filter after the last step.  Any pointer may be NULL.
- * x, logw: N pre-resampling particles and log-weights; cdf: N tile-local inclusive
- * weight sums; ancestors: N indices used by the last step (requires set_debug(1)). */
-int ssme_pf_download_state(ssme_pf_handle h, int32_t filter, double* x, double* logw, double* cdf,
+ * x, logw: N pre-resampling particles and log-weights; cdf: N tile-local inclusive sums of the
+ * fixed-point weights q_i = rne(exp(logw_i - max) * 2^rshift) (exact uint64 arithmetic);
+ * ancestors: N indices used by the last step (requires set_debug(1)). */
+int ssme_pf_download_state(ssme_pf_handle h, int32_t filter, double* x, double* logw, uint64_t* cdf,
                            uint32_t* ancestors);
-int ssme_pf_download_scalars(ssme_pf_handle h, int32_t filter, double* max_logw, double* sum_w,
-                             double* tile_sums, double* tile_prefix);
+/* max_logw: max log-weight of the last step; sum_q: exact integer weight sum; tile_sums: one
+ * integer sum per 2048-particle tile; rshift: the fixed-point exponent r = 62 - ceil(log2(Npad)). */
+int ssme_pf_download_scalars(ssme_pf_handle h, int32_t filter, double* max_logw, uint64_t* sum_q,
+                             uint64_t* tile_sums, int32_t* rshift);
 int ssme_pf_set_debug(ssme_pf_handle h, int32_t record_ancestors);
 
 /* Execution policy of run_series: 0 = eager launches, 1 = one hipGraph per series (default). */
@@ -135,12 +138,16 @@ int ssme_pf_last_elapsed_ms(ssme_pf_handle h, float* ms);
 int ssme_pf_profile_series(ssme_pf_handle h, const double* y, const double* z, int32_t T,
                            double* mean_us_out /*2*/, int32_t* launches_out /*2*/);
 
-/* Device-side primitives exposed for bit-parity tests against the oracle (n values). */
-int ssme_pf_test_math(int32_t device, int32_t fn /*0 exp,1 log,2 sin2pi,3 cos2pi,4 sqrt*/, const double* in,
-                      double* out, int64_t n);
+/* Device-side primitives exposed for bit-parity tests against the oracle. */
+int ssme_pf_test_math(int32_t device, int32_t fn /*0 exp,1 log,2 sin2pi,3 cos2pi,4 sqrt,5 log (normal-only core)*/,
+                      const double* in, double* out, int64_t n);
 int ssme_pf_test_philox(int32_t device, const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4);
-int ssme_pf_test_rows_scan(int32_t device, const double* in, int32_t nrows, double* incl, double* excl,
-                           double* total);
+/* q = rne(exp(in) * 2^shift) as uint64, n values */
+int ssme_pf_test_quantize(int32_t device, const double* in, int32_t shift, uint64_t* out, int64_t n);
+/* exact inclusive scan of 2048 uint64 values by one 256-thread block (DPP wave scans) */
+int ssme_pf_test_block_scan(int32_t device, const uint64_t* in2048, uint64_t* incl2048, uint64_t* total);
+/* n Gamma(shape) draws for tiles 0..n-1 at time t of filter `rep` */
+int ssme_pf_test_gamma(int32_t device, uint64_t seed, uint32_t rep, int32_t t, double shape, int32_t n, double* out);
 
 const char* ssme_pf_strerror(int status);
 const char* ssme_pf_last_error(ssme_pf_handle h);

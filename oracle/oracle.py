@@ -16,7 +16,6 @@ _SO = os.path.join(_HERE, "libssme_oracle.so")
 MODEL_SVOL, MODEL_SVOL_LEVERAGE, MODEL_LIN_GAUSS = 0, 1, 2
 RESAMP_MULTINOMIAL, RESAMP_SYSTEMATIC, RESAMP_STRATIFIED, RESAMP_MULTINOMIAL_IID = 0, 1, 2, 3
 TILE = 2048
-ROW = 512
 
 
 def build(force=False):
@@ -40,7 +39,12 @@ def lib():
             f.argtypes = [dp, dp, C.c_long]
         L.orc_sincos2pi.argtypes = [dp, dp, dp, C.c_long]
         L.orc_normals.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, dp]
-        L.orc_rows_scan.argtypes = [dp, C.c_int, dp, dp, dp]
+        u64p = C.POINTER(C.c_uint64)
+        L.orc_exp_scaled.argtypes = [dp, C.c_int, dp, C.c_long]
+        L.orc_gamma.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_double, C.c_int, dp]
+        L.orc_quantize.argtypes = [dp, C.c_int, u64p, C.c_long]
+        L.orc_pf_sum_int.restype = C.c_uint64
+        L.orc_pf_sum_int.argtypes = [C.c_void_p]
         L.orc_pf_create.restype = C.c_void_p
         L.orc_pf_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, dp]
         L.orc_pf_destroy.argtypes = [C.c_void_p]
@@ -51,7 +55,7 @@ def lib():
         L.orc_pf_loglik.argtypes = [C.c_void_p]
         L.orc_pf_run_series.restype = C.c_double
         L.orc_pf_run_series.argtypes = [C.c_void_p, dp, dp, C.c_int, dp]
-        L.orc_pf_state.argtypes = [C.c_void_p, dp, dp, dp, u32p, dp, dp, dp]
+        L.orc_pf_state.argtypes = [C.c_void_p, dp, dp, u64p, u32p, u64p, dp]
         L.orc_pf_expectation.restype = C.c_double
         L.orc_pf_expectation.argtypes = [C.c_void_p, C.c_int]
         L.orc_ref_run_series.restype = C.c_double
@@ -112,13 +116,28 @@ def normals(seed, rep, t, n):
     return out
 
 
-def rows_scan(v):
-    v = np.ascontiguousarray(v, dtype=np.float64)
-    assert v.size % ROW == 0
-    incl, excl = np.empty_like(v), np.empty_like(v)
-    tot = np.zeros(1)
-    lib().orc_rows_scan(_dp(v), v.size // ROW, _dp(incl), _dp(excl), _dp(tot))
-    return incl, excl, float(tot[0])
+def _u64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64)) if a is not None else None
+
+
+def exp_scaled(x, sc):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    lib().orc_exp_scaled(_dp(x), int(sc), _dp(y), x.size)
+    return y
+
+
+def gamma_draws(seed, rep, t, shape, n):
+    out = np.empty(n, dtype=np.float64)
+    lib().orc_gamma(seed, rep, t, float(shape), n, _dp(out))
+    return out
+
+
+def quantize(x, sc):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    q = np.empty(x.size, dtype=np.uint64)
+    lib().orc_quantize(_dp(x), int(sc), _u64p(q), x.size)
+    return q
 
 
 class Filter:
@@ -154,11 +173,13 @@ class Filter:
 
     def state(self):
         n = self.n
-        x, lw, loc = np.empty(n), np.empty(n), np.empty(n)
+        x, lw = np.empty(n), np.empty(n)
+        loc = np.empty(n, dtype=np.uint64)
         anc = np.empty(n, dtype=np.uint32)
-        A, P, sc = np.empty(self.nt), np.empty(self.nt), np.empty(2)
-        lib().orc_pf_state(self._h, _dp(x), _dp(lw), _dp(loc), _u32p(anc), _dp(A), _dp(P), _dp(sc))
-        return dict(x=x, logw=lw, cdf=loc, anc=anc, A=A, P=P, m=sc[0], S=sc[1])
+        A, sc = np.empty(self.nt, dtype=np.uint64), np.empty(3)
+        lib().orc_pf_state(self._h, _dp(x), _dp(lw), _u64p(loc), _u32p(anc), _u64p(A), _dp(sc))
+        return dict(x=x, logw=lw, cdf=loc, anc=anc, A=A, m=sc[0], S=int(lib().orc_pf_sum_int(self._h)),
+                    rshift=int(sc[2]))
 
     def expectation(self, kind):
         return lib().orc_pf_expectation(self._h, kind)

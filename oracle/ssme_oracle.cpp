@@ -21,9 +21,9 @@
 //  (A) "reference-faithful": std::mt19937 + std::normal_distribution +
 //      std::discrete_distribution, reference operation order in logGEv.  Used for the
 //      statistical cross-check and as bench.py's cpu_baseline ("port").
-//  (B) "kernel-matched": Philox4x32-10 counter RNG, libm-free fp64 math, and the
-//      canonical summation tree documented in DESIGN.md section 4.  The HIP kernels are
-//      compared BIT FOR BIT against this mode.
+//  (B) "kernel-matched": Philox4x32-10 counter RNG, libm-free fp64 math, and the exact
+//      fixed-point weight cdf documented in DESIGN.md section 4 (integer sums: no summation
+//      tree to mirror).  The HIP kernels are compared BIT FOR BIT against this mode.
 //
 // Reference lines followed (all relative to /root/reference):
 //   model callbacks      example/univ_svol_bootstrap_filter.h:55-103   (svol_bs)
@@ -87,18 +87,16 @@ inline double bits_to_double(uint64_t u) { double d; std::memcpy(&d, &u, 8); ret
 inline uint64_t double_to_bits(double d) { uint64_t u; std::memcpy(&u, &d, 8); return u; }
 inline double pow2i(int n) { return bits_to_double((uint64_t)(n + 1023) << 52); }   // n in [-1022,1023]
 
-double o_exp(double x) {
-    if (x != x) return x;
-    if (x > 709.782712893384) return std::numeric_limits<double>::infinity();
-    if (x < -745.1332191019412) return 0.0;
+// exp(x) * 2^sc.  Clamp squashes NaN to the lower bound (fmax/fmin = IEEE maxNum/minNum).
+double o_exp_scaled(double x, int sc) {
     const double LOG2E = 1.4426950408889634074;
     const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
     const double SH = 6755399441055744.0;  // 1.5 * 2^52
-    const double kf = (x * LOG2E + SH) - SH;
+    const double xc = std::fmin(std::fmax(x, -746.0), 710.0);
+    const double kf = std::fma(xc, LOG2E, SH) - SH;
     const int k = (int)kf;
-    double r = std::fma(-kf, LN2_HI, x);
+    double r = std::fma(-kf, LN2_HI, xc);
     r = std::fma(-kf, LN2_LO, r);
-    // q = sum_{n=2..13} r^(n-2)/n!
     double q = 1.6059043836821613e-10;            // 1/13!
     q = std::fma(q, r, 2.08767569878681e-09);     // 1/12!
     q = std::fma(q, r, 2.505210838544172e-08);    // 1/11!
@@ -113,9 +111,9 @@ double o_exp(double x) {
     q = std::fma(q, r, 0.5);                      // 1/2!
     const double e = std::fma(r * r, q, r);
     const double p = 1.0 + e;
-    const int k1 = k / 2, k2 = k - k1;
-    return (p * pow2i(k1)) * pow2i(k2);
+    return std::ldexp(p, k + sc);
 }
+double o_exp(double x) { return o_exp_scaled(x, 0); }
 
 double o_log(double x) {
     if (x != x) return x;
@@ -263,66 +261,28 @@ inline double m_logg(const ModelConst& c, double y, double x) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Canonical summation tree.  A "row" is 512 values owned by 256
-// threads x 2 consecutive values; 4 waves of 64 lanes.  Up to 4 rows form a tile (2048).
+// Exact fixed-point weight cdf.
+//   q_i   = round-to-nearest-even( exp(logw_i - m) * 2^r ),  r = 62 - ceil(log2(Npad))
+//   C_j   = sum_{i<=j} q_i          (uint64, EXACT: no summation tree, monotone by construction)
+//   anc   = #{ j : C_j < ceil(tau) }  clamped to N-1,  tau = U * (double)C_{N-1}
+// The device keeps C as tile-local sums loc_j plus exact tile prefixes; the result is the same
+// integer count whatever the kernel's scan/search strategy.
 // ---------------------------------------------------------------------------------------
-constexpr int ROW = 512, TILE = 2048, THREADS = 256, WAVE = 64;
+constexpr int TILE = 2048;
+constexpr int E_SHIFT = 45;                   // exponential spacings: qE = round(E * 2^45)
+constexpr double TWO52 = 4503599627370496.0;
+constexpr uint64_t MASK52 = (1ull << 52) - 1;
 
-struct RowScan { double base[THREADS]; double s0[THREADS]; double s1[THREADS]; double total; };
-
-// scan one row: base[tid] = O_w + exc_lane ; value(c) = base + s_c ; total = O_3 + W_3
-void row_scan(const double* v, RowScan& rs) {
-    double inc[THREADS];
-    for (int tid = 0; tid < THREADS; ++tid) {
-        rs.s0[tid] = v[2 * tid];
-        rs.s1[tid] = rs.s0[tid] + v[2 * tid + 1];
-        inc[tid] = rs.s1[tid];
-    }
-    for (int w = 0; w < THREADS / WAVE; ++w) {                 // Kogge-Stone inside each wave
-        double* p = inc + w * WAVE;
-        for (int d = 1; d < WAVE; d <<= 1) {
-            double nxt[WAVE];
-            for (int l = 0; l < WAVE; ++l) nxt[l] = (l >= d) ? p[l] + p[l - d] : p[l];
-            std::memcpy(p, nxt, sizeof(nxt));
-        }
-    }
-    double O[4];
-    O[0] = 0.0;
-    for (int w = 1; w < 4; ++w) O[w] = O[w - 1] + inc[(w - 1) * WAVE + WAVE - 1];
-    rs.total = O[3] + inc[3 * WAVE + WAVE - 1];
-    for (int tid = 0; tid < THREADS; ++tid) {
-        const int w = tid / WAVE, l = tid % WAVE;
-        const double exc = l ? inc[tid - 1] : 0.0;
-        rs.base[tid] = O[w] + exc;
-    }
+inline int ceil_log2(int n) { int k = 0; while ((1ll << k) < n) ++k; return k; }
+// round-to-nearest-even of v in [0, 2^52) via the 2^52 trick (same two ops on the device)
+inline uint64_t rne_u64(double v) { return double_to_bits(v + TWO52) & MASK52; }
+inline uint64_t tau_to_u64(double tau) {
+    double c = std::ceil(tau);
+    c = std::fmin(std::fmax(c, 0.0), 9.2e18);          // NaN -> 0
+    return (uint64_t)c;
 }
 
-// multi-row structure over n = nrows*512 values: inclusive loc[], exclusive ex[], total
-void rows_scan(const double* v, int nrows, double* incl, double* excl, double* total) {
-    std::vector<RowScan> rs(nrows);
-    for (int k = 0; k < nrows; ++k) row_scan(v + k * ROW, rs[k]);
-    std::vector<double> Q(nrows);
-    Q[0] = 0.0;
-    for (int k = 1; k < nrows; ++k) Q[k] = Q[k - 1] + rs[k - 1].total;
-    for (int k = 0; k < nrows; ++k)
-        for (int tid = 0; tid < THREADS; ++tid) {
-            const double b = Q[k] + rs[k].base[tid];
-            if (incl) { incl[k * ROW + 2 * tid] = b + rs[k].s0[tid]; incl[k * ROW + 2 * tid + 1] = b + rs[k].s1[tid]; }
-            if (excl) { excl[k * ROW + 2 * tid] = b; excl[k * ROW + 2 * tid + 1] = b + rs[k].s0[tid]; }
-        }
-    *total = Q[nrows - 1] + rs[nrows - 1].total;
-}
-
-inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
-
-// fixed-probe lower bound over n = 2^k values produced by get(j); returns [0, n-1]
-template <class F>
-inline int lower_bound_pow2(int n, double target, F get) {
-    int pos = 0;
-    for (int step = n >> 1; step >= 1; step >>= 1)
-        if (get(pos + step - 1) < target) pos += step;
-    return pos;
-}
+enum { STREAM_GAMMA = 16 };
 
 // ---------------------------------------------------------------------------------------
 // Kernel-matched filter (mode B), one replicate.
@@ -332,26 +292,26 @@ struct Filter {
     uint32_t key[2];
     uint32_t rep;
     ModelConst mc;
-    int B, Npad, nrows2;
+    int B, Npad, rshift;
     int t;
-    std::vector<double> x, xprev, logw, loc, A, P, Tend, AE;
+    std::vector<double> x, xprev, logw;
+    std::vector<uint64_t> loc, A, Tincl;      // tile-local inclusive sums, tile sums, inclusive tile prefixes
     std::vector<uint32_t> anc;
-    double m, S, prev, loglik, last_ll, G;
-    bool have_resamp_tables;
+    double m, prev, loglik, last_ll;
+    uint64_t Sint;
 
     void init(int model_, int N_, int resamp_, int rs_, uint64_t seed, uint32_t rep_, const double* th) {
         model = model_; N = N_; resamp = resamp_; rs = rs_ < 1 ? 1 : rs_;
         key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32); rep = rep_;
         mc = derive(model, th);
         B = (N + TILE - 1) / TILE; Npad = B * TILE;
-        nrows2 = (B + ROW - 1) / ROW;
-        x.assign(Npad, 0.0); xprev.assign(Npad, 0.0); logw.assign(Npad, 0.0); loc.assign(Npad, 0.0);
-        A.assign(nrows2 * ROW, 0.0); P.assign(nrows2 * ROW, 0.0); Tend.assign(nrows2 * ROW, 0.0);
-        AE.assign(nrows2 * ROW, 0.0);
+        rshift = 62 - ceil_log2(Npad);
+        x.assign(Npad, 0.0); xprev.assign(Npad, 0.0); logw.assign(Npad, 0.0); loc.assign(Npad, 0);
+        A.assign(B, 0); Tincl.assign(B, 0);
         anc.assign(Npad, 0u);
         reset();
     }
-    void reset() { t = 0; loglik = 0.0; last_ll = 0.0; prev = o_log((double)N); m = 0; S = 0; G = 0; have_resamp_tables = false; }
+    void reset() { t = 0; loglik = 0.0; last_ll = 0.0; prev = o_log((double)N); m = 0; Sint = 0; }
 
     // standard normal for particle i at time tt (Box-Muller on the pair i>>1)
     double normal(int i, int tt) const {
@@ -362,7 +322,6 @@ struct Filter {
         double sn, cs; o_sincos2pi(u2, &sn, &cs);
         return (i & 1) ? rad * sn : rad * cs;
     }
-    // per-particle resampling uniform at consuming time tt: [0,1) or (0,1]
     void resamp_words(int i, int tt, uint32_t* a, uint32_t* b) const {
         const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, STREAM_RESAMP};
         uint32_t o[4]; philox4x32_10(ctr, key, o);
@@ -372,40 +331,90 @@ struct Filter {
         const uint32_t ctr[4] = {0u, (uint32_t)tt, rep, STREAM_RESAMP_EXTRA};
         philox4x32_10(ctr, key, o);
     }
+    // Gamma(shape) draw for tile b at time tt: Marsaglia & Tsang (2000), counter-driven attempts
+    double gamma_draw(int b, int tt, double shape) const {
+        const double d = shape - 0.3333333333333333;
+        const double c = 1.0 / std::sqrt(9.0 * d);
+        for (int a = 0; a < 32; ++a) {
+            const uint32_t c1[4] = {(uint32_t)b, (uint32_t)tt, rep, (uint32_t)(STREAM_GAMMA + 2 * a)};
+            const uint32_t c2[4] = {(uint32_t)b, (uint32_t)tt, rep, (uint32_t)(STREAM_GAMMA + 2 * a + 1)};
+            uint32_t o1[4], o2[4];
+            philox4x32_10(c1, key, o1); philox4x32_10(c2, key, o2);
+            const double rad = std::sqrt(-2.0 * o_log(u01_oc(o1[0], o1[1])));
+            double sn, cs; o_sincos2pi(u01_co(o1[2], o1[3]), &sn, &cs);
+            const double xn = rad * cs;
+            const double v = 1.0 + c * xn;
+            if (v > 0.0) {
+                const double v3 = (v * v) * v;
+                const double lhs = o_log(u01_oc(o2[0], o2[1]));
+                const double rhs = ((0.5 * (xn * xn) + d) - d * v3) + d * o_log(v3);
+                if (lhs < rhs) return d * v3;
+            }
+        }
+        return d;
+    }
 
-    // targets for the ancestors consumed at time tt (drawn against the cdf of step tt-1)
-    void targets(int tt, std::vector<double>& tau) const {
-        tau.assign(Npad, 0.0);
+    // integer targets for the ancestors consumed at time tt (drawn against the cdf of step tt-1)
+    void targets(int tt, std::vector<uint64_t>& tau) const {
+        tau.assign(N, 0);
+        const double Sd = (double)Sint;
         if (resamp == RESAMP_MULTINOMIAL) {
-            // exponential spacings (liu_west_filter.h:105-139): U_(i) = sum_{j<=i} E_j / G
-            std::vector<double> E(Npad, 0.0), locE(Npad), AEv(nrows2 * ROW, 0.0), PE(nrows2 * ROW);
-            for (int i = 0; i < N; ++i) { uint32_t a, b; resamp_words(i, tt, &a, &b); E[i] = -o_log(u01_oc(a, b)); }
-            for (int b = 0; b < B; ++b) rows_scan(&E[b * TILE], 4, &locE[b * TILE], nullptr, &AEv[b]);
-            double Etot; rows_scan(AEv.data(), nrows2, nullptr, PE.data(), &Etot);
+            // multinomial by sorted uniforms = exponential spacings (liu_west_filter.h:105-139):
+            //   U_(i) = sum_{j<=i} E_j / sum_{j<=N+1} E_j.
+            // Per tile the spacings are generated as Gamma_b * (E_j / sum_tile E), with
+            // Gamma_b ~ Gamma(n_b) drawn directly: the normalised spacings are Dirichlet(1..1) and
+            // independent of their sum, so the joint law of the U_(i) is unchanged.
+            std::vector<double> gam(B), pgam(B);
+            double run = 0.0;
+            for (int b = 0; b < B; ++b) {
+                const int nb = std::min(TILE, N - b * TILE);
+                gam[b] = gamma_draw(b, tt, (double)nb);
+                pgam[b] = run;
+                run = run + gam[b];
+            }
             uint32_t o[4]; extra_words(tt, o);
-            const double Gv = Etot + (-o_log(u01_oc(o[0], o[1])));
-            const double scale = S / Gv;
-            for (int i = 0; i < N; ++i) tau[i] = (PE[i / TILE] + locE[i]) * scale;
+            const double G = run + (-o_log(u01_oc(o[0], o[1])));
+            const double scale = Sd / G;
+            for (int b = 0; b < B; ++b) {
+                const int nb = std::min(TILE, N - b * TILE);
+                std::vector<uint64_t> locE(nb);
+                uint64_t s = 0;
+                for (int j = 0; j < nb; ++j) {
+                    uint32_t wa, wb; resamp_words(b * TILE + j, tt, &wa, &wb);
+                    const double E = -o_log(u01_oc(wa, wb));
+                    s += double_to_bits(std::fma(E, 35184372088832.0 /* 2^45 */, TWO52)) & MASK52;
+                    locE[j] = s;
+                }
+                const double ratio = gam[b] / (double)s;
+                for (int j = 0; j < nb; ++j) {
+                    const double t1 = ratio * (double)locE[j];
+                    const double t2 = pgam[b] + t1;
+                    tau[b * TILE + j] = tau_to_u64(t2 * scale);
+                }
+            }
         } else if (resamp == RESAMP_SYSTEMATIC) {
             uint32_t o[4]; extra_words(tt, o);
             const double u0 = u01_co(o[0], o[1]);
-            const double scale = S / (double)N;
-            for (int i = 0; i < N; ++i) tau[i] = ((double)i + u0) * scale;
+            const double scale = Sd / (double)N;
+            for (int i = 0; i < N; ++i) tau[i] = tau_to_u64(((double)i + u0) * scale);
         } else if (resamp == RESAMP_STRATIFIED) {
-            const double scale = S / (double)N;
-            for (int i = 0; i < N; ++i) { uint32_t a, b; resamp_words(i, tt, &a, &b); tau[i] = ((double)i + u01_co(a, b)) * scale; }
+            const double scale = Sd / (double)N;
+            for (int i = 0; i < N; ++i) { uint32_t a, b; resamp_words(i, tt, &a, &b); tau[i] = tau_to_u64(((double)i + u01_co(a, b)) * scale); }
         } else {
-            for (int i = 0; i < N; ++i) { uint32_t a, b; resamp_words(i, tt, &a, &b); tau[i] = u01_co(a, b) * S; }
+            for (int i = 0; i < N; ++i) { uint32_t a, b; resamp_words(i, tt, &a, &b); tau[i] = tau_to_u64(u01_co(a, b) * Sd); }
         }
     }
 
-    int search(double target) const {
-        const int Bp = next_pow2(B);
-        const int b = lower_bound_pow2(Bp, target, [&](int j) { return j < B ? Tend[j] : POS_INF; });
-        const int bb = std::min(b, B - 1);
-        const double Pb = P[bb];
-        const int j = lower_bound_pow2(TILE, target, [&](int q) { return Pb + loc[bb * TILE + q]; });
-        return std::min(bb * TILE + j, N - 1);
+    // anc = #{ j : C_j < tau } (global exact cdf), expressed through tiles as the device does
+    int search(uint64_t tau) const {
+        int b = (int)(std::lower_bound(Tincl.begin(), Tincl.end(), tau) - Tincl.begin());   // #{T_b < tau}
+        if (b > B - 1) b = B - 1;
+        const uint64_t Pb = Tincl[b] - A[b];
+        const uint64_t tl = tau - Pb;                                    // unsigned, as on the device
+        const uint64_t* tile = &loc[(size_t)b * TILE];
+        int j = (int)(std::lower_bound(tile, tile + TILE, tl) - tile);   // #{loc_j < tl}
+        if (j > TILE - 1) j = TILE - 1;
+        return std::min(b * TILE + j, N - 1);
     }
 
     double step(double y, double zcov) {
@@ -416,24 +425,31 @@ struct Filter {
         } else {
             xprev.swap(x);
             if (resampled_prev) {
-                std::vector<double> tau; targets(t, tau);
-                for (int i = 0; i < N; ++i) { anc[i] = (uint32_t)search(tau[i]); }
+                std::vector<uint64_t> tau; targets(t, tau);
+                for (int i = 0; i < N; ++i) anc[i] = (uint32_t)search(tau[i]);
                 for (int i = 0; i < N; ++i) x[i] = m_prop(mc, xprev[anc[i]], normal(i, t), zcov);
             } else {
                 for (int i = 0; i < N; ++i) { lw_old[i] = logw[i]; x[i] = m_prop(mc, xprev[i], normal(i, t), zcov); }
             }
         }
         for (int i = 0; i < N; ++i) logw[i] = lw_old[i] + m_logg(mc, y, x[i]);
-        // max: fold of fmax from -inf (NaN-ignoring)
-        double mx = NEG_INF;
-        for (int i = 0; i < N; ++i) if (logw[i] > mx) mx = logw[i];
-        m = mx;
-        std::vector<double> w(Npad, 0.0);
-        for (int i = 0; i < N; ++i) w[i] = o_exp(logw[i] - m);
-        for (int b = 0; b < B; ++b) rows_scan(&w[b * TILE], 4, &loc[b * TILE], nullptr, &A[b]);
-        rows_scan(A.data(), nrows2, nullptr, P.data(), &S);
-        for (int b = 0; b < B; ++b) Tend[b] = P[b] + A[b];
-        const double lse = m + o_log(S);
+        // NaN-propagating max: any NaN log-weight -> NaN log-likelihood (as the reference's sums)
+        double mx = NEG_INF; bool nan = false;
+        for (int i = 0; i < N; ++i) { if (logw[i] != logw[i]) nan = true; else if (logw[i] > mx) mx = logw[i]; }
+        m = nan ? std::numeric_limits<double>::quiet_NaN() : mx;
+        uint64_t run = 0;
+        for (int b = 0; b < B; ++b) {
+            uint64_t s = 0;
+            for (int j = 0; j < TILE; ++j) {
+                const int i = b * TILE + j;
+                if (i < N) s += rne_u64(o_exp_scaled(logw[i] - m, rshift));
+                loc[i] = s;
+            }
+            A[b] = s; run += s; Tincl[b] = run;
+        }
+        Sint = run;
+        const double Sd = Sint ? std::ldexp((double)Sint, -rshift) : std::numeric_limits<double>::quiet_NaN();
+        const double lse = m + o_log(Sd);
         last_ll = lse - prev;
         loglik += last_ll;
         const bool resample_now = ((t + 1) % rs == 0);
@@ -442,6 +458,7 @@ struct Filter {
         return last_ll;
     }
 };
+
 
 // ---------------------------------------------------------------------------------------
 // Mode A: reference-faithful scalar filter (mt19937, <random>), templated on float type.
@@ -542,8 +559,14 @@ void orc_normals(uint64_t seed, uint32_t rep, int t, int n, double* out) {
     Filter f; double th[3] = {1.0, 0.5, 0.1}; f.init(MODEL_SVOL, n, 0, 1, seed, rep, th);
     for (int i = 0; i < n; ++i) out[i] = f.normal(i, t);
 }
-// scan tree exposed for direct unit tests: n = nrows*512
-void orc_rows_scan(const double* v, int nrows, double* incl, double* excl, double* total) { rows_scan(v, nrows, incl, excl, total); }
+void orc_exp_scaled(const double* x, int sc, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_exp_scaled(x[i], sc); }
+// Gamma(shape) draws for tiles b = 0..n-1 at time t (Marsaglia-Tsang, counter driven)
+void orc_gamma(uint64_t seed, uint32_t rep, int t, double shape, int n, double* out) {
+    Filter f; double th[3] = {1.0, 0.5, 0.1}; f.init(MODEL_SVOL, 2048, 0, 1, seed, rep, th);
+    for (int b = 0; b < n; ++b) out[b] = f.gamma_draw(b, t, shape);
+}
+// fixed-point quantisation of weights: q = rne(exp(x) * 2^sc) for x <= 0
+void orc_quantize(const double* x, int sc, uint64_t* q, long n) { for (long i = 0; i < n; ++i) q[i] = rne_u64(o_exp_scaled(x[i], sc)); }
 
 void* orc_pf_create(int model, int N, int resamp, int rs, uint64_t seed, uint32_t rep, const double* theta) {
     Filter* f = new Filter(); f->init(model, N, resamp, rs, seed, rep, theta); return f;
@@ -557,18 +580,18 @@ double orc_pf_run_series(void* h, const double* y, const double* z, int T, doubl
     for (int t = 0; t < T; ++t) { const double l = f->step(y[t], z ? z[t] : 0.0); if (per_step) per_step[t] = l; }
     return f->loglik;
 }
-// state after the last step: particles (pre-resampling), log-weights, tile-local cdf,
-// ancestors used by the last step, tile aggregates / prefixes, scalars {m, S}
-void orc_pf_state(void* h, double* x, double* logw, double* loc, uint32_t* anc, double* A, double* P, double* scal) {
+// state after the last step: particles (pre-resampling), log-weights, tile-local integer cdf,
+// ancestors used by the last step, integer tile sums, scalars {m, (double)S_int, r}
+void orc_pf_state(void* h, double* x, double* logw, uint64_t* loc, uint32_t* anc, uint64_t* A, double* scal) {
     Filter* f = (Filter*)h;
     if (x) std::memcpy(x, f->x.data(), sizeof(double) * f->N);
     if (logw) std::memcpy(logw, f->logw.data(), sizeof(double) * f->N);
-    if (loc) std::memcpy(loc, f->loc.data(), sizeof(double) * f->N);
+    if (loc) std::memcpy(loc, f->loc.data(), sizeof(uint64_t) * f->N);
     if (anc) std::memcpy(anc, f->anc.data(), sizeof(uint32_t) * f->N);
-    if (A) std::memcpy(A, f->A.data(), sizeof(double) * f->B);
-    if (P) std::memcpy(P, f->P.data(), sizeof(double) * f->B);
-    if (scal) { scal[0] = f->m; scal[1] = f->S; }
+    if (A) std::memcpy(A, f->A.data(), sizeof(uint64_t) * f->B);
+    if (scal) { scal[0] = f->m; scal[1] = (double)f->Sint; scal[2] = (double)f->rshift; }
 }
+uint64_t orc_pf_sum_int(void* h) { return ((Filter*)h)->Sint; }
 // weighted expectation of a built-in functional, pre-resampling (liu_west_filter.h:1662-1683)
 // kind: 0 = x, 1 = x^2, 2 = exp(x/2) (volatility), 3 = constant 42 (test_pswarm.cpp:252 KAT)
 double orc_pf_expectation(void* h, int kind) {

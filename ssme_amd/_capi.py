@@ -23,7 +23,8 @@ EXPORTS = [
     "ssme_pf_run_series", "ssme_pf_get_per_step", "ssme_pf_get_loglik", "ssme_pf_get_expectations",
     "ssme_pf_log_mean_exp", "ssme_pf_download_state", "ssme_pf_download_scalars", "ssme_pf_set_debug",
     "ssme_pf_set_graph_mode", "ssme_pf_last_elapsed_ms", "ssme_pf_profile_series", "ssme_pf_test_math",
-    "ssme_pf_test_philox", "ssme_pf_test_rows_scan", "ssme_pf_strerror", "ssme_pf_last_error",
+    "ssme_pf_test_philox", "ssme_pf_test_quantize", "ssme_pf_test_block_scan", "ssme_pf_test_gamma",
+    "ssme_pf_strerror", "ssme_pf_last_error",
     "ssme_pf_version",
 ]
 
@@ -53,6 +54,7 @@ def lib():
                           "there is no CPU fallback")
         L = C.CDLL(SO_PATH)
         dp, u32p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
+        u64p = C.POINTER(C.c_uint64)
         H = C.c_void_p
         L.ssme_pf_create.argtypes = [C.POINTER(Config), C.POINTER(H)]
         L.ssme_pf_destroy.argtypes = [H]
@@ -64,15 +66,17 @@ def lib():
         L.ssme_pf_get_loglik.argtypes = [H, dp]
         L.ssme_pf_get_expectations.argtypes = [H, C.c_int32, dp]
         L.ssme_pf_log_mean_exp.argtypes = [H, dp]
-        L.ssme_pf_download_state.argtypes = [H, C.c_int32, dp, dp, dp, u32p]
-        L.ssme_pf_download_scalars.argtypes = [H, C.c_int32, dp, dp, dp, dp]
+        L.ssme_pf_download_state.argtypes = [H, C.c_int32, dp, dp, u64p, u32p]
+        L.ssme_pf_download_scalars.argtypes = [H, C.c_int32, dp, u64p, u64p, i32p]
         L.ssme_pf_set_debug.argtypes = [H, C.c_int32]
         L.ssme_pf_set_graph_mode.argtypes = [H, C.c_int32]
         L.ssme_pf_last_elapsed_ms.argtypes = [H, C.POINTER(C.c_float)]
         L.ssme_pf_profile_series.argtypes = [H, dp, dp, C.c_int32, dp, i32p]
         L.ssme_pf_test_math.argtypes = [C.c_int32, C.c_int32, dp, dp, C.c_int64]
         L.ssme_pf_test_philox.argtypes = [C.c_int32, u32p, u32p, u32p]
-        L.ssme_pf_test_rows_scan.argtypes = [C.c_int32, dp, C.c_int32, dp, dp, dp]
+        L.ssme_pf_test_quantize.argtypes = [C.c_int32, dp, C.c_int32, u64p, C.c_int64]
+        L.ssme_pf_test_block_scan.argtypes = [C.c_int32, u64p, u64p, u64p]
+        L.ssme_pf_test_gamma.argtypes = [C.c_int32, C.c_uint64, C.c_uint32, C.c_int32, C.c_double, C.c_int32, dp]
         L.ssme_pf_strerror.restype = C.c_char_p
         L.ssme_pf_strerror.argtypes = [C.c_int]
         L.ssme_pf_last_error.restype = C.c_char_p
@@ -91,6 +95,10 @@ def dptr(a):
 
 def u32ptr(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def u64ptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint64))
 
 
 def check(status, handle=None):

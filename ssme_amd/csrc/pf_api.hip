@@ -15,7 +15,8 @@ using namespace ssme;
 
 struct ssme_pf_s {
     ssme_pf_config cfg;
-    int N, R, Npad, B, Bs, nrows2, Bpow2;
+    int N, R, Npad, B, Bs, Bpow2, rshift;
+    size_t ka_lds;
     int t;                   // next time index
     bool params_set;
     bool last_step_finalized;
@@ -25,8 +26,11 @@ struct ssme_pf_s {
     hipEvent_t ev0, ev1;
     float last_ms;
     // device
-    double *xa, *xb, *logw, *cdf, *tile_sum, *tile_esum, *tile_max, *ybuf, *zbuf, *per_step, *scratchR;
+    double *xa, *xb, *logw, *tile_max, *ybuf, *zbuf, *per_step, *scratchR;
+    double *gam, *pgam, *gtot;   // Gamma tables of the multinomial resampler, gcap time rows
+    u64 *cdf, *tile_sum;
     uint32_t* anc;
+    int gcap;
     FilterScalars* scal;
     ModelConst* mc;
     int cur;                 // which of xa/xb holds the latest particles
@@ -45,6 +49,7 @@ static int fail(ssme_pf_handle h, int code, const char* what, hipError_t e) {
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, SSME_ERR_HIP, #call, e_); } while (0)
 
 static int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+static int ceil_log2(int n) { int k = 0; while ((1ll << k) < n) ++k; return k; }
 
 // Derived constants; operation order mirrors oracle/ssme_oracle.cpp derive().
 static ModelConst derive(int model, const double* th) {
@@ -79,23 +84,39 @@ static int n_theta_of(int model) { return model == SSME_MODEL_SVOL_LEVERAGE ? 4 
 static StepArgs base_args(ssme_pf_handle h) {
     StepArgs a{};
     a.logw = h->logw; a.cdf = h->cdf; a.anc = h->debug_anc ? h->anc : nullptr;
-    a.tile_sum = h->tile_sum; a.tile_esum = h->tile_esum; a.tile_max = h->tile_max;
+    a.tile_sum = h->tile_sum; a.tile_max = h->tile_max;
     a.scal = h->scal; a.mc = h->mc; a.y = h->ybuf; a.z = nullptr; a.per_step = nullptr;
-    a.N = h->N; a.Npad = h->Npad; a.B = h->B; a.Bs = h->Bs; a.nrows2 = h->nrows2; a.Bpow2 = h->Bpow2;
+    a.gam = h->gam; a.pgam = h->pgam; a.gtot = h->gtot;
+    a.N = h->N; a.Npad = h->Npad; a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = h->R;
     a.Tcap = h->tcap;
-    a.model = h->cfg.model; a.resampler = h->cfg.resampler; a.resamp_sched = h->cfg.resamp_sched;
+    a.resampler = h->cfg.resampler; a.resamp_sched = h->cfg.resamp_sched;
     a.key0 = (uint32_t)h->cfg.seed; a.key1 = (uint32_t)(h->cfg.seed >> 32); a.first_filter = h->cfg.first_filter_id;
     a.logN = dlog((double)h->N);
     return a;
 }
 
+template <int MODEL>
+static hipError_t set_ka_lds(size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ka_propagate_weight<MODEL>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 static void launch_ka(ssme_pf_handle h, const StepArgs& a) {
     dim3 grid(h->B, h->R), block(kThreads);
     switch (h->cfg.model) {
-        case SSME_MODEL_SVOL: hipLaunchKernelGGL(ka_propagate_weight<MODEL_SVOL>, grid, block, 0, h->stream, a); break;
-        case SSME_MODEL_SVOL_LEVERAGE: hipLaunchKernelGGL(ka_propagate_weight<MODEL_SVOL_LEVERAGE>, grid, block, 0, h->stream, a); break;
-        default: hipLaunchKernelGGL(ka_propagate_weight<MODEL_LIN_GAUSS>, grid, block, 0, h->stream, a); break;
+        case SSME_MODEL_SVOL: hipLaunchKernelGGL(ka_propagate_weight<MODEL_SVOL>, grid, block, h->ka_lds, h->stream, a); break;
+        case SSME_MODEL_SVOL_LEVERAGE: hipLaunchKernelGGL(ka_propagate_weight<MODEL_SVOL_LEVERAGE>, grid, block, h->ka_lds, h->stream, a); break;
+        default: hipLaunchKernelGGL(ka_propagate_weight<MODEL_LIN_GAUSS>, grid, block, h->ka_lds, h->stream, a); break;
     }
+}
+// Gamma tables for time indices t0 .. t0+nT-1 into table rows 0 .. nT-1
+static void launch_gamma(ssme_pf_handle h, int t0, int nT) {
+    if (h->cfg.resampler != SSME_RESAMP_MULTINOMIAL) return;
+    const uint32_t k0 = (uint32_t)h->cfg.seed, k1 = (uint32_t)(h->cfg.seed >> 32);
+    hipLaunchKernelGGL(k_gamma_draw, dim3((h->B + kThreads - 1) / kThreads, nT, h->R), dim3(kThreads), 0, h->stream,
+                       h->gam, h->N, h->B, h->R, t0, k0, k1, h->cfg.first_filter_id);
+    hipLaunchKernelGGL(k_gamma_prefix, dim3((nT * h->R + kThreads - 1) / kThreads), dim3(kThreads), 0, h->stream,
+                       h->gam, h->pgam, h->gtot, h->B, h->R, nT, t0, k0, k1, h->cfg.first_filter_id);
 }
 static void launch_kr(ssme_pf_handle h, const StepArgs& a) {
     hipLaunchKernelGGL(kr_normalize_scan, dim3(h->B, h->R), dim3(kThreads), 0, h->stream, a);
@@ -105,13 +126,13 @@ static void launch_kf(ssme_pf_handle h, const StepArgs& a) {
 }
 
 // enqueue one filter step (KA, KR) at time index t reading y[yi]
-static void enqueue_step(ssme_pf_handle h, int t, int yi, bool has_z, bool finalize_prev, bool record_per_step) {
+static void enqueue_step(ssme_pf_handle h, int t, int yi, int gi, bool has_z, bool finalize_prev, bool record_per_step) {
     StepArgs a = base_args(h);
     a.x_in = h->cur ? h->xb : h->xa;
     a.x_out = h->cur ? h->xa : h->xb;
     a.z = has_z ? h->zbuf : nullptr;
     a.per_step = record_per_step ? h->per_step : nullptr;
-    a.t = t; a.yi = yi; a.finalize_prev = finalize_prev ? 1 : 0;
+    a.t = t; a.yi = yi; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
     launch_ka(h, a);
     launch_kr(h, a);
     h->cur ^= 1;
@@ -125,6 +146,17 @@ static int ensure_series_capacity(ssme_pf_handle h, int T) {
         HIPCHK(hipMalloc(&h->ybuf, sizeof(double) * T));
         HIPCHK(hipMalloc(&h->zbuf, sizeof(double) * T));
         h->ycap = T;
+        if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+    }
+    if (h->cfg.resampler == SSME_RESAMP_MULTINOMIAL && T > h->gcap) {
+        if (h->gam) hipFree(h->gam);
+        if (h->pgam) hipFree(h->pgam);
+        if (h->gtot) hipFree(h->gtot);
+        h->gam = h->pgam = h->gtot = nullptr;
+        HIPCHK(hipMalloc(&h->gam, sizeof(double) * (size_t)T * h->R * h->B));
+        HIPCHK(hipMalloc(&h->pgam, sizeof(double) * (size_t)T * h->R * h->B));
+        HIPCHK(hipMalloc(&h->gtot, sizeof(double) * (size_t)T * h->R));
+        h->gcap = T;
         if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     }
     if (T > h->tcap) {
@@ -178,7 +210,9 @@ int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) {
     if (!h) return SSME_ERR_INVALID_ARG;
     h->cfg = *cfg;
     h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * kTile;
-    h->nrows2 = (B + kRow - 1) / kRow; h->Bs = h->nrows2 * kRow; h->Bpow2 = next_pow2(B);
+    h->Bs = (B + 1) & ~1; h->Bpow2 = next_pow2(B);
+    h->rshift = 62 - ceil_log2(h->Npad);
+    h->ka_lds = sizeof(u64) * ((size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2) + (size_t)kStageTiles * kTile);
     h->graph_mode = 1;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) { delete h; return SSME_ERR_HIP; }
@@ -190,19 +224,20 @@ int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) {
         HIPCHK(hipMalloc(&h->xa, sizeof(double) * np));
         HIPCHK(hipMalloc(&h->xb, sizeof(double) * np));
         HIPCHK(hipMalloc(&h->logw, sizeof(double) * np));
-        HIPCHK(hipMalloc(&h->cdf, sizeof(double) * np));
-        HIPCHK(hipMalloc(&h->tile_sum, sizeof(double) * nb));
-        HIPCHK(hipMalloc(&h->tile_esum, sizeof(double) * nb));
+        HIPCHK(hipMalloc(&h->cdf, sizeof(u64) * np));
+        HIPCHK(hipMalloc(&h->tile_sum, sizeof(u64) * nb));
         HIPCHK(hipMalloc(&h->tile_max, sizeof(double) * nb));
+        HIPCHK(set_ka_lds<MODEL_SVOL>(h->ka_lds));
+        HIPCHK(set_ka_lds<MODEL_SVOL_LEVERAGE>(h->ka_lds));
+        HIPCHK(set_ka_lds<MODEL_LIN_GAUSS>(h->ka_lds));
         HIPCHK(hipMalloc(&h->scal, sizeof(FilterScalars) * h->R));
         HIPCHK(hipMalloc(&h->mc, sizeof(ModelConst) * h->R));
         HIPCHK(hipMalloc(&h->scratchR, sizeof(double) * h->R));
         HIPCHK(hipMemset(h->xa, 0, sizeof(double) * np));
         HIPCHK(hipMemset(h->xb, 0, sizeof(double) * np));
         HIPCHK(hipMemset(h->logw, 0, sizeof(double) * np));
-        HIPCHK(hipMemset(h->cdf, 0, sizeof(double) * np));
-        HIPCHK(hipMemset(h->tile_sum, 0, sizeof(double) * nb));
-        HIPCHK(hipMemset(h->tile_esum, 0, sizeof(double) * nb));
+        HIPCHK(hipMemset(h->cdf, 0, sizeof(u64) * np));
+        HIPCHK(hipMemset(h->tile_sum, 0, sizeof(u64) * nb));
         HIPCHK(hipMemset(h->tile_max, 0, sizeof(double) * nb));
         return ensure_series_capacity(h, 1);
     }();
@@ -216,8 +251,8 @@ int ssme_pf_destroy(ssme_pf_handle h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->gexec) hipGraphExecDestroy(h->gexec);
-    void* bufs[] = {h->xa, h->xb, h->logw, h->cdf, h->tile_sum, h->tile_esum, h->tile_max, h->ybuf, h->zbuf,
-                    h->per_step, h->scratchR, h->anc, h->scal, h->mc};
+    void* bufs[] = {h->xa, h->xb, h->logw, h->cdf, h->tile_sum, h->tile_max, h->ybuf, h->zbuf,
+                    h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -269,7 +304,8 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (z) HIPCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double), hipMemcpyHostToDevice, h->stream));
-    enqueue_step(h, h->t, 0, z != nullptr, /*finalize_prev=*/false, /*per_step=*/false);
+    if (h->t > 0 && h->t % h->cfg.resamp_sched == 0) launch_gamma(h, h->t, 1);
+    enqueue_step(h, h->t, 0, 0, z != nullptr, /*finalize_prev=*/false, /*per_step=*/false);
     StepArgs a = base_args(h);
     a.t = h->t;
     launch_kf(h, a);
@@ -287,7 +323,8 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
 }
 
 static void enqueue_series(ssme_pf_handle h, int T, bool has_z) {
-    for (int t = 0; t < T; ++t) enqueue_step(h, t, t, has_z, /*finalize_prev=*/t > 0, /*per_step=*/true);
+    launch_gamma(h, 0, T);
+    for (int t = 0; t < T; ++t) enqueue_step(h, t, t, t, has_z, /*finalize_prev=*/t > 0, /*per_step=*/true);
     StepArgs a = base_args(h);
     a.t = T - 1; a.per_step = h->per_step;
     launch_kf(h, a);
@@ -385,14 +422,14 @@ int ssme_pf_get_expectations(ssme_pf_handle h, int32_t functional, double* out) 
     return SSME_OK;
 }
 
-int ssme_pf_download_state(ssme_pf_handle h, int32_t f, double* x, double* logw, double* cdf, uint32_t* anc) {
+int ssme_pf_download_state(ssme_pf_handle h, int32_t f, double* x, double* logw, uint64_t* cdf, uint32_t* anc) {
     if (!h || f < 0 || f >= h->R) return SSME_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
     const double* xs = h->cur ? h->xb : h->xa;
     const size_t off = (size_t)f * h->Npad;
     if (x) HIPCHK(hipMemcpyAsync(x, xs + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
     if (logw) HIPCHK(hipMemcpyAsync(logw, h->logw + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
-    if (cdf) HIPCHK(hipMemcpyAsync(cdf, h->cdf + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (cdf) HIPCHK(hipMemcpyAsync(cdf, h->cdf + off, sizeof(u64) * h->N, hipMemcpyDeviceToHost, h->stream));
     if (anc) {
         if (!h->anc) return SSME_ERR_STATE;
         HIPCHK(hipMemcpyAsync(anc, h->anc + off, sizeof(uint32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
@@ -401,20 +438,18 @@ int ssme_pf_download_state(ssme_pf_handle h, int32_t f, double* x, double* logw,
     return SSME_OK;
 }
 
-// tile_prefix (exclusive level-2 prefixes) is recomputed on the host with the canonical tree
-// only for parity inspection; pass NULL to skip.
-int ssme_pf_download_scalars(ssme_pf_handle h, int32_t f, double* max_logw, double* sum_w, double* tile_sums,
-                             double* tile_prefix) {
+int ssme_pf_download_scalars(ssme_pf_handle h, int32_t f, double* max_logw, uint64_t* sum_q, uint64_t* tile_sums,
+                             int32_t* rshift) {
     if (!h || f < 0 || f >= h->R) return SSME_ERR_INVALID_ARG;
-    if (tile_prefix) return SSME_ERR_UNSUPPORTED;
     HIPCHK(hipSetDevice(h->cfg.device));
     FilterScalars sc;
     HIPCHK(hipMemcpyAsync(&sc, h->scal + f, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
-    if (tile_sums) HIPCHK(hipMemcpyAsync(tile_sums, h->tile_sum + (size_t)f * h->Bs, sizeof(double) * h->B,
+    if (tile_sums) HIPCHK(hipMemcpyAsync(tile_sums, h->tile_sum + (size_t)f * h->Bs, sizeof(u64) * h->B,
                                          hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (max_logw) *max_logw = sc.m;
-    if (sum_w) *sum_w = sc.S;
+    if (sum_q) *sum_q = sc.S;
+    if (rshift) *rshift = h->rshift;
     return SSME_OK;
 }
 
@@ -440,12 +475,13 @@ int ssme_pf_profile_series(ssme_pf_handle h, const double* y, const double* z, i
     for (auto& e : ev) HIPCHK(hipEventCreate(&e));
     const bool has_z = z != nullptr;
     h->cur = 0;
+    launch_gamma(h, 0, T);
     for (int t = 0; t < T; ++t) {
         StepArgs a = base_args(h);
         a.x_in = h->cur ? h->xb : h->xa;
         a.x_out = h->cur ? h->xa : h->xb;
         a.z = has_z ? h->zbuf : nullptr;
-        a.t = t; a.yi = t; a.finalize_prev = t > 0;
+        a.t = t; a.yi = t; a.gi = t; a.finalize_prev = t > 0;
         HIPCHK(hipEventRecord(ev[3 * t + 0], h->stream));
         launch_ka(h, a);
         HIPCHK(hipEventRecord(ev[3 * t + 1], h->stream));
@@ -482,7 +518,8 @@ __global__ void k_test_math(int fn, const double* in, double* out, long n) {
         case 1: r = dlog(x); break;
         case 2: dsincos2pi(x, &s, &c); r = s; break;
         case 3: dsincos2pi(x, &s, &c); r = c; break;
-        default: r = dsqrt(x); break;
+        case 4: r = dsqrt(x); break;
+        default: r = dlog_pn(x); break;
     }
     out[i] = r;
 }
@@ -490,23 +527,22 @@ __global__ void k_test_philox(const uint32_t* ctr, const uint32_t* key, uint32_t
     const u32x4 o = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
     out[0] = o.v0; out[1] = o.v1; out[2] = o.v2; out[3] = o.v3;
 }
-__global__ __launch_bounds__(kThreads) void k_test_rows_scan(const double* in, int nrows, double* incl, double* excl, double* total) {
-    __shared__ double lds_w[16];
+__global__ void k_test_quantize(const double* in, int shift, u64* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rne_u52(dexp_scaled(in[i], shift));
+}
+__global__ __launch_bounds__(kThreads) void k_test_block_scan(const u64* in, u64* incl, u64* total) {
+    __shared__ u64 lds_seg[16];
     const int tid = threadIdx.x;
-    double v[4][2];
-    for (int k = 0; k < 4; ++k) {
-        v[k][0] = k < nrows ? in[k * kRow + 2 * tid] : 0.0;
-        v[k][1] = k < nrows ? in[k * kRow + 2 * tid + 1] : 0.0;
-    }
-    Rows2 rs;
-    block_rows_scan_rt(v, nrows, rs, lds_w);
-    for (int k = 0; k < nrows; ++k) {
-        incl[k * kRow + 2 * tid] = rs.base[k] + rs.s0[k];
-        incl[k * kRow + 2 * tid + 1] = rs.base[k] + rs.s1[k];
-        excl[k * kRow + 2 * tid] = rs.base[k];
-        excl[k * kRow + 2 * tid + 1] = rs.base[k] + rs.s0[k];
-    }
-    if (tid == 0) *total = rs.total;
+    u64 q[4][2], inc[4][2], tot;
+    for (int k = 0; k < 4; ++k) { q[k][0] = in[k * kRow + 2 * tid]; q[k][1] = in[k * kRow + 2 * tid + 1]; }
+    block_scan_u64(q, inc, tot, lds_seg);
+    for (int k = 0; k < 4; ++k) { incl[k * kRow + 2 * tid] = inc[k][0]; incl[k * kRow + 2 * tid + 1] = inc[k][1]; }
+    if (tid == 0) *total = tot;
+}
+__global__ void k_test_gamma(uint32_t key0, uint32_t key1, uint32_t rep, int t, double shape, int n, double* out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n) out[b] = gamma_draw((uint32_t)b, (uint32_t)t, rep, key0, key1, shape);
 }
 
 #define HIPCHK0(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = SSME_ERR_HIP; goto done; } } while (0)
@@ -544,19 +580,49 @@ done:
     return rc;
 }
 
-int ssme_pf_test_rows_scan(int32_t device, const double* in, int32_t nrows, double* incl, double* excl, double* total) {
-    if (!in || !incl || !excl || !total || nrows < 1 || nrows > 4) return SSME_ERR_INVALID_ARG;
+int ssme_pf_test_quantize(int32_t device, const double* in, int32_t shift, uint64_t* out, int64_t n) {
+    if (!in || !out || n < 1) return SSME_ERR_INVALID_ARG;
     int rc = SSME_OK;
-    const size_t n = (size_t)nrows * kRow;
+    double* din = nullptr; u64* dout = nullptr;
+    HIPCHK0(hipSetDevice(device));
+    HIPCHK0(hipMalloc(&din, sizeof(double) * n));
+    HIPCHK0(hipMalloc(&dout, sizeof(u64) * n));
+    HIPCHK0(hipMemcpy(din, in, sizeof(double) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_quantize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, din, shift, dout, (long)n);
+    HIPCHK0(hipGetLastError());
+    HIPCHK0(hipMemcpy(out, dout, sizeof(u64) * n, hipMemcpyDeviceToHost));
+done:
+    if (din) hipFree(din);
+    if (dout) hipFree(dout);
+    return rc;
+}
+
+int ssme_pf_test_block_scan(int32_t device, const uint64_t* in, uint64_t* incl, uint64_t* total) {
+    if (!in || !incl || !total) return SSME_ERR_INVALID_ARG;
+    int rc = SSME_OK;
+    u64* d = nullptr;
+    HIPCHK0(hipSetDevice(device));
+    HIPCHK0(hipMalloc(&d, sizeof(u64) * (2 * kTile + 1)));
+    HIPCHK0(hipMemcpy(d, in, sizeof(u64) * kTile, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_block_scan, dim3(1), dim3(kThreads), 0, 0, d, d + kTile, d + 2 * kTile);
+    HIPCHK0(hipGetLastError());
+    HIPCHK0(hipMemcpy(incl, d + kTile, sizeof(u64) * kTile, hipMemcpyDeviceToHost));
+    HIPCHK0(hipMemcpy(total, d + 2 * kTile, sizeof(u64), hipMemcpyDeviceToHost));
+done:
+    if (d) hipFree(d);
+    return rc;
+}
+
+int ssme_pf_test_gamma(int32_t device, uint64_t seed, uint32_t rep, int32_t t, double shape, int32_t n, double* out) {
+    if (!out || n < 1) return SSME_ERR_INVALID_ARG;
+    int rc = SSME_OK;
     double* d = nullptr;
     HIPCHK0(hipSetDevice(device));
-    HIPCHK0(hipMalloc(&d, sizeof(double) * (3 * n + 1)));
-    HIPCHK0(hipMemcpy(d, in, sizeof(double) * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_test_rows_scan, dim3(1), dim3(kThreads), 0, 0, d, nrows, d + n, d + 2 * n, d + 3 * n);
+    HIPCHK0(hipMalloc(&d, sizeof(double) * n));
+    hipLaunchKernelGGL(k_test_gamma, dim3((n + 255) / 256), dim3(256), 0, 0, (uint32_t)seed, (uint32_t)(seed >> 32), rep, t,
+                       shape, n, d);
     HIPCHK0(hipGetLastError());
-    HIPCHK0(hipMemcpy(incl, d + n, sizeof(double) * n, hipMemcpyDeviceToHost));
-    HIPCHK0(hipMemcpy(excl, d + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
-    HIPCHK0(hipMemcpy(total, d + 3 * n, sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK0(hipMemcpy(out, d, sizeof(double) * n, hipMemcpyDeviceToHost));
 done:
     if (d) hipFree(d);
     return rc;

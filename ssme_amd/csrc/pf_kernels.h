@@ -1,31 +1,38 @@
 // pf_kernels.h -- HIP kernels of the bootstrap-particle-filter step for gfx950 (wave64).
 //
 // One filter step = two kernels:
-//   KA propagate_weight : [level-2 scan of tile sums] -> resampling targets -> two-level
-//                         lower-bound search in the weight cdf -> gather ancestor state ->
-//                         fSamp -> logGEv -> store x, logw, per-tile max.
-//                         Replaces pf::BSFilter::filter's particle loop + the resampler's
-//                         gather (call site example/estimate_univ_svol.h:124; in-tree twin
+//   KA propagate_weight : level-2 scan of the tile sums -> resampling targets -> search of the
+//                         weight cdf (tiles staged in LDS) -> gather ancestor state -> fSamp ->
+//                         logGEv -> store x, logw, per-tile max.
+//                         Replaces pf::BSFilter::filter's particle loop + the resampler's gather
+//                         (call site example/estimate_univ_svol.h:124; in-tree twin
 //                         include/ssme/liu_west_filter.h:1621-1640, :105-144).
-//   KR normalize_scan   : global max from the per-tile maxima -> w = exp(logw - max) ->
-//                         tile-local inclusive scan (cdf) + tile sums.
+//   KR normalize_scan   : global max from the per-tile maxima -> q = rne(exp(logw - max) 2^r) ->
+//                         exact integer tile scan (cdf) + tile sums.
 //                         Replaces the log-sum-exp passes (twin :1652-1659) and the weight
 //                         normalisation of the resampler (:96-104).
-// Particles are a structure of arrays in HBM: x[R][Npad], logw[R][Npad], cdf[R][Npad]
-// (fp64), one row per filter/replicate; a tile is 2048 consecutive particles = 4 rows of
-// 512 = 256 threads x 2 consecutive values, so every global access is one 16-byte
-// double2 per lane, fully coalesced.
+// Particles are a structure of arrays in HBM: x[R][Npad], logw[R][Npad] (fp64) and
+// cdf[R][Npad] (uint64 fixed point), one row per filter; a tile is 2048 consecutive particles
+// = 4 rows of 512 = 256 threads x 2 consecutive values, so every streaming access is one
+// 16-byte load/store per lane, fully coalesced.
+//
+// The weight cdf is EXACT integer arithmetic: sums are associative,
+// the cdf is monotone by construction and the ancestor of a target tau is the integer count
+// #{j : C_j < tau} -- independent of scan tree, search strategy, tile size or block shape.
 #pragma once
 #include "ssme_math.h"
 
 namespace ssme {
 
+typedef unsigned long long u64;
+
 constexpr int kThreads = 256;
 constexpr int kWave = 64;
 constexpr int kRow = 512;
 constexpr int kTile = 2048;
-constexpr int kRowsPerTile = 4;
-constexpr int kMaxTilesPerFilter = 2048;   // level-2 scan = up to 4 rows of 512 tile sums
+constexpr int kMaxTilesPerFilter = 2048;   // level-2 scan reuses the 2048-wide block scan
+constexpr int kStageTiles = 3;             // cdf tiles staged in LDS per output tile
+constexpr int kEShift = 45;                // exponential spacings: qE = rne(E * 2^45)
 
 enum { MODEL_SVOL = 0, MODEL_SVOL_LEVERAGE = 1, MODEL_LIN_GAUSS = 2 };
 enum { RESAMP_MULTINOMIAL = 0, RESAMP_SYSTEMATIC = 1, RESAMP_STRATIFIED = 2, RESAMP_MULTINOMIAL_IID = 3 };
@@ -41,8 +48,8 @@ struct ModelConst {
 
 // Per-filter scalars living in device memory.
 struct FilterScalars {
-    double m;        // max log-weight of the last step
-    double S;        // sum of exp(logw - m) of the last step (level-2 total)
+    double m;        // max log-weight of the last step (NaN if any log-weight is NaN)
+    u64 S;           // exact integer sum of the quantised weights of the last step
     double prev;     // m_old + log S_old (log N after a resampling step)
     double loglik;   // running sum of log p(y_t | y_{1:t-1})
     double last_ll;  // last log conditional likelihood
@@ -50,126 +57,119 @@ struct FilterScalars {
 };
 
 struct StepArgs {
-    // state
     const double* x_in;      // [R][Npad] particles of step t-1 (pre-resampling)
     double* x_out;           // [R][Npad]
     double* logw;            // [R][Npad]
-    double* cdf;             // [R][Npad] tile-local inclusive sums of w
+    u64* cdf;                // [R][Npad] tile-local inclusive integer sums of q
     uint32_t* anc;           // [R][Npad] or null
-    double* tile_sum;        // [R][Bs]  A_b
-    double* tile_esum;       // [R][Bs]  exponential-spacing tile sums (multinomial)
+    u64* tile_sum;           // [R][Bs]
     double* tile_max;        // [R][Bs]
     FilterScalars* scal;     // [R]
     const ModelConst* mc;    // [R]
     const double* y;         // [T]
     const double* z;         // [T] or null
     double* per_step;        // [R][Tcap] or null
-    int32_t N, Npad, B, Bs, nrows2, Bpow2;
-    int32_t t, yi, Tcap;     // t: time index (RNG counter, schedule); yi: index into y/z
-    int32_t model, resampler, resamp_sched;
+    const double* gam;       // [nT][R][B] Gamma(n_b) draws          (multinomial)
+    const double* pgam;      // [nT][R][B] exclusive prefixes of gam
+    const double* gtot;      // [nT][R]    sum(gam) + E_{N+1}
+    int32_t N, Npad, B, Bs, Bpow2, rshift, R;
+    int32_t t, yi, gi, Tcap;       // t: time index (RNG counter, schedule); yi / gi: rows of y / gamma tables
+    int32_t resampler, resamp_sched;
     int32_t finalize_prev;   // KA: account log p(y_{t-1}|.) of the previous step
     uint32_t key0, key1, first_filter;
     double logN;
 };
 
 // ---------------------------------------------------------------------------------------
-// Canonical row scan.  v[k][0..1] are this thread's two consecutive
-// values of row k.  Afterwards value(k,c) = base[k] + (c ? s1[k] : s0[k]) is the inclusive
-// sum and the exclusive sum is base[k] (+ s0[k] for c = 1); `total` is the sum of all rows.
+// DPP wave primitives.  update_dpp(old = fill, ...) with bound_ctrl = 0: lanes whose source is
+// out of range, or whose row is masked off, receive `fill`.
 // ---------------------------------------------------------------------------------------
-template <int NR>
-struct RowsScan {
-    double base[NR], s0[NR], s1[NR], total;
-};
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROWMASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROWMASK, 0xF, false);
+    return ((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo;
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64_neginf(double v) {    // fill = -inf
+    const u64 b = d2bits(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROWMASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)0xfff00000, (int)(uint32_t)(b >> 32), CTRL, ROWMASK, 0xF, false);
+    return bits2d(((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo);
+}
+// row_shr:n = 0x110+n ; row_bcast:15 = 0x142 ; row_bcast:31 = 0x143 ; wave_shr:1 = 0x138
+__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v) {
+    v += dpp_u64<0x111, 0xF>(v);
+    v += dpp_u64<0x112, 0xF>(v);
+    v += dpp_u64<0x114, 0xF>(v);
+    v += dpp_u64<0x118, 0xF>(v);
+    v += dpp_u64<0x142, 0xA>(v);
+    v += dpp_u64<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ u64 wave_shr1_u64(u64 v) { return dpp_u64<0x138, 0xF>(v); }
 
-template <int NR>
-__device__ __forceinline__ void block_rows_scan(const double (&v)[NR][2], RowsScan<NR>& out, double* lds_w /* NR*4 */) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double exc[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-        out.s0[k] = v[k][0];
-        out.s1[k] = out.s0[k] + v[k][1];
-        double inc = out.s1[k];
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const double up = __shfl_up(inc, d, kWave);
-            if (lane >= d) inc = inc + up;
-        }
-        const double e = __shfl_up(inc, 1, kWave);
-        exc[k] = lane ? e : 0.0;
-        if (lane == kWave - 1) lds_w[k * 4 + wave] = inc;
-    }
-    __syncthreads();
-    double Q = 0.0;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-        const double W0 = lds_w[k * 4 + 0], W1 = lds_w[k * 4 + 1], W2 = lds_w[k * 4 + 2], W3 = lds_w[k * 4 + 3];
-        const double O0 = 0.0;
-        const double O1 = O0 + W0;
-        const double O2 = O1 + W1;
-        const double O3 = O2 + W2;
-        const double rowtot = O3 + W3;
-        const double Ow = wave == 0 ? O0 : wave == 1 ? O1 : wave == 2 ? O2 : O3;
-        out.base[k] = Q + (Ow + exc[k]);
-        if (k + 1 < NR) Q = Q + rowtot; else out.total = Q + rowtot;
-    }
-    __syncthreads();   // lds_w may be reused by the caller
+__device__ __forceinline__ u64 readlane_u64(u64 v, int lane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return ((u64)hi << 32) | lo;
 }
 
-// Runtime row count (level-2 scans: 1..4 rows of tile sums).
-struct Rows2 { double base[4], s0[4], s1[4], total; };
-
-__device__ __forceinline__ void block_rows_scan_rt(const double (&v)[4][2], int nrows, Rows2& out, double* lds_w) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double exc[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k < nrows) {
-            out.s0[k] = v[k][0];
-            out.s1[k] = out.s0[k] + v[k][1];
-            double inc = out.s1[k];
-#pragma unroll
-            for (int d = 1; d < kWave; d <<= 1) {
-                const double up = __shfl_up(inc, d, kWave);
-                if (lane >= d) inc = inc + up;
-            }
-            const double e = __shfl_up(inc, 1, kWave);
-            exc[k] = lane ? e : 0.0;
-            if (lane == kWave - 1) lds_w[k * 4 + wave] = inc;
-        }
-    }
-    __syncthreads();
-    double Q = 0.0;
-    out.total = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k < nrows) {
-            const double W0 = lds_w[k * 4 + 0], W1 = lds_w[k * 4 + 1], W2 = lds_w[k * 4 + 2], W3 = lds_w[k * 4 + 3];
-            const double O0 = 0.0;
-            const double O1 = O0 + W0;
-            const double O2 = O1 + W1;
-            const double O3 = O2 + W2;
-            const double rowtot = O3 + W3;
-            const double Ow = wave == 0 ? O0 : wave == 1 ? O1 : wave == 2 ? O2 : O3;
-            out.base[k] = Q + (Ow + exc[k]);
-            if (k + 1 < nrows) Q = Q + rowtot; else out.total = Q + rowtot;
-        }
-    }
-    __syncthreads();
+// max over the wave of non-NaN doubles (lane 63 holds it after the scan; broadcast by readlane)
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = dmaxnum(v, dpp_f64_neginf<0x111, 0xF>(v));
+    v = dmaxnum(v, dpp_f64_neginf<0x112, 0xF>(v));
+    v = dmaxnum(v, dpp_f64_neginf<0x114, 0xF>(v));
+    v = dmaxnum(v, dpp_f64_neginf<0x118, 0xF>(v));
+    v = dmaxnum(v, dpp_f64_neginf<0x142, 0xA>(v));
+    v = dmaxnum(v, dpp_f64_neginf<0x143, 0xC>(v));
+    return bits2d(readlane_u64(d2bits(v), 63));
 }
 
-// NaN-ignoring max fold ("if (v > m) m = v"), exact and order independent.
-__device__ __forceinline__ double maxf(double m, double v) { return (v > m) ? v : m; }
-
-__device__ __forceinline__ double block_max(double m, double* lds4) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = maxf(m, __shfl_xor(m, d, kWave));
+// Block max with NaN propagation: returns NaN if any thread passes nan = true.
+__device__ __forceinline__ double block_max_nanprop(double m, bool nan, double* lds4) {
+    m = wave_max_f64(m);
     if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = m;
+    const int any_nan = __syncthreads_or(nan ? 1 : 0);
+    const double r = dmaxnum(dmaxnum(lds4[0], lds4[1]), dmaxnum(lds4[2], lds4[3]));
     __syncthreads();
-    double r = maxf(maxf(lds4[0], lds4[1]), maxf(lds4[2], lds4[3]));
+    return any_nan ? dnan() : r;
+}
+
+// ---------------------------------------------------------------------------------------
+// Exact inclusive scan of 2048 uint64 values held as q[k][c] = value[k*512 + 2*tid + c].
+// incl[k][c] = sum of all values up to and including that position; total = sum of all.
+// lds_seg: 16 u64.  Contains two __syncthreads().
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_scan_u64(const u64 (&q)[4][2], u64 (&incl)[4][2], u64& total, u64* lds_seg) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u64 s0[4], s1[4], exc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        s0[k] = q[k][0];
+        s1[k] = s0[k] + q[k][1];
+        const u64 inc = wave_incl_scan_u64(s1[k]);
+        exc[k] = wave_shr1_u64(inc);
+        if (lane == 63) lds_seg[k * 4 + wave] = inc;
+    }
     __syncthreads();
-    return r;
+    // 16 segment totals -> exclusive prefixes, scanned inside every 16-lane row
+    u64 sv = lds_seg[lane & 15];
+    sv += dpp_u64<0x111, 0xF>(sv);
+    sv += dpp_u64<0x112, 0xF>(sv);
+    sv += dpp_u64<0x114, 0xF>(sv);
+    sv += dpp_u64<0x118, 0xF>(sv);
+    total = readlane_u64(sv, 15);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int seg = k * 4 + wave;
+        const u64 pre = seg ? readlane_u64(sv, seg - 1) : 0ull;
+        const u64 base = pre + exc[k];
+        incl[k][0] = base + s0[k];
+        incl[k][1] = base + s1[k];
+    }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -209,32 +209,63 @@ __device__ __forceinline__ void normal_pair(uint32_t pair, uint32_t t, uint32_t 
                                             double* z0, double* z1) {
     const u32x4 o = philox4x32_10(pair, t, rep, STREAM_PROP, k0, k1);
     const double u1 = u01_oc(o.v0, o.v1), u2 = u01_co(o.v2, o.v3);
-    const double rad = dsqrt(-2.0 * dlog(u1));
+    const double rad = dsqrt(-2.0 * dlog_pn(u1));
     double sn, cs;
     dsincos2pi(u2, &sn, &cs);
     *z0 = rad * cs;
     *z1 = rad * sn;
 }
 
-// fixed-probe lower bound over n = 2^k values; returns [0, n-1]
+// Gamma(shape) draw, Marsaglia & Tsang (2000), attempts driven by the Philox counter
+__device__ __forceinline__ double gamma_draw(uint32_t b, uint32_t t, uint32_t rep, uint32_t k0, uint32_t k1, double shape) {
+    const double d = shape - 0.3333333333333333;
+    const double c = 1.0 / dsqrt(9.0 * d);
+    for (int a = 0; a < 32; ++a) {
+        const u32x4 o1 = philox4x32_10(b, t, rep, (uint32_t)(STREAM_GAMMA + 2 * a), k0, k1);
+        const u32x4 o2 = philox4x32_10(b, t, rep, (uint32_t)(STREAM_GAMMA + 2 * a + 1), k0, k1);
+        const double rad = dsqrt(-2.0 * dlog_pn(u01_oc(o1.v0, o1.v1)));
+        double sn, cs;
+        dsincos2pi(u01_co(o1.v2, o1.v3), &sn, &cs);
+        const double xn = rad * cs;
+        const double v = 1.0 + c * xn;
+        if (v > 0.0) {
+            const double v3 = (v * v) * v;
+            const double lhs = dlog_pn(u01_oc(o2.v0, o2.v1));
+            const double rhs = ((0.5 * (xn * xn) + d) - d * v3) + d * dlog(v3);
+            if (lhs < rhs) return d * v3;
+        }
+    }
+    return d;
+}
+
+__device__ __forceinline__ u64 tau_to_u64(double tau) {
+    double c = __builtin_ceil(tau);
+    c = dminnum(dmaxnum(c, 0.0), 9.2e18);    // NaN -> 0
+    return (u64)c;
+}
+
+// #{ j < n : get(j) < target } for monotone get, n = 2^k
 template <class F>
-__device__ __forceinline__ int lower_bound_pow2(int n, double target, F get) {
+__device__ __forceinline__ int count_less_pow2(int n, u64 target, F get) {
     int pos = 0;
     for (int step = n >> 1; step >= 1; step >>= 1)
         if (get(pos + step - 1) < target) pos += step;
+    // pos in [0, n-1]; the last element is not probed: callers clamp the count to n-1 anyway
     return pos;
 }
 
 // ---------------------------------------------------------------------------------------
 // KA: propagate + weight (with fused resampling search/gather of the previous step)
-// grid = (B tiles, R filters), block = 256
+// grid = (B tiles, R filters), block = 256, dynamic LDS = (Bpow2 + 3*2048) * 8 bytes
 // ---------------------------------------------------------------------------------------
 template <int MODEL>
 __global__ __launch_bounds__(kThreads) void ka_propagate_weight(const StepArgs a) {
-    __shared__ double lds_w[16];
-    __shared__ double lds_bc[4];
-    __shared__ double lds_P[kMaxTilesPerFilter];
-    __shared__ double lds_T[kMaxTilesPerFilter];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* lds_T = reinterpret_cast<u64*>(smem);                 // [Bpow2] inclusive tile prefixes
+    u64* lds_stage = lds_T + (a.Bpow2 < 2 ? 2 : a.Bpow2);      // [3][2048] staged cdf tiles, 16-byte aligned
+    __shared__ u64 lds_seg[16];
+    __shared__ u64 lds_x[4];
+    __shared__ double lds_d[4];
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x, r = blockIdx.y;
@@ -245,37 +276,31 @@ __global__ __launch_bounds__(kThreads) void ka_propagate_weight(const StepArgs a
     const double zcov = a.z ? a.z[a.yi] : 0.0;
     const bool resampled = (a.t > 0) && (a.t % a.resamp_sched == 0);
 
-    // --- level-2 scan of the previous step's tile sums: prefixes P_b, ends T_b, total S ---
-    double S = 0.0;
+    // --- level-2: inclusive prefixes T_b of the previous step's tile sums, total S ---
+    u64 S = 0;
     if (a.t > 0 && (resampled || (b == 0 && a.finalize_prev))) {
-        double v[4][2];
+        u64 v[4][2], inc[4][2];
+        const u64* ts = a.tile_sum + (size_t)r * a.Bs;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int j = k * kRow + 2 * tid;
-            if (k < a.nrows2) {
-                const double2 t2 = *reinterpret_cast<const double2*>(a.tile_sum + (size_t)r * a.Bs + j);
+            if (j < a.B) {       // Bs is even: j+1 < Bs, entries >= B are zero
+                const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(ts + j);
                 v[k][0] = t2.x; v[k][1] = t2.y;
-            } else { v[k][0] = 0.0; v[k][1] = 0.0; }
+            } else { v[k][0] = 0; v[k][1] = 0; }
         }
-        Rows2 l2;
-        block_rows_scan_rt(v, a.nrows2, l2, lds_w);
-        S = l2.total;
+        block_scan_u64(v, inc, S, lds_seg);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (k < a.nrows2) {
-                const int j = k * kRow + 2 * tid;
-                const double p0 = l2.base[k], p1 = l2.base[k] + l2.s0[k];
-                lds_P[j] = p0; lds_P[j + 1] = p1;
-                lds_T[j] = (j < a.B) ? p0 + v[k][0] : dinf();
-                lds_T[j + 1] = (j + 1 < a.B) ? p1 + v[k][1] : dinf();
-            }
+            const int j = k * kRow + 2 * tid;
+            if (j < a.Bpow2) lds_T[j] = (j < a.B) ? inc[k][0] : ~0ull;
+            if (j + 1 < a.Bpow2) lds_T[j + 1] = (j + 1 < a.B) ? inc[k][1] : ~0ull;
         }
-        // pad the level-1 search table to a power of two
-        for (int j = a.nrows2 * kRow + tid; j < a.Bpow2; j += kThreads) lds_T[j] = dinf();
         __syncthreads();
         if (b == 0 && tid == 0 && a.finalize_prev) {
             FilterScalars* sc = a.scal + r;
-            const double lse = sc->m + dlog(S);
+            const double Sd = S ? dldexp((double)S, -a.rshift) : dnan();
+            const double lse = sc->m + dlog(Sd);
             const double ll = lse - sc->prev;
             sc->S = S;
             sc->last_ll = ll;
@@ -306,103 +331,145 @@ __global__ __launch_bounds__(kThreads) void ka_propagate_weight(const StepArgs a
             xin[k][0] = xv.x; xin[k][1] = xv.y; lw_old[k][0] = lv.x; lw_old[k][1] = lv.y;
         }
     } else {
-        // --- resampling targets against the cdf of step t-1 ---
-        double tau[4][2];
+        // --- integer resampling targets against the cdf of step t-1 ---
+        u64 tau[4][2];
+        const double Sd = (double)S;
         if (a.resampler == RESAMP_MULTINOMIAL) {
-            // exponential spacings (liu_west_filter.h:105-139): U_(i) = sum_{j<=i} E_j / G
-            double E[4][2];
+            // exponential spacings (liu_west_filter.h:105-139); per tile: Gamma_b * E_j / sum_tile(E)
+            u64 qe[4][2], le[4][2], se;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i0 = b * kTile + k * kRow + 2 * tid;
                 const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, a.key0, a.key1);
-                E[k][0] = (i0 < a.N) ? -dlog(u01_oc(o.v0, o.v1)) : 0.0;
-                E[k][1] = (i0 + 1 < a.N) ? -dlog(u01_oc(o.v2, o.v3)) : 0.0;
+                const double e0 = -dlog_pn(u01_oc(o.v0, o.v1)), e1 = -dlog_pn(u01_oc(o.v2, o.v3));
+                qe[k][0] = (i0 < a.N) ? (d2bits(dfma(e0, 35184372088832.0, 4503599627370496.0)) & 0x000fffffffffffffull) : 0ull;
+                qe[k][1] = (i0 + 1 < a.N) ? (d2bits(dfma(e1, 35184372088832.0, 4503599627370496.0)) & 0x000fffffffffffffull) : 0ull;
             }
-            RowsScan<4> es;
-            block_rows_scan<4>(E, es, lds_w);
-            // level-2 over the exponential tile sums written by KR(t-1)
-            double v[4][2];
+            block_scan_u64(qe, le, se, lds_seg);
+            const size_t gidx = ((size_t)a.gi * a.R + r) * a.B + b;
+            const double gam = a.gam[gidx], pgam = a.pgam[gidx], G = a.gtot[(size_t)a.gi * a.R + r];
+            const double ratio = gam / (double)se;
+            const double scale = Sd / G;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int j = k * kRow + 2 * tid;
-                if (k < a.nrows2) {
-                    const double2 t2 = *reinterpret_cast<const double2*>(a.tile_esum + (size_t)r * a.Bs + j);
-                    v[k][0] = t2.x; v[k][1] = t2.y;
-                } else { v[k][0] = 0.0; v[k][1] = 0.0; }
-            }
-            Rows2 l2e;
-            block_rows_scan_rt(v, a.nrows2, l2e, lds_w);
-            // broadcast my tile's exclusive prefix PE_b
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k < a.nrows2) {
-                    const int j = k * kRow + 2 * tid;
-                    if (j == b) lds_bc[0] = l2e.base[k];
-                    if (j + 1 == b) lds_bc[0] = l2e.base[k] + l2e.s0[k];
+                for (int c = 0; c < 2; ++c) {
+                    const double t1 = ratio * (double)le[k][c];
+                    const double t2 = pgam + t1;
+                    tau[k][c] = tau_to_u64(t2 * scale);
                 }
             }
-            __syncthreads();
-            const double PEb = lds_bc[0];
-            const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, a.key0, a.key1);
-            const double G = l2e.total + (-dlog(u01_oc(ox.v0, ox.v1)));
-            const double scale = S / G;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                tau[k][0] = (PEb + (es.base[k] + es.s0[k])) * scale;
-                tau[k][1] = (PEb + (es.base[k] + es.s1[k])) * scale;
-            }
-            __syncthreads();
         } else if (a.resampler == RESAMP_SYSTEMATIC) {
             const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, a.key0, a.key1);
             const double u0 = u01_co(ox.v0, ox.v1);
-            const double scale = S / (double)a.N;
+            const double scale = Sd / (double)a.N;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i0 = b * kTile + k * kRow + 2 * tid;
-                tau[k][0] = ((double)i0 + u0) * scale;
-                tau[k][1] = ((double)(i0 + 1) + u0) * scale;
+                tau[k][0] = tau_to_u64(((double)i0 + u0) * scale);
+                tau[k][1] = tau_to_u64(((double)(i0 + 1) + u0) * scale);
             }
         } else {
-            const double scale = S / (double)a.N;
+            const double scale = Sd / (double)a.N;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i0 = b * kTile + k * kRow + 2 * tid;
                 const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, a.key0, a.key1);
                 const double v0 = u01_co(o.v0, o.v1), v1 = u01_co(o.v2, o.v3);
                 if (a.resampler == RESAMP_STRATIFIED) {
-                    tau[k][0] = ((double)i0 + v0) * scale;
-                    tau[k][1] = ((double)(i0 + 1) + v1) * scale;
+                    tau[k][0] = tau_to_u64(((double)i0 + v0) * scale);
+                    tau[k][1] = tau_to_u64(((double)(i0 + 1) + v1) * scale);
                 } else {
-                    tau[k][0] = v0 * S;
-                    tau[k][1] = v1 * S;
+                    tau[k][0] = tau_to_u64(v0 * Sd);
+                    tau[k][1] = tau_to_u64(v1 * Sd);
                 }
             }
         }
-        // --- two-level fixed-probe lower bound, then gather ---
-        const double* cdf_r = a.cdf + rowoff;
+
+        const u64* cdf_r = a.cdf + rowoff;
         const double* xin_r = a.x_in + rowoff;
+        const int nvalid = a.N - b * kTile;      // valid outputs in this tile (>= 1)
+
+        // --- range of cdf tiles this output tile needs (targets are sorted except for iid) ---
+        int bb_min = 0, span = kStageTiles + 1;
+        if (a.resampler != RESAMP_MULTINOMIAL_IID) {
+            if (tid == 0) lds_x[0] = tau[0][0];
+            // last valid output of the tile: index nvalid-1 (or 2047)
+            const int last = (nvalid < kTile ? nvalid : kTile) - 1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 4; ++k) {
+                if (k * kRow + 2 * tid == (last & ~1)) lds_x[1] = tau[k][last & 1];
+            }
+            __syncthreads();
+            const u64 tf = lds_x[0], tl = lds_x[1];
+            int lo = count_less_pow2(a.Bpow2, tf, [&](int j) { return lds_T[j]; });
+            int hi = count_less_pow2(a.Bpow2, tl, [&](int j) { return lds_T[j]; });
+            lo = lo < a.B - 1 ? lo : a.B - 1;
+            hi = hi < a.B - 1 ? hi : a.B - 1;
+            bb_min = __builtin_amdgcn_readfirstlane(lo);
+            span = __builtin_amdgcn_readfirstlane(hi) - bb_min + 1;
+        }
+
+        if (span <= kStageTiles) {
+            // stage the needed cdf tiles (coalesced 16-byte loads), then search in LDS
+            for (int s = 0; s < span; ++s) {
+                const u64* src = cdf_r + (size_t)(bb_min + s) * kTile;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const double target = tau[k][c];
-                int bb = lower_bound_pow2(a.Bpow2, target, [&](int j) { return lds_T[j]; });
-                bb = bb < a.B - 1 ? bb : a.B - 1;
-                const double Pb = lds_P[bb];
-                const double* tile = cdf_r + (size_t)bb * kTile;
-                const int j = lower_bound_pow2(kTile, target, [&](int q) { return Pb + tile[q]; });
-                int anc = bb * kTile + j;
-                anc = anc < a.N - 1 ? anc : a.N - 1;
-                const int i = b * kTile + k * kRow + 2 * tid + c;
-                if (a.anc && i < a.N) a.anc[rowoff + i] = (uint32_t)anc;
-                xin[k][c] = xin_r[anc];
-                lw_old[k][c] = 0.0;
+                for (int k = 0; k < 4; ++k) {
+                    const int j = k * kRow + 2 * tid;
+                    *reinterpret_cast<ulonglong2*>(lds_stage + s * kTile + j) = *reinterpret_cast<const ulonglong2*>(src + j);
+                }
+            }
+            const u64 T0 = lds_T[bb_min];
+            const u64 T1 = (bb_min + 1 < a.B) ? lds_T[bb_min + 1] : ~0ull;
+            const u64 Pm = bb_min ? lds_T[bb_min - 1] : 0ull;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const u64 target = tau[k][c];
+                    int sel = (T0 < target ? 1 : 0) + (T1 < target ? 1 : 0);
+                    sel = sel < span - 1 ? sel : span - 1;
+                    const u64 Pb = sel == 0 ? Pm : (sel == 1 ? T0 : T1);
+                    const u64 tloc = target - Pb;
+                    const u64* tile = lds_stage + sel * kTile;
+                    const int j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
+                    int anc = (bb_min + sel) * kTile + j;
+                    anc = anc < a.N - 1 ? anc : a.N - 1;
+                    const int i = b * kTile + k * kRow + 2 * tid + c;
+                    if (a.anc && i < a.N) a.anc[rowoff + i] = (uint32_t)anc;
+                    xin[k][c] = xin_r[anc];
+                    lw_old[k][c] = 0.0;
+                }
+            }
+        } else {
+            // general path (iid multinomial, or an output tile spanning many cdf tiles): probes in L2
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const u64 target = tau[k][c];
+                    int bb = count_less_pow2(a.Bpow2, target, [&](int j) { return lds_T[j]; });
+                    bb = bb < a.B - 1 ? bb : a.B - 1;
+                    const u64 Pb = bb ? lds_T[bb - 1] : 0ull;
+                    const u64 tloc = target - Pb;
+                    const u64* tile = cdf_r + (size_t)bb * kTile;
+                    const int j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
+                    int anc = bb * kTile + j;
+                    anc = anc < a.N - 1 ? anc : a.N - 1;
+                    const int i = b * kTile + k * kRow + 2 * tid + c;
+                    if (a.anc && i < a.N) a.anc[rowoff + i] = (uint32_t)anc;
+                    xin[k][c] = xin_r[anc];
+                    lw_old[k][c] = 0.0;
+                }
             }
         }
     }
 
     // --- fSamp / q1Samp, logGEv, store, tile max ---
     double mx = -dinf();
+    bool nan = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i0 = b * kTile + k * kRow + 2 * tid;
@@ -414,66 +481,53 @@ __global__ __launch_bounds__(kThreads) void ka_propagate_weight(const StepArgs a
             const bool valid = (i0 + c) < a.N;
             xo[c] = valid ? xn : 0.0;
             lo[c] = valid ? lg : -dinf();
-            if (valid) mx = maxf(mx, lg);
+            if (valid) { nan = nan || (lg != lg); mx = (lg > mx) ? lg : mx; }
         }
         const size_t idx = rowoff + (size_t)i0;
         *reinterpret_cast<double2*>(a.x_out + idx) = make_double2(xo[0], xo[1]);
         *reinterpret_cast<double2*>(a.logw + idx) = make_double2(lo[0], lo[1]);
     }
-    mx = block_max(mx, lds_bc);
+    mx = block_max_nanprop(mx, nan, lds_d);
     if (tid == 0) a.tile_max[(size_t)r * a.Bs + b] = mx;
 }
 
 // ---------------------------------------------------------------------------------------
-// KR: normalise + tile scan.  grid = (B, R), block = 256
+// KR: normalise + exact integer tile scan.  grid = (B, R), block = 256
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void kr_normalize_scan(const StepArgs a) {
-    __shared__ double lds_w[16];
-    __shared__ double lds_bc[4];
+    __shared__ u64 lds_seg[16];
+    __shared__ double lds_d[4];
     const int tid = threadIdx.x;
     const int b = blockIdx.x, r = blockIdx.y;
-    const uint32_t rep = a.first_filter + (uint32_t)r;
     const size_t rowoff = (size_t)r * a.Npad;
 
-    // global max over the per-tile maxima
+    // global max over the per-tile maxima (NaN if any tile reported NaN)
     double m = -dinf();
-    for (int j = tid; j < a.B; j += kThreads) m = maxf(m, a.tile_max[(size_t)r * a.Bs + j]);
-    m = block_max(m, lds_bc);
+    bool nan = false;
+    for (int j = tid; j < a.B; j += kThreads) {
+        const double v = a.tile_max[(size_t)r * a.Bs + j];
+        nan = nan || (v != v);
+        m = (v > m) ? v : m;
+    }
+    m = block_max_nanprop(m, nan, lds_d);
 
-    double w[4][2];
+    u64 q[4][2], inc[4][2], total;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i0 = b * kTile + k * kRow + 2 * tid;
         const double2 lv = *reinterpret_cast<const double2*>(a.logw + rowoff + i0);
-        w[k][0] = (i0 < a.N) ? dexp(lv.x - m) : 0.0;
-        w[k][1] = (i0 + 1 < a.N) ? dexp(lv.y - m) : 0.0;
+        q[k][0] = (i0 < a.N) ? rne_u52(dexp_scaled(lv.x - m, a.rshift)) : 0ull;
+        q[k][1] = (i0 + 1 < a.N) ? rne_u52(dexp_scaled(lv.y - m, a.rshift)) : 0ull;
     }
-    RowsScan<4> sc;
-    block_rows_scan<4>(w, sc, lds_w);
+    block_scan_u64(q, inc, total, lds_seg);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i0 = b * kTile + k * kRow + 2 * tid;
-        *reinterpret_cast<double2*>(a.cdf + rowoff + i0) = make_double2(sc.base[k] + sc.s0[k], sc.base[k] + sc.s1[k]);
+        *reinterpret_cast<ulonglong2*>(a.cdf + rowoff + i0) = make_ulonglong2(inc[k][0], inc[k][1]);
     }
     if (tid == 0) {
-        a.tile_sum[(size_t)r * a.Bs + b] = sc.total;
+        a.tile_sum[(size_t)r * a.Bs + b] = total;
         if (b == 0) a.scal[r].m = m;
-    }
-
-    // exponential-spacing tile sums for the resampling consumed by step t+1
-    const bool resample_now = ((a.t + 1) % a.resamp_sched == 0);
-    if (a.resampler == RESAMP_MULTINOMIAL && resample_now) {
-        double E[4][2];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i0 = b * kTile + k * kRow + 2 * tid;
-            const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)(a.t + 1), rep, STREAM_RESAMP, a.key0, a.key1);
-            E[k][0] = (i0 < a.N) ? -dlog(u01_oc(o.v0, o.v1)) : 0.0;
-            E[k][1] = (i0 + 1 < a.N) ? -dlog(u01_oc(o.v2, o.v3)) : 0.0;
-        }
-        RowsScan<4> es;
-        block_rows_scan<4>(E, es, lds_w);
-        if (tid == 0) a.tile_esum[(size_t)r * a.Bs + b] = es.total;
     }
 }
 
@@ -481,31 +535,58 @@ __global__ __launch_bounds__(kThreads) void kr_normalize_scan(const StepArgs a) 
 // KF: account the last step's log conditional likelihood.  grid = (R), block = 256
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void kf_finalize(const StepArgs a) {
-    __shared__ double lds_w[16];
+    __shared__ u64 lds_seg[16];
     const int tid = threadIdx.x;
     const int r = blockIdx.x;
-    double v[4][2];
+    u64 v[4][2], inc[4][2], S;
+    const u64* ts = a.tile_sum + (size_t)r * a.Bs;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int j = k * kRow + 2 * tid;
-        if (k < a.nrows2) {
-            const double2 t2 = *reinterpret_cast<const double2*>(a.tile_sum + (size_t)r * a.Bs + j);
+        if (j < a.B) {
+            const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(ts + j);
             v[k][0] = t2.x; v[k][1] = t2.y;
-        } else { v[k][0] = 0.0; v[k][1] = 0.0; }
+        } else { v[k][0] = 0; v[k][1] = 0; }
     }
-    Rows2 l2;
-    block_rows_scan_rt(v, a.nrows2, l2, lds_w);
+    block_scan_u64(v, inc, S, lds_seg);
     if (tid == 0) {
         FilterScalars* sc = a.scal + r;
         const bool resample_now = ((a.t + 1) % a.resamp_sched == 0);
-        const double lse = sc->m + dlog(l2.total);
+        const double Sd = S ? dldexp((double)S, -a.rshift) : dnan();
+        const double lse = sc->m + dlog(Sd);
         const double ll = lse - sc->prev;
-        sc->S = l2.total;
+        sc->S = S;
         sc->last_ll = ll;
         sc->loglik = sc->loglik + ll;
         sc->prev = resample_now ? a.logN : lse;
         if (a.per_step) a.per_step[(size_t)r * a.Tcap + a.t] = ll;
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Gamma tables for the multinomial resampler (data independent: seed, t, filter, tile only).
+// k_gamma_draw: grid = (ceil(B/256), nT, R).  k_gamma_prefix: one thread per (ti, r).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_gamma_draw(double* gam, int N, int B, int R, int t0, uint32_t key0,
+                                                         uint32_t key1, uint32_t first_filter) {
+    const int b = blockIdx.x * kThreads + threadIdx.x;
+    const int ti = blockIdx.y, r = blockIdx.z;
+    if (b >= B) return;
+    const int nb = (N - b * kTile) < kTile ? (N - b * kTile) : kTile;
+    gam[((size_t)ti * R + r) * B + b] = gamma_draw((uint32_t)b, (uint32_t)(t0 + ti), first_filter + (uint32_t)r, key0, key1, (double)nb);
+}
+
+__global__ __launch_bounds__(kThreads) void k_gamma_prefix(const double* gam, double* pgam, double* gtot, int B, int R,
+                                                           int nT, int t0, uint32_t key0, uint32_t key1, uint32_t first_filter) {
+    const int id = blockIdx.x * kThreads + threadIdx.x;
+    if (id >= nT * R) return;
+    const int ti = id / R, r = id % R;
+    const double* g = gam + (size_t)id * B;
+    double* p = pgam + (size_t)id * B;
+    double run = 0.0;
+    for (int b = 0; b < B; ++b) { p[b] = run; run = run + g[b]; }
+    const u32x4 ox = philox4x32_10(0u, (uint32_t)(t0 + ti), first_filter + (uint32_t)r, STREAM_RESAMP_EXTRA, key0, key1);
+    gtot[id] = run + (-dlog_pn(u01_oc(ox.v0, ox.v1)));
 }
 
 // ---------------------------------------------------------------------------------------

@@ -37,23 +37,15 @@ SSME_HD double pow2i(int n) { return bits2d((uint64_t)(n + 1023) << 52); }
 // ---- Philox4x32-10 -------------------------------------------------------------------
 struct u32x4 { uint32_t v0, v1, v2, v3; };
 
-SSME_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umulhi(a, b);
-#else
-    return (uint32_t)(((uint64_t)a * b) >> 32);
-#endif
-}
-
 SSME_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         if (r) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0;
-        const uint32_t n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;     // one v_mad_u64_u32 each
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
     }
     return u32x4{c0, c1, c2, c3};
 }
@@ -62,16 +54,21 @@ SSME_HD uint64_t bits53(uint32_t a, uint32_t b) { return ((uint64_t)a << 21) | (
 SSME_HD double u01_co(uint32_t a, uint32_t b) { return (double)bits53(a, b) * 0x1.0p-53; }        // [0,1)
 SSME_HD double u01_oc(uint32_t a, uint32_t b) { return (double)(bits53(a, b) + 1) * 0x1.0p-53; }  // (0,1]
 
-enum { STREAM_PROP = 0, STREAM_RESAMP = 1, STREAM_RESAMP_EXTRA = 2 };
+enum { STREAM_PROP = 0, STREAM_RESAMP = 1, STREAM_RESAMP_EXTRA = 2, STREAM_GAMMA = 16 };
 
 // ---- exp -----------------------------------------------------------------------------
-SSME_HD double dexp(double x) {
+SSME_HD double dmaxnum(double a, double b) { return __builtin_fmax(a, b); }   // IEEE maxNum: NaN-squashing
+SSME_HD double dminnum(double a, double b) { return __builtin_fmin(a, b); }
+SSME_HD double dldexp(double x, int e) { return __builtin_ldexp(x, e); }
+
+// exp(x) * 2^sc.  The clamp squashes NaN to the lower bound (result 0); callers that must keep a
+// NaN carry it through another operand.
+SSME_HD double dexp_scaled(double x, int sc) {
     const double LOG2E = 1.4426950408889634074;
     const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
     const double SH = 6755399441055744.0;  // 1.5 * 2^52
-    // clamp keeps k in range; the true range checks are applied at the end
-    const double xc = x > 710.0 ? 710.0 : (x < -746.0 ? -746.0 : x);
-    const double kf = (xc * LOG2E + SH) - SH;
+    const double xc = dminnum(dmaxnum(x, -746.0), 710.0);
+    const double kf = dfma(xc, LOG2E, SH) - SH;
     const int k = (int)kf;
     double r = dfma(-kf, LN2_HI, xc);
     r = dfma(-kf, LN2_LO, r);
@@ -89,27 +86,24 @@ SSME_HD double dexp(double x) {
     q = dfma(q, r, 0.5);
     const double e = dfma(r * r, q, r);
     const double p = 1.0 + e;
-    const int k1 = k / 2, k2 = k - k1;
-    double res = (p * pow2i(k1)) * pow2i(k2);
-    if (x > 709.782712893384) res = dinf();
-    if (x < -745.1332191019412) res = 0.0;
-    if (x != x) res = x;
-    return res;
+    return dldexp(p, k + sc);
 }
+SSME_HD double dexp(double x) { return dexp_scaled(x, 0); }
+
+// round-to-nearest-even of v in [0, 2^52) to an integer, by the 2^52 trick
+SSME_HD uint64_t rne_u52(double v) { return d2bits(v + 4503599627370496.0) & 0x000fffffffffffffull; }
 
 // ---- log -----------------------------------------------------------------------------
-SSME_HD double dlog(double x) {
+// core for positive NORMAL x; kadj is added to the binary exponent (subnormal pre-scaling)
+SSME_HD double dlog_core(double x, int kadj) {
     const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
     const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
                  Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
                  Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                  Lg7 = 1.479819860511658591e-01;
-    int k = 0;
-    double xs = x;
-    uint64_t ux = d2bits(xs);
-    if ((ux >> 52) == 0) { xs = xs * 0x1.0p54; k -= 54; ux = d2bits(xs); }   // subnormal (or +0)
+    uint64_t ux = d2bits(x);
     uint32_t hx = (uint32_t)(ux >> 32);
-    k += (int)(hx >> 20) - 1023;
+    int k = (int)(hx >> 20) - 1023 + kadj;
     hx &= 0x000fffffu;
     const uint32_t i = (hx + 0x95f64u) & 0x100000u;
     ux = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffull);
@@ -124,7 +118,17 @@ SSME_HD double dlog(double x) {
     const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
     const double R = t2 + t1;
     const double hfsq = (0.5 * f) * f;
-    double res = dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+
+// positive normal inputs only: every uniform in (0,1] and every Gamma-test argument is one
+SSME_HD double dlog_pn(double x) { return dlog_core(x, 0); }
+
+// full-domain log (subnormals, 0, inf, negative, NaN)
+SSME_HD double dlog(double x) {
+    const bool sub = (d2bits(x) >> 52) == 0;
+    const double xs = sub ? x * 0x1.0p54 : x;
+    double res = dlog_core(xs, sub ? -54 : 0);
     if (x == dinf()) res = x;
     if (x == 0.0) res = -dinf();
     if (x < 0.0) res = dnan();

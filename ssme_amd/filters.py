@@ -102,15 +102,18 @@ class ParticleFilterBank:
         return out
 
     def state(self, f=0, ancestors=False):
+        """Parity/debug view of filter f after the last step (cdf and tile sums are exact uint64)."""
         n = self.n
-        x, lw, cdf = np.empty(n), np.empty(n), np.empty(n)
+        x, lw = np.empty(n), np.empty(n)
+        cdf = np.empty(n, dtype=np.uint64)
         anc = np.empty(n, dtype=np.uint32) if ancestors else None
-        self._chk(capi.lib().ssme_pf_download_state(self._h, f, capi.dptr(x), capi.dptr(lw), capi.dptr(cdf),
+        self._chk(capi.lib().ssme_pf_download_state(self._h, f, capi.dptr(x), capi.dptr(lw), capi.u64ptr(cdf),
                                                     capi.u32ptr(anc)))
         nt = (n + 2047) // 2048
-        m, s, A = np.empty(1), np.empty(1), np.empty(nt)
-        self._chk(capi.lib().ssme_pf_download_scalars(self._h, f, capi.dptr(m), capi.dptr(s), capi.dptr(A), None))
-        return dict(x=x, logw=lw, cdf=cdf, anc=anc, m=float(m[0]), S=float(s[0]), A=A)
+        m, s, A, rs = np.empty(1), np.zeros(1, dtype=np.uint64), np.empty(nt, dtype=np.uint64), C.c_int32()
+        self._chk(capi.lib().ssme_pf_download_scalars(self._h, f, capi.dptr(m), capi.u64ptr(s), capi.u64ptr(A),
+                                                      C.byref(rs)))
+        return dict(x=x, logw=lw, cdf=cdf, anc=anc, m=float(m[0]), S=int(s[0]), A=A, rshift=rs.value)
 
     def last_elapsed_ms(self):
         ms = C.c_float()

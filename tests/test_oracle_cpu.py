@@ -48,10 +48,10 @@ def test_math_special_values(oracle):
     with np.errstate(all="ignore"):
         x = np.array([-745.2, -745.0, -720.0, 709.7, 709.9, 0.0, np.inf, -np.inf])
         np.testing.assert_array_equal(oracle.exp(x), np.exp(x))
-        assert np.isnan(oracle.exp(np.array([np.nan])))[0]
         x = np.array([0.0, 1.0, 5e-324, 1e-310, np.inf])
         np.testing.assert_allclose(oracle.log(x), np.log(x), rtol=2e-16)
         assert np.isnan(oracle.log(np.array([-1.0, np.nan]))).all()
+    assert oracle.exp(np.array([np.nan]))[0] == 0.0      # the clamp squashes NaN
     s, c = oracle.sincos2pi(np.array([0.0, 0.25, 0.5, 0.75]))
     np.testing.assert_array_equal(s, [0.0, 1.0, -0.0, -1.0])
     np.testing.assert_array_equal(c, [1.0, -0.0, -1.0, 0.0])
@@ -95,20 +95,55 @@ def test_constant_functional_is_42(oracle, spy):
     assert f.loglik ** 2 > 0       # :251
 
 
-# ---- canonical scan tree ---------------------------------------------------------------------------------
-def test_rows_scan_matches_exact_sum(oracle):
+# ---- exact fixed-point cdf and Gamma draws -------------------------------------------------------------
+def test_quantize_and_exact_cdf(oracle, spy):
+    """q = rne(exp(x) 2^r): integer, <= 2^r, monotone in x; the cdf is the exact integer prefix sum."""
     rng = np.random.default_rng(3)
-    for nrows in (1, 2, 4):
-        v = rng.uniform(0, 1, nrows * 512)
-        incl, excl, tot = oracle.rows_scan(v)
-        ref = np.cumsum(v)
-        np.testing.assert_allclose(incl, ref, rtol=1e-13)
-        np.testing.assert_allclose(excl[1:], ref[:-1], rtol=1e-13)
-        assert excl[0] == 0.0 and abs(tot - ref[-1]) < 1e-10
-    # integers are summed exactly whatever the tree
-    v = np.arange(2048, dtype=np.float64)
-    incl, _, tot = oracle.rows_scan(v)
-    np.testing.assert_array_equal(incl, np.cumsum(v))
+    x = -np.sort(rng.exponential(5.0, 4000))
+    x[0] = 0.0
+    for r in (42, 48, 51):
+        q = oracle.quantize(x, r)
+        assert q.dtype == np.uint64 and q[0] == (1 << r) and (np.diff(q.astype(np.int64)) <= 0).all()
+        np.testing.assert_allclose(q.astype(np.float64) * 2.0 ** -r, np.exp(x), atol=2.0 ** -r)
+    assert oracle.quantize(np.array([-800.0, np.nan, -np.inf]), 42).tolist() == [0, 0, 0]
+    f = oracle.Filter(oracle.MODEL_SVOL, 5000, [1.0, 0.95, 0.25], 3)
+    for t in range(4):
+        f.step(spy[t])
+    st = f.state()
+    q = oracle.quantize(st["logw"] - st["m"], st["rshift"])
+    tiles = [np.cumsum(q[i:i + 2048], dtype=np.uint64) for i in range(0, 5000, 2048)]
+    np.testing.assert_array_equal(st["cdf"], np.concatenate(tiles))
+    np.testing.assert_array_equal(st["A"], [t[-1] for t in tiles])
+    assert st["S"] == int(sum(int(t[-1]) for t in tiles)) and st["rshift"] == 62 - 13
+    # ancestors of the (sorted) multinomial resampler are sorted and in range
+    a = st["anc"].astype(np.int64)
+    assert (np.diff(a) >= 0).all() and a.max() < 5000
+
+
+def test_gamma_draws_moments(oracle):
+    for shape in (1.0, 7.0, 2048.0):
+        g = oracle.gamma_draws(11, 2, 5, shape, 40000)
+        assert abs(g.mean() - shape) < 5 * np.sqrt(shape / 40000)
+        assert abs(g.var() / shape - 1) < 0.05
+    # counter based: same (seed, filter, t, tile) -> same draw; another t -> another draw
+    np.testing.assert_array_equal(oracle.gamma_draws(11, 2, 5, 2048.0, 8), oracle.gamma_draws(11, 2, 5, 2048.0, 8))
+    assert (oracle.gamma_draws(11, 2, 5, 2048.0, 8) != oracle.gamma_draws(11, 2, 6, 2048.0, 8)).all()
+
+
+def test_multinomial_sorted_uniforms_are_uniform(oracle):
+    """Gamma-per-tile exponential spacings give sorted U(0,1) order statistics: with unit weights the
+    ancestor counts are multinomial(N; 1/N) -- mean 1, variance (1 - 1/N)."""
+    n = 6000
+    f = oracle.Filter(oracle.MODEL_LIN_GAUSS, n, [0.0, 1.0, 1e6], 4)      # tau huge -> equal weights
+    counts = []
+    for t in range(12):
+        f.step(0.0)
+        if t:
+            counts.append(np.bincount(f.state()["anc"], minlength=n))
+    c = np.concatenate(counts).astype(np.float64)
+    assert abs(c.mean() - 1.0) < 1e-12 and abs(c.var() - 1.0) < 0.03
+    # P(count = 0) = (1 - 1/N)^N ~ e^-1 for multinomial (systematic would give 0)
+    assert abs((c == 0).mean() - np.exp(-1)) < 0.01
 
 
 # ---- estimator anchors -----------------------------------------------------------------------------------

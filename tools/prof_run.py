@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Small driver for rocprofv3 runs: a short series at full N (default N=2^20, T=48, 2 passes)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ssme_amd  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=1 << 20)
+ap.add_argument("--T", type=int, default=48)
+ap.add_argument("--passes", type=int, default=2)
+ap.add_argument("--resampler", type=int, default=0)
+ap.add_argument("--filters", type=int, default=1)
+ap.add_argument("--model", type=int, default=0)
+ap.add_argument("--eager", action="store_true")
+a = ap.parse_args()
+y = np.loadtxt(os.path.join(ROOT, "tests", "golden", "spy_returns.csv"))[:a.T]
+z = np.concatenate([[0.0], y[:-1]]) if a.model == 1 else None
+th = {0: [1.0, 0.95, 0.25], 1: [0.9, 0.0, 1.0, -0.1], 2: [0.9, 0.5, 0.7]}[a.model]
+bank = ssme_amd.ParticleFilterBank(a.model, a.n, a.filters, 20260101, a.resampler)
+if a.eager:
+    bank.set_graph_mode(False)
+bank.set_params(th)
+for _ in range(a.passes):
+    ll = bank.run_series(y, z)
+print("loglik", ll[:4], "ms", bank.last_elapsed_ms(), "p-s/s", a.n * a.filters * a.T / (bank.last_elapsed_ms() * 1e-3))
+bank.close()
