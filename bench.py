@@ -25,8 +25,10 @@ sys.path.insert(0, ROOT)
 N_PARTICLES = 1 << 20
 SEED = 20260101
 THETA = [1.0, 0.95, 0.25]           # (beta, phi, sigma): realistic point of SURVEY.md section 8d
-BYTES_PER_PSTEP = 48.0               # KA 32 B (cdf 8 + gather x 8 + x' 8 + logw 8) + KR 16 B
-BYTES_KA, BYTES_KR = 32.0, 16.0
+# Algorithmic bytes per particle-step of the fused step kernel: read cdf 8 + gather x 8 +
+# write x' 8 + write cdf 8.  SURVEY.md section 8d budgets 48 B for a three-kernel split (it adds a 16 B log-weight
+# round trip); the fused kernel keeps log-weights in registers, so the smaller figure is the honest one.
+BYTES_PER_PSTEP = 32.0
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -129,24 +131,23 @@ def main():
             "loglik_log_mean_exp": lme,
             "device_ms_per_step": dev_ms / args.steps,
         }
-        # per-kernel launch durations, live, HIP events on the handle's stream
+        # launch duration of the step kernel, live, HIP events on the handle's stream
         prof = bank.profile_series(y)
-        ka_us, kr_us = prof["propagate_weight_us"], prof["normalize_scan_us"]
-        achieved = BYTES_KA * n / (ka_us * 1e-6) / 1e9
+        k_us = prof["filter_step_us"]
+        achieved = BYTES_PER_PSTEP * n / (k_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("propagate_weight_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("filter_step_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "ka_propagate_weight", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        out["roofline"] = {"bound": "hbm", "kernel": "k_filter_step", "achieved": achieved, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "algorithmic_bytes_per_launch": BYTES_KA * n, "mean_launch_us": ka_us,
+                           "algorithmic_bytes_per_launch": BYTES_PER_PSTEP * n, "mean_launch_us": k_us,
                            "launches": prof["launches"],
-                           "other_kernels": {"kr_normalize_scan": {"mean_launch_us": kr_us,
-                                                                   "achieved": BYTES_KR * n / (kr_us * 1e-6) / 1e9}},
-                           "whole_step_GBps": BYTES_PER_PSTEP * value / world / 1e9}
+                           "graph_replay_us_per_step": dev_ms * 1e3 / args.steps / T,
+                           "whole_pass_GBps": BYTES_PER_PSTEP * value / world / 1e9}
         d, lg, lo = oracle_delta(bank, y, 12)
         out["loglik_delta_vs_oracle"] = {"abs_delta": d, "gpu": lg, "oracle": lo,
                                          "sample": "first 12 steps, N=2^20, oracle Philox mode (bit-matched)"}

@@ -114,16 +114,23 @@ int ssme_pf_get_expectations(ssme_pf_handle h, int32_t functional, double* out);
 int ssme_pf_log_mean_exp(ssme_pf_handle h, double* out);
 
 /* Parity/debug: state of one filter after the last step.  Any pointer may be NULL.
- * x, logw: N pre-resampling particles and log-weights; cdf: N tile-local inclusive sums of the
- * fixed-point weights q_i = rne(exp(logw_i - max) * 2^rshift) (exact uint64 arithmetic);
- * ancestors: N indices used by the last step (requires set_debug(1)). */
+ * x: N pre-resampling particles; logw: their log-weights (only kept in memory after
+ * set_debug(flags & 2), or when resamp_sched > 1); cdf: N tile-local inclusive sums of the
+ * fixed-point weights q_i = rne(exp(logw_i - max_tile) * 2^51) (exact uint64 arithmetic);
+ * ancestors: N indices used by the last step (requires set_debug(flags & 1)). */
 int ssme_pf_download_state(ssme_pf_handle h, int32_t filter, double* x, double* logw, uint64_t* cdf,
                            uint32_t* ancestors);
-/* max_logw: max log-weight of the last step; sum_q: exact integer weight sum; tile_sums: one
- * integer sum per 2048-particle tile; rshift: the fixed-point exponent r = 62 - ceil(log2(Npad)). */
+/* max_logw: max log-weight of the last step; sum_q: exact integer sum of the rescaled tile sums;
+ * tile_sums / tile_max: one integer weight sum and one max log-weight per 2048-particle tile;
+ * rshift: the fixed-point exponent rg = 62 - ceil(log2(Npad)) of sum_q. */
 int ssme_pf_download_scalars(ssme_pf_handle h, int32_t filter, double* max_logw, uint64_t* sum_q,
-                             uint64_t* tile_sums, int32_t* rshift);
-int ssme_pf_set_debug(ssme_pf_handle h, int32_t record_ancestors);
+                             uint64_t* tile_sums, double* tile_max, int32_t* rshift);
+/* flags: bit 0 = record ancestor indices, bit 1 = keep log-weights in memory (parity tests). */
+int ssme_pf_set_debug(ssme_pf_handle h, int32_t flags);
+
+/* Threads per 2048-particle tile of the step kernel: 256, 512 (default) or 1024.  Results do
+ * not depend on it (the weight cdf is exact integer arithmetic). */
+int ssme_pf_set_tuning(ssme_pf_handle h, int32_t threads_per_tile);
 
 /* Execution policy of run_series: 0 = eager launches, 1 = one hipGraph per series (default). */
 int ssme_pf_set_graph_mode(ssme_pf_handle h, int32_t mode);
@@ -132,11 +139,11 @@ int ssme_pf_set_graph_mode(ssme_pf_handle h, int32_t mode);
  * 8*T-byte upload of y and the 8*R-byte download of the result excluded). */
 int ssme_pf_last_elapsed_ms(ssme_pf_handle h, float* ms);
 
-/* Measurement aid for bench.py: runs a T-step series eagerly with a HIP event pair around
- * every launch of each kernel; returns the mean launch duration (microseconds) and launch
- * count per kernel.  kernel ids: 0 = propagate_weight (KA), 1 = normalize_scan (KR). */
+/* Measurement aid for bench.py: runs a T-step series eagerly with a HIP event between consecutive
+ * launches of the step kernel (k_filter_step) on the handle's stream; returns the mean launch
+ * duration in microseconds (mean_us_out[0]) and the launch count (launches_out[0]). */
 int ssme_pf_profile_series(ssme_pf_handle h, const double* y, const double* z, int32_t T,
-                           double* mean_us_out /*2*/, int32_t* launches_out /*2*/);
+                           double* mean_us_out /*1*/, int32_t* launches_out /*1*/);
 
 /* Device-side primitives exposed for bit-parity tests against the oracle. */
 int ssme_pf_test_math(int32_t device, int32_t fn /*0 exp,1 log,2 sin2pi,3 cos2pi,4 sqrt,5 log (normal-only core)*/,
@@ -144,8 +151,12 @@ int ssme_pf_test_math(int32_t device, int32_t fn /*0 exp,1 log,2 sin2pi,3 cos2pi
 int ssme_pf_test_philox(int32_t device, const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4);
 /* q = rne(exp(in) * 2^shift) as uint64, n values */
 int ssme_pf_test_quantize(int32_t device, const double* in, int32_t shift, uint64_t* out, int64_t n);
-/* exact inclusive scan of 2048 uint64 values by one 256-thread block (DPP wave scans) */
-int ssme_pf_test_block_scan(int32_t device, const uint64_t* in2048, uint64_t* incl2048, uint64_t* total);
+/* out = rint((double)tile_sum * exp(dm) * 2^shift): the cross-tile rescaling of tile sums */
+int ssme_pf_test_rescale(int32_t device, const uint64_t* tile_sums, const double* dm, int32_t shift, uint64_t* out,
+                         int64_t n);
+/* exact inclusive scan of 2048 uint64 values by one block of 256/512/1024 threads (DPP wave scans) */
+int ssme_pf_test_block_scan(int32_t device, int32_t threads, const uint64_t* in2048, uint64_t* incl2048,
+                            uint64_t* total);
 /* n Gamma(shape) draws for tiles 0..n-1 at time t of filter `rep` */
 int ssme_pf_test_gamma(int32_t device, uint64_t seed, uint32_t rep, int32_t t, double shape, int32_t n, double* out);
 

@@ -55,7 +55,8 @@ def lib():
         L.orc_pf_loglik.argtypes = [C.c_void_p]
         L.orc_pf_run_series.restype = C.c_double
         L.orc_pf_run_series.argtypes = [C.c_void_p, dp, dp, C.c_int, dp]
-        L.orc_pf_state.argtypes = [C.c_void_p, dp, dp, u64p, u32p, u64p, dp]
+        L.orc_pf_state.argtypes = [C.c_void_p, dp, dp, u64p, u32p, u64p, dp, dp]
+        L.orc_rescale.argtypes = [u64p, dp, C.c_int, u64p, C.c_long]
         L.orc_pf_expectation.restype = C.c_double
         L.orc_pf_expectation.argtypes = [C.c_void_p, C.c_int]
         L.orc_ref_run_series.restype = C.c_double
@@ -133,6 +134,14 @@ def gamma_draws(seed, rep, t, shape, n):
     return out
 
 
+def rescale(A, dm, sc):
+    A = np.ascontiguousarray(A, dtype=np.uint64)
+    dm = np.ascontiguousarray(dm, dtype=np.float64)
+    out = np.empty(A.size, dtype=np.uint64)
+    lib().orc_rescale(_u64p(A), _dp(dm), int(sc), _u64p(out), A.size)
+    return out
+
+
 def quantize(x, sc):
     x = np.ascontiguousarray(x, dtype=np.float64)
     q = np.empty(x.size, dtype=np.uint64)
@@ -176,9 +185,9 @@ class Filter:
         x, lw = np.empty(n), np.empty(n)
         loc = np.empty(n, dtype=np.uint64)
         anc = np.empty(n, dtype=np.uint32)
-        A, sc = np.empty(self.nt, dtype=np.uint64), np.empty(3)
-        lib().orc_pf_state(self._h, _dp(x), _dp(lw), _u64p(loc), _u32p(anc), _u64p(A), _dp(sc))
-        return dict(x=x, logw=lw, cdf=loc, anc=anc, A=A, m=sc[0], S=int(lib().orc_pf_sum_int(self._h)),
+        A, mb, sc = np.empty(self.nt, dtype=np.uint64), np.empty(self.nt), np.empty(3)
+        lib().orc_pf_state(self._h, _dp(x), _dp(lw), _u64p(loc), _u32p(anc), _u64p(A), _dp(mb), _dp(sc))
+        return dict(x=x, logw=lw, cdf=loc, anc=anc, A=A, mb=mb, m=sc[0], S=int(lib().orc_pf_sum_int(self._h)),
                     rshift=int(sc[2]))
 
     def expectation(self, kind):

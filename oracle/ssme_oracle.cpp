@@ -261,14 +261,23 @@ inline double m_logg(const ModelConst& c, double y, double x) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Exact fixed-point weight cdf.
-//   q_i   = round-to-nearest-even( exp(logw_i - m) * 2^r ),  r = 62 - ceil(log2(Npad))
-//   C_j   = sum_{i<=j} q_i          (uint64, EXACT: no summation tree, monotone by construction)
-//   anc   = #{ j : C_j < ceil(tau) }  clamped to N-1,  tau = U * (double)C_{N-1}
-// The device keeps C as tile-local sums loc_j plus exact tile prefixes; the result is the same
-// integer count whatever the kernel's scan/search strategy.
+// Exact fixed-point weight cdf with per-tile scales.
+//   tile b (2048 particles):  m_b = max logw,  q_i = rne( exp(logw_i - m_b) * 2^51 )
+//                             loc_j = sum_{i<=j in tile} q_i      (uint64, EXACT, monotone)
+//                             A_b   = loc_last
+//   across tiles:             m = max_b m_b,  A'_b = rint( (double)A_b * exp(m_b - m) * 2^(rg-51) ),
+//                             rg = 62 - ceil(log2(Npad)),  T'_b = sum_{c<=b} A'_c (exact),  S' = T'_last
+//   log-sum-exp:              m + log(S' * 2^-rg)
+//   ancestor of target tau in [0, S']:
+//       b* = min(#{b : T'_b < tau}, B-1);  d = tau - (T'_b* - A'_b*)
+//       tl = ceil( (double)d * ((double)A_b* / (double)A'_b*) );  j* = min(#{j : loc_j < tl}, 2047)
+//       anc = min(b* * 2048 + j*, N-1)
+// Integer sums are associative: no summation tree to mirror; the ancestor is an integer COUNT,
+// independent of the kernel's scan and search strategy.  No global max pass is needed, so the
+// device runs ONE kernel per filter step.
 // ---------------------------------------------------------------------------------------
 constexpr int TILE = 2048;
+constexpr int TILE_SHIFT = 51;                // tile-local fixed point: q <= 2^51, tile sums <= 2^62
 constexpr int E_SHIFT = 45;                   // exponential spacings: qE = round(E * 2^45)
 constexpr double TWO52 = 4503599627370496.0;
 constexpr uint64_t MASK52 = (1ull << 52) - 1;
@@ -278,6 +287,11 @@ inline int ceil_log2(int n) { int k = 0; while ((1ll << k) < n) ++k; return k; }
 inline uint64_t rne_u64(double v) { return double_to_bits(v + TWO52) & MASK52; }
 inline uint64_t tau_to_u64(double tau) {
     double c = std::ceil(tau);
+    c = std::fmin(std::fmax(c, 0.0), 9.2e18);          // NaN -> 0
+    return (uint64_t)c;
+}
+inline uint64_t rint_to_u64(double v) {
+    double c = std::rint(v);
     c = std::fmin(std::fmax(c, 0.0), 9.2e18);          // NaN -> 0
     return (uint64_t)c;
 }
@@ -295,7 +309,8 @@ struct Filter {
     int B, Npad, rshift;
     int t;
     std::vector<double> x, xprev, logw;
-    std::vector<uint64_t> loc, A, Tincl;      // tile-local inclusive sums, tile sums, inclusive tile prefixes
+    std::vector<uint64_t> loc, A, Ap, Tincl;  // tile-local sums, tile sums (tile scale), rescaled tile sums, their prefixes
+    std::vector<double> mb;                   // per-tile max log-weight
     std::vector<uint32_t> anc;
     double m, prev, loglik, last_ll;
     uint64_t Sint;
@@ -307,7 +322,7 @@ struct Filter {
         B = (N + TILE - 1) / TILE; Npad = B * TILE;
         rshift = 62 - ceil_log2(Npad);
         x.assign(Npad, 0.0); xprev.assign(Npad, 0.0); logw.assign(Npad, 0.0); loc.assign(Npad, 0);
-        A.assign(B, 0); Tincl.assign(B, 0);
+        A.assign(B, 0); Ap.assign(B, 0); Tincl.assign(B, 0); mb.assign(B, 0.0);
         anc.assign(Npad, 0u);
         reset();
     }
@@ -405,12 +420,13 @@ struct Filter {
         }
     }
 
-    // anc = #{ j : C_j < tau } (global exact cdf), expressed through tiles as the device does
+    // ancestor of an integer target (see the header of this section)
     int search(uint64_t tau) const {
-        int b = (int)(std::lower_bound(Tincl.begin(), Tincl.end(), tau) - Tincl.begin());   // #{T_b < tau}
+        int b = (int)(std::lower_bound(Tincl.begin(), Tincl.end(), tau) - Tincl.begin());   // #{T'_b < tau}
         if (b > B - 1) b = B - 1;
-        const uint64_t Pb = Tincl[b] - A[b];
-        const uint64_t tl = tau - Pb;                                    // unsigned, as on the device
+        const uint64_t d = tau - (Tincl[b] - Ap[b]);                     // unsigned, as on the device
+        const double ratio = (double)A[b] / (double)Ap[b];
+        const uint64_t tl = tau_to_u64((double)d * ratio);
         const uint64_t* tile = &loc[(size_t)b * TILE];
         int j = (int)(std::lower_bound(tile, tile + TILE, tl) - tile);   // #{loc_j < tl}
         if (j > TILE - 1) j = TILE - 1;
@@ -433,19 +449,34 @@ struct Filter {
             }
         }
         for (int i = 0; i < N; ++i) logw[i] = lw_old[i] + m_logg(mc, y, x[i]);
-        // NaN-propagating max: any NaN log-weight -> NaN log-likelihood (as the reference's sums)
-        double mx = NEG_INF; bool nan = false;
-        for (int i = 0; i < N; ++i) { if (logw[i] != logw[i]) nan = true; else if (logw[i] > mx) mx = logw[i]; }
-        m = nan ? std::numeric_limits<double>::quiet_NaN() : mx;
-        uint64_t run = 0;
+        // per-tile NaN-propagating max, tile-local exact cdf
         for (int b = 0; b < B; ++b) {
+            double mx = NEG_INF; bool nan = false;
+            for (int j = 0; j < TILE; ++j) {
+                const int i = b * TILE + j;
+                if (i >= N) break;
+                if (logw[i] != logw[i]) nan = true; else if (logw[i] > mx) mx = logw[i];
+            }
+            mb[b] = nan ? std::numeric_limits<double>::quiet_NaN() : mx;
             uint64_t s = 0;
             for (int j = 0; j < TILE; ++j) {
                 const int i = b * TILE + j;
-                if (i < N) s += rne_u64(o_exp_scaled(logw[i] - m, rshift));
+                if (i < N) s += rne_u64(o_exp_scaled(logw[i] - mb[b], TILE_SHIFT));
                 loc[i] = s;
             }
-            A[b] = s; run += s; Tincl[b] = run;
+            A[b] = s;
+        }
+        // across tiles: global max (NaN if any tile is NaN: any NaN log-weight -> NaN log-likelihood,
+        // as the reference's sums), rescaled integer tile sums and their exact prefixes
+        {
+            double mx = NEG_INF; bool nan = false;
+            for (int b = 0; b < B; ++b) { if (mb[b] != mb[b]) nan = true; else if (mb[b] > mx) mx = mb[b]; }
+            m = nan ? std::numeric_limits<double>::quiet_NaN() : mx;
+        }
+        uint64_t run = 0;
+        for (int b = 0; b < B; ++b) {
+            Ap[b] = rint_to_u64((double)A[b] * o_exp_scaled(mb[b] - m, rshift - TILE_SHIFT));
+            run += Ap[b]; Tincl[b] = run;
         }
         Sint = run;
         const double Sd = Sint ? std::ldexp((double)Sint, -rshift) : std::numeric_limits<double>::quiet_NaN();
@@ -566,6 +597,8 @@ void orc_gamma(uint64_t seed, uint32_t rep, int t, double shape, int n, double* 
     for (int b = 0; b < n; ++b) out[b] = f.gamma_draw(b, t, shape);
 }
 // fixed-point quantisation of weights: q = rne(exp(x) * 2^sc) for x <= 0
+// A'_b = rint((double)A * exp(dm) * 2^sc)
+void orc_rescale(const uint64_t* A, const double* dm, int sc, uint64_t* out, long n) { for (long i = 0; i < n; ++i) out[i] = rint_to_u64((double)A[i] * o_exp_scaled(dm[i], sc)); }
 void orc_quantize(const double* x, int sc, uint64_t* q, long n) { for (long i = 0; i < n; ++i) q[i] = rne_u64(o_exp_scaled(x[i], sc)); }
 
 void* orc_pf_create(int model, int N, int resamp, int rs, uint64_t seed, uint32_t rep, const double* theta) {
@@ -582,13 +615,14 @@ double orc_pf_run_series(void* h, const double* y, const double* z, int T, doubl
 }
 // state after the last step: particles (pre-resampling), log-weights, tile-local integer cdf,
 // ancestors used by the last step, integer tile sums, scalars {m, (double)S_int, r}
-void orc_pf_state(void* h, double* x, double* logw, uint64_t* loc, uint32_t* anc, uint64_t* A, double* scal) {
+void orc_pf_state(void* h, double* x, double* logw, uint64_t* loc, uint32_t* anc, uint64_t* A, double* mb, double* scal) {
     Filter* f = (Filter*)h;
     if (x) std::memcpy(x, f->x.data(), sizeof(double) * f->N);
     if (logw) std::memcpy(logw, f->logw.data(), sizeof(double) * f->N);
     if (loc) std::memcpy(loc, f->loc.data(), sizeof(uint64_t) * f->N);
     if (anc) std::memcpy(anc, f->anc.data(), sizeof(uint32_t) * f->N);
     if (A) std::memcpy(A, f->A.data(), sizeof(uint64_t) * f->B);
+    if (mb) std::memcpy(mb, f->mb.data(), sizeof(double) * f->B);
     if (scal) { scal[0] = f->m; scal[1] = (double)f->Sint; scal[2] = (double)f->rshift; }
 }
 uint64_t orc_pf_sum_int(void* h) { return ((Filter*)h)->Sint; }

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libssme_pf.so")
+SO_PATH = os.environ.get("SSME_PF_LIB") or os.path.join(HERE, "libssme_pf.so")   # SSME_PF_LIB: measurement builds
 
 # enums of include/ssme_pf.h
 OK, ERR_INVALID_ARG, ERR_LENGTH, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE = range(6)
@@ -22,8 +22,9 @@ EXPORTS = [
     "ssme_pf_create", "ssme_pf_destroy", "ssme_pf_set_params", "ssme_pf_reset", "ssme_pf_step",
     "ssme_pf_run_series", "ssme_pf_get_per_step", "ssme_pf_get_loglik", "ssme_pf_get_expectations",
     "ssme_pf_log_mean_exp", "ssme_pf_download_state", "ssme_pf_download_scalars", "ssme_pf_set_debug",
-    "ssme_pf_set_graph_mode", "ssme_pf_last_elapsed_ms", "ssme_pf_profile_series", "ssme_pf_test_math",
-    "ssme_pf_test_philox", "ssme_pf_test_quantize", "ssme_pf_test_block_scan", "ssme_pf_test_gamma",
+    "ssme_pf_set_graph_mode", "ssme_pf_set_tuning", "ssme_pf_last_elapsed_ms", "ssme_pf_profile_series", "ssme_pf_test_math",
+    "ssme_pf_test_philox", "ssme_pf_test_quantize", "ssme_pf_test_rescale", "ssme_pf_test_block_scan",
+    "ssme_pf_test_gamma",
     "ssme_pf_strerror", "ssme_pf_last_error",
     "ssme_pf_version",
 ]
@@ -67,15 +68,17 @@ def lib():
         L.ssme_pf_get_expectations.argtypes = [H, C.c_int32, dp]
         L.ssme_pf_log_mean_exp.argtypes = [H, dp]
         L.ssme_pf_download_state.argtypes = [H, C.c_int32, dp, dp, u64p, u32p]
-        L.ssme_pf_download_scalars.argtypes = [H, C.c_int32, dp, u64p, u64p, i32p]
+        L.ssme_pf_download_scalars.argtypes = [H, C.c_int32, dp, u64p, u64p, dp, i32p]
         L.ssme_pf_set_debug.argtypes = [H, C.c_int32]
         L.ssme_pf_set_graph_mode.argtypes = [H, C.c_int32]
+        L.ssme_pf_set_tuning.argtypes = [H, C.c_int32]
         L.ssme_pf_last_elapsed_ms.argtypes = [H, C.POINTER(C.c_float)]
         L.ssme_pf_profile_series.argtypes = [H, dp, dp, C.c_int32, dp, i32p]
         L.ssme_pf_test_math.argtypes = [C.c_int32, C.c_int32, dp, dp, C.c_int64]
         L.ssme_pf_test_philox.argtypes = [C.c_int32, u32p, u32p, u32p]
         L.ssme_pf_test_quantize.argtypes = [C.c_int32, dp, C.c_int32, u64p, C.c_int64]
-        L.ssme_pf_test_block_scan.argtypes = [C.c_int32, u64p, u64p, u64p]
+        L.ssme_pf_test_block_scan.argtypes = [C.c_int32, C.c_int32, u64p, u64p, u64p]
+        L.ssme_pf_test_rescale.argtypes = [C.c_int32, u64p, dp, C.c_int32, u64p, C.c_int64]
         L.ssme_pf_test_gamma.argtypes = [C.c_int32, C.c_uint64, C.c_uint32, C.c_int32, C.c_double, C.c_int32, dp]
         L.ssme_pf_strerror.restype = C.c_char_p
         L.ssme_pf_strerror.argtypes = [C.c_int]

@@ -29,14 +29,15 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not needs_build():
+def build(force=False, verbose=False, extra=(), out=None):
+    """out: alternative output path (measurement builds, e.g. extra=("-DSSME_ABLATE",))."""
+    if out is None and not force and not needs_build():
         return SO
-    cmd = [hipcc()] + FLAGS + list(extra) + SOURCES + ["-o", SO]
+    cmd = [hipcc()] + FLAGS + list(extra) + SOURCES + ["-o", out or SO]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return SO
+    return out or SO
 
 
 if __name__ == "__main__":

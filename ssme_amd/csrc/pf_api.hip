@@ -1,11 +1,12 @@
 // pf_api.hip -- extern "C" boundary (include/ssme_pf.h) over the gfx950 kernels.
-// Host side of the drop-in: owns device buffers, the HIP stream, hipGraph of a series.
+// Host side of the drop-in: owns device buffers, the HIP stream, the hipGraph of a series.
 // No torch types; no CPU fallback: without a HIP device every call fails with SSME_ERR_HIP.
 #include "../../include/ssme_pf.h"
 #include "pf_kernels.h"
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -16,28 +17,30 @@ using namespace ssme;
 struct ssme_pf_s {
     ssme_pf_config cfg;
     int N, R, Npad, B, Bs, Bpow2, rshift;
-    size_t ka_lds;
+    size_t lds_bytes;
     int t;                   // next time index
     bool params_set;
-    bool last_step_finalized;
-    int debug_anc;
+    int debug_anc, keep_logw;
     int graph_mode;
+    int nt;                  // threads per 2048-particle tile of k_filter_step (256, 512, 1024)
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     float last_ms;
-    // device
-    double *xa, *xb, *logw, *tile_max, *ybuf, *zbuf, *per_step, *scratchR;
+    // device state; [2] = ping-pong (step t reads cur, writes cur ^ 1)
+    double* x[2];
+    u64* cdf[2];
+    u64* tsum[2];
+    double* tmax[2];
+    double *logw, *ybuf, *zbuf, *per_step, *scratchR;
     double *gam, *pgam, *gtot;   // Gamma tables of the multinomial resampler, gcap time rows
-    u64 *cdf, *tile_sum;
     uint32_t* anc;
-    int gcap;
     FilterScalars* scal;
     ModelConst* mc;
-    int cur;                 // which of xa/xb holds the latest particles
-    int ycap, tcap;
+    int cur;                 // buffer index holding the latest step's output
+    int ycap, tcap, gcap;
     // graph cache
     hipGraphExec_t gexec;
-    int g_T, g_has_z, g_debug;
+    int g_T, g_has_z, g_debug, g_logw, g_nt;
     std::vector<ModelConst> h_mc;
     std::string err;
 };
@@ -80,11 +83,18 @@ static ModelConst derive(int model, const double* th) {
 }
 
 static int n_theta_of(int model) { return model == SSME_MODEL_SVOL_LEVERAGE ? 4 : 3; }
+static bool logw_needed(ssme_pf_handle h) { return h->keep_logw || h->cfg.resamp_sched > 1; }
 
-static StepArgs base_args(ssme_pf_handle h) {
+// arguments of the step that reads buffers `cur` and writes `cur ^ 1`
+static StepArgs step_args(ssme_pf_handle h) {
     StepArgs a{};
-    a.logw = h->logw; a.cdf = h->cdf; a.anc = h->debug_anc ? h->anc : nullptr;
-    a.tile_sum = h->tile_sum; a.tile_max = h->tile_max;
+    const int i = h->cur, o = h->cur ^ 1;
+    a.x_in = h->x[i]; a.x_out = h->x[o];
+    a.cdf_in = h->cdf[i]; a.cdf_out = h->cdf[o];
+    a.tsum_in = h->tsum[i]; a.tsum_out = h->tsum[o];
+    a.tmax_in = h->tmax[i]; a.tmax_out = h->tmax[o];
+    a.logw = logw_needed(h) ? h->logw : nullptr;
+    a.anc = h->debug_anc ? h->anc : nullptr;
     a.scal = h->scal; a.mc = h->mc; a.y = h->ybuf; a.z = nullptr; a.per_step = nullptr;
     a.gam = h->gam; a.pgam = h->pgam; a.gtot = h->gtot;
     a.N = h->N; a.Npad = h->Npad; a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = h->R;
@@ -92,21 +102,39 @@ static StepArgs base_args(ssme_pf_handle h) {
     a.resampler = h->cfg.resampler; a.resamp_sched = h->cfg.resamp_sched;
     a.key0 = (uint32_t)h->cfg.seed; a.key1 = (uint32_t)(h->cfg.seed >> 32); a.first_filter = h->cfg.first_filter_id;
     a.logN = dlog((double)h->N);
+#ifdef SSME_ABLATE
+    { const char* e = getenv("SSME_ABLATE_MASK"); a.ablate = e ? atoi(e) : 0; }
+#endif
     return a;
 }
 
-template <int MODEL>
-static hipError_t set_ka_lds(size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ka_propagate_weight<MODEL>),
+template <int MODEL, int NT>
+static hipError_t set_lds1(size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_step<MODEL, NT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
+template <int MODEL>
+static hipError_t set_lds(size_t bytes) {
+    hipError_t e = set_lds1<MODEL, 256>(bytes);
+    if (e == hipSuccess) e = set_lds1<MODEL, 512>(bytes);
+    if (e == hipSuccess) e = set_lds1<MODEL, 1024>(bytes);
+    return e;
+}
 
-static void launch_ka(ssme_pf_handle h, const StepArgs& a) {
-    dim3 grid(h->B, h->R), block(kThreads);
+template <int MODEL>
+static void launch_step_m(ssme_pf_handle h, const StepArgs& a) {
+    dim3 grid(h->B, h->R);
+    switch (h->nt) {
+        case 256: hipLaunchKernelGGL((k_filter_step<MODEL, 256>), grid, dim3(256), h->lds_bytes, h->stream, a); break;
+        case 512: hipLaunchKernelGGL((k_filter_step<MODEL, 512>), grid, dim3(512), h->lds_bytes, h->stream, a); break;
+        default: hipLaunchKernelGGL((k_filter_step<MODEL, 1024>), grid, dim3(1024), h->lds_bytes, h->stream, a); break;
+    }
+}
+static void launch_step(ssme_pf_handle h, const StepArgs& a) {
     switch (h->cfg.model) {
-        case SSME_MODEL_SVOL: hipLaunchKernelGGL(ka_propagate_weight<MODEL_SVOL>, grid, block, h->ka_lds, h->stream, a); break;
-        case SSME_MODEL_SVOL_LEVERAGE: hipLaunchKernelGGL(ka_propagate_weight<MODEL_SVOL_LEVERAGE>, grid, block, h->ka_lds, h->stream, a); break;
-        default: hipLaunchKernelGGL(ka_propagate_weight<MODEL_LIN_GAUSS>, grid, block, h->ka_lds, h->stream, a); break;
+        case SSME_MODEL_SVOL: launch_step_m<MODEL_SVOL>(h, a); break;
+        case SSME_MODEL_SVOL_LEVERAGE: launch_step_m<MODEL_SVOL_LEVERAGE>(h, a); break;
+        default: launch_step_m<MODEL_LIN_GAUSS>(h, a); break;
     }
 }
 // Gamma tables for time indices t0 .. t0+nT-1 into table rows 0 .. nT-1
@@ -118,23 +146,21 @@ static void launch_gamma(ssme_pf_handle h, int t0, int nT) {
     hipLaunchKernelGGL(k_gamma_prefix, dim3((nT * h->R + kThreads - 1) / kThreads), dim3(kThreads), 0, h->stream,
                        h->gam, h->pgam, h->gtot, h->B, h->R, nT, t0, k0, k1, h->cfg.first_filter_id);
 }
-static void launch_kr(ssme_pf_handle h, const StepArgs& a) {
-    hipLaunchKernelGGL(kr_normalize_scan, dim3(h->B, h->R), dim3(kThreads), 0, h->stream, a);
-}
-static void launch_kf(ssme_pf_handle h, const StepArgs& a) {
+// accounts the log conditional likelihood of step t from the buffers the step wrote (now `cur`)
+static void launch_kf(ssme_pf_handle h, int t, bool record_per_step) {
+    StepArgs a = step_args(h);
+    a.t = t;
+    a.per_step = record_per_step ? h->per_step : nullptr;
     hipLaunchKernelGGL(kf_finalize, dim3(h->R), dim3(kThreads), 0, h->stream, a);
 }
 
-// enqueue one filter step (KA, KR) at time index t reading y[yi]
+// enqueue one filter step at time index t reading y[yi] and gamma-table row gi
 static void enqueue_step(ssme_pf_handle h, int t, int yi, int gi, bool has_z, bool finalize_prev, bool record_per_step) {
-    StepArgs a = base_args(h);
-    a.x_in = h->cur ? h->xb : h->xa;
-    a.x_out = h->cur ? h->xa : h->xb;
+    StepArgs a = step_args(h);
     a.z = has_z ? h->zbuf : nullptr;
     a.per_step = record_per_step ? h->per_step : nullptr;
     a.t = t; a.yi = yi; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
-    launch_ka(h, a);
-    launch_kr(h, a);
+    launch_step(h, a);
     h->cur ^= 1;
 }
 
@@ -169,19 +195,28 @@ static int ensure_series_capacity(ssme_pf_handle h, int T) {
     return SSME_OK;
 }
 
+static int ensure_logw(ssme_pf_handle h) {
+    if (logw_needed(h) && !h->logw) {
+        const size_t np = (size_t)h->R * h->Npad;
+        HIPCHK(hipMalloc(&h->logw, sizeof(double) * np));
+        HIPCHK(hipMemset(h->logw, 0, sizeof(double) * np));
+    }
+    return SSME_OK;
+}
+
 static int do_reset(ssme_pf_handle h) {
     std::vector<FilterScalars> sc(h->R);
     const double logN = dlog((double)h->N);
     for (auto& s : sc) { std::memset(&s, 0, sizeof(s)); s.prev = logN; }
     HIPCHK(hipMemcpyAsync(h->scal, sc.data(), sizeof(FilterScalars) * h->R, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));   // sc is a stack/heap temporary
-    h->t = 0; h->cur = 0; h->last_step_finalized = true;
+    HIPCHK(hipStreamSynchronize(h->stream));   // sc is a temporary
+    h->t = 0; h->cur = 0;
     return SSME_OK;
 }
 
 extern "C" {
 
-int ssme_pf_version(void) { return 100; }
+int ssme_pf_version(void) { return 200; }
 
 const char* ssme_pf_strerror(int s) {
     switch (s) {
@@ -212,8 +247,9 @@ int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) {
     h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * kTile;
     h->Bs = (B + 1) & ~1; h->Bpow2 = next_pow2(B);
     h->rshift = 62 - ceil_log2(h->Npad);
-    h->ka_lds = sizeof(u64) * ((size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2) + (size_t)kStageTiles * kTile);
+    h->lds_bytes = sizeof(u64) * (2 * (size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2) + (size_t)kStageTiles * kTile);
     h->graph_mode = 1;
+    h->nt = 512;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) { delete h; return SSME_ERR_HIP; }
     int rc = [&]() -> int {
@@ -221,24 +257,24 @@ int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) {
         HIPCHK(hipEventCreate(&h->ev0));
         HIPCHK(hipEventCreate(&h->ev1));
         const size_t np = (size_t)h->R * h->Npad, nb = (size_t)h->R * h->Bs;
-        HIPCHK(hipMalloc(&h->xa, sizeof(double) * np));
-        HIPCHK(hipMalloc(&h->xb, sizeof(double) * np));
-        HIPCHK(hipMalloc(&h->logw, sizeof(double) * np));
-        HIPCHK(hipMalloc(&h->cdf, sizeof(u64) * np));
-        HIPCHK(hipMalloc(&h->tile_sum, sizeof(u64) * nb));
-        HIPCHK(hipMalloc(&h->tile_max, sizeof(double) * nb));
-        HIPCHK(set_ka_lds<MODEL_SVOL>(h->ka_lds));
-        HIPCHK(set_ka_lds<MODEL_SVOL_LEVERAGE>(h->ka_lds));
-        HIPCHK(set_ka_lds<MODEL_LIN_GAUSS>(h->ka_lds));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipMalloc(&h->x[i], sizeof(double) * np));
+            HIPCHK(hipMalloc(&h->cdf[i], sizeof(u64) * np));
+            HIPCHK(hipMalloc(&h->tsum[i], sizeof(u64) * nb));
+            HIPCHK(hipMalloc(&h->tmax[i], sizeof(double) * nb));
+            HIPCHK(hipMemset(h->x[i], 0, sizeof(double) * np));
+            HIPCHK(hipMemset(h->cdf[i], 0, sizeof(u64) * np));
+            HIPCHK(hipMemset(h->tsum[i], 0, sizeof(u64) * nb));
+            HIPCHK(hipMemset(h->tmax[i], 0, sizeof(double) * nb));
+        }
+        HIPCHK(set_lds<MODEL_SVOL>(h->lds_bytes));
+        HIPCHK(set_lds<MODEL_SVOL_LEVERAGE>(h->lds_bytes));
+        HIPCHK(set_lds<MODEL_LIN_GAUSS>(h->lds_bytes));
         HIPCHK(hipMalloc(&h->scal, sizeof(FilterScalars) * h->R));
         HIPCHK(hipMalloc(&h->mc, sizeof(ModelConst) * h->R));
         HIPCHK(hipMalloc(&h->scratchR, sizeof(double) * h->R));
-        HIPCHK(hipMemset(h->xa, 0, sizeof(double) * np));
-        HIPCHK(hipMemset(h->xb, 0, sizeof(double) * np));
-        HIPCHK(hipMemset(h->logw, 0, sizeof(double) * np));
-        HIPCHK(hipMemset(h->cdf, 0, sizeof(u64) * np));
-        HIPCHK(hipMemset(h->tile_sum, 0, sizeof(u64) * nb));
-        HIPCHK(hipMemset(h->tile_max, 0, sizeof(double) * nb));
+        int rc2 = ensure_logw(h);
+        if (rc2 != SSME_OK) return rc2;
         return ensure_series_capacity(h, 1);
     }();
     if (rc != SSME_OK) { ssme_pf_destroy(h); return rc; }
@@ -251,8 +287,8 @@ int ssme_pf_destroy(ssme_pf_handle h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->gexec) hipGraphExecDestroy(h->gexec);
-    void* bufs[] = {h->xa, h->xb, h->logw, h->cdf, h->tile_sum, h->tile_max, h->ybuf, h->zbuf,
-                    h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot};
+    void* bufs[] = {h->x[0], h->x[1], h->cdf[0], h->cdf[1], h->tsum[0], h->tsum[1], h->tmax[0], h->tmax[1], h->logw,
+                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -281,14 +317,23 @@ int ssme_pf_reset(ssme_pf_handle h) {
     return do_reset(h);
 }
 
-int ssme_pf_set_debug(ssme_pf_handle h, int32_t record_ancestors) {
+// flags: bit 0 = record ancestor indices, bit 1 = keep the log-weights in memory
+int ssme_pf_set_debug(ssme_pf_handle h, int32_t flags) {
     if (!h) return SSME_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
-    if (record_ancestors && !h->anc) {
+    if ((flags & 1) && !h->anc) {
         HIPCHK(hipMalloc(&h->anc, sizeof(uint32_t) * (size_t)h->R * h->Npad));
         HIPCHK(hipMemset(h->anc, 0, sizeof(uint32_t) * (size_t)h->R * h->Npad));
     }
-    h->debug_anc = record_ancestors ? 1 : 0;
+    h->debug_anc = (flags & 1) ? 1 : 0;
+    h->keep_logw = (flags & 2) ? 1 : 0;
+    return ensure_logw(h);
+}
+
+int ssme_pf_set_tuning(ssme_pf_handle h, int32_t threads_per_tile) {
+    if (!h) return SSME_ERR_INVALID_ARG;
+    if (threads_per_tile != 256 && threads_per_tile != 512 && threads_per_tile != 1024) return SSME_ERR_INVALID_ARG;
+    h->nt = threads_per_tile;
     return SSME_OK;
 }
 
@@ -306,9 +351,7 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
     if (z) HIPCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (h->t > 0 && h->t % h->cfg.resamp_sched == 0) launch_gamma(h, h->t, 1);
     enqueue_step(h, h->t, 0, 0, z != nullptr, /*finalize_prev=*/false, /*per_step=*/false);
-    StepArgs a = base_args(h);
-    a.t = h->t;
-    launch_kf(h, a);
+    launch_kf(h, h->t, false);
     HIPCHK(hipGetLastError());
     h->t += 1;
     if (out) {
@@ -325,9 +368,7 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
 static void enqueue_series(ssme_pf_handle h, int T, bool has_z) {
     launch_gamma(h, 0, T);
     for (int t = 0; t < T; ++t) enqueue_step(h, t, t, t, has_z, /*finalize_prev=*/t > 0, /*per_step=*/true);
-    StepArgs a = base_args(h);
-    a.t = T - 1; a.per_step = h->per_step;
-    launch_kf(h, a);
+    launch_kf(h, T - 1, true);
 }
 
 int ssme_pf_run_series(ssme_pf_handle h, const double* y, const double* z, int32_t T, double* loglik_out) {
@@ -342,8 +383,10 @@ int ssme_pf_run_series(ssme_pf_handle h, const double* y, const double* z, int32
     rc = do_reset(h);
     if (rc != SSME_OK) return rc;
     const bool has_z = z != nullptr;
+    const int lw = logw_needed(h) ? 1 : 0;
     if (h->graph_mode) {
-        if (!h->gexec || h->g_T != T || h->g_has_z != (int)has_z || h->g_debug != h->debug_anc) {
+        if (!h->gexec || h->g_T != T || h->g_has_z != (int)has_z || h->g_debug != h->debug_anc || h->g_logw != lw ||
+            h->g_nt != h->nt) {
             if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
@@ -352,7 +395,7 @@ int ssme_pf_run_series(ssme_pf_handle h, const double* y, const double* z, int32
             HIPCHK(hipStreamEndCapture(h->stream, &g));
             HIPCHK(hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0));
             HIPCHK(hipGraphDestroy(g));
-            h->g_T = T; h->g_has_z = has_z; h->g_debug = h->debug_anc;
+            h->g_T = T; h->g_has_z = has_z; h->g_debug = h->debug_anc; h->g_logw = lw; h->g_nt = h->nt;
         }
         HIPCHK(hipEventRecord(h->ev0, h->stream));
         HIPCHK(hipGraphLaunch(h->gexec, h->stream));
@@ -413,9 +456,8 @@ int ssme_pf_get_expectations(ssme_pf_handle h, int32_t functional, double* out) 
     if (!h || !out || functional < 0 || functional > SSME_H_CONST42) return SSME_ERR_INVALID_ARG;
     if (h->t < 1) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
-    const double* x = h->cur ? h->xb : h->xa;
-    hipLaunchKernelGGL(k_expectation, dim3(h->R), dim3(kThreads), 0, h->stream, x, h->logw, h->scal, h->N, h->Npad,
-                       functional, h->scratchR);
+    hipLaunchKernelGGL(k_expectation, dim3(h->R), dim3(kThreads), 0, h->stream, h->x[h->cur], h->cdf[h->cur],
+                       h->tmax[h->cur], h->N, h->Npad, h->B, h->Bs, functional, h->scratchR);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, h->scratchR, sizeof(double) * h->R, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -425,11 +467,13 @@ int ssme_pf_get_expectations(ssme_pf_handle h, int32_t functional, double* out) 
 int ssme_pf_download_state(ssme_pf_handle h, int32_t f, double* x, double* logw, uint64_t* cdf, uint32_t* anc) {
     if (!h || f < 0 || f >= h->R) return SSME_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
-    const double* xs = h->cur ? h->xb : h->xa;
     const size_t off = (size_t)f * h->Npad;
-    if (x) HIPCHK(hipMemcpyAsync(x, xs + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
-    if (logw) HIPCHK(hipMemcpyAsync(logw, h->logw + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
-    if (cdf) HIPCHK(hipMemcpyAsync(cdf, h->cdf + off, sizeof(u64) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (x) HIPCHK(hipMemcpyAsync(x, h->x[h->cur] + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (logw) {
+        if (!h->logw || !logw_needed(h)) return SSME_ERR_STATE;      // set_debug(2) before stepping
+        HIPCHK(hipMemcpyAsync(logw, h->logw + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (cdf) HIPCHK(hipMemcpyAsync(cdf, h->cdf[h->cur] + off, sizeof(u64) * h->N, hipMemcpyDeviceToHost, h->stream));
     if (anc) {
         if (!h->anc) return SSME_ERR_STATE;
         HIPCHK(hipMemcpyAsync(anc, h->anc + off, sizeof(uint32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
@@ -439,13 +483,15 @@ int ssme_pf_download_state(ssme_pf_handle h, int32_t f, double* x, double* logw,
 }
 
 int ssme_pf_download_scalars(ssme_pf_handle h, int32_t f, double* max_logw, uint64_t* sum_q, uint64_t* tile_sums,
-                             int32_t* rshift) {
+                             double* tile_max, int32_t* rshift) {
     if (!h || f < 0 || f >= h->R) return SSME_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
     FilterScalars sc;
     HIPCHK(hipMemcpyAsync(&sc, h->scal + f, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
-    if (tile_sums) HIPCHK(hipMemcpyAsync(tile_sums, h->tile_sum + (size_t)f * h->Bs, sizeof(u64) * h->B,
+    if (tile_sums) HIPCHK(hipMemcpyAsync(tile_sums, h->tsum[h->cur] + (size_t)f * h->Bs, sizeof(u64) * h->B,
                                          hipMemcpyDeviceToHost, h->stream));
+    if (tile_max) HIPCHK(hipMemcpyAsync(tile_max, h->tmax[h->cur] + (size_t)f * h->Bs, sizeof(double) * h->B,
+                                        hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (max_logw) *max_logw = sc.m;
     if (sum_q) *sum_q = sc.S;
@@ -471,41 +517,32 @@ int ssme_pf_profile_series(ssme_pf_handle h, const double* y, const double* z, i
     if (z) HIPCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
     rc = do_reset(h);
     if (rc != SSME_OK) return rc;
-    std::vector<hipEvent_t> ev((size_t)3 * T);
+    std::vector<hipEvent_t> ev((size_t)T + 1);
     for (auto& e : ev) HIPCHK(hipEventCreate(&e));
     const bool has_z = z != nullptr;
     h->cur = 0;
     launch_gamma(h, 0, T);
+    HIPCHK(hipEventRecord(ev[0], h->stream));
     for (int t = 0; t < T; ++t) {
-        StepArgs a = base_args(h);
-        a.x_in = h->cur ? h->xb : h->xa;
-        a.x_out = h->cur ? h->xa : h->xb;
-        a.z = has_z ? h->zbuf : nullptr;
-        a.t = t; a.yi = t; a.gi = t; a.finalize_prev = t > 0;
-        HIPCHK(hipEventRecord(ev[3 * t + 0], h->stream));
-        launch_ka(h, a);
-        HIPCHK(hipEventRecord(ev[3 * t + 1], h->stream));
-        launch_kr(h, a);
-        HIPCHK(hipEventRecord(ev[3 * t + 2], h->stream));
-        h->cur ^= 1;
+        enqueue_step(h, t, t, t, has_z, t > 0, false);
+        HIPCHK(hipEventRecord(ev[t + 1], h->stream));
     }
-    StepArgs a = base_args(h);
-    a.t = T - 1;
-    launch_kf(h, a);
+    launch_kf(h, T - 1, false);
     HIPCHK(hipStreamSynchronize(h->stream));
-    double sa = 0, sr = 0;
+    double sa = 0;
     for (int t = 0; t < T; ++t) {
-        float m1 = 0, m2 = 0;
-        HIPCHK(hipEventElapsedTime(&m1, ev[3 * t], ev[3 * t + 1]));
-        HIPCHK(hipEventElapsedTime(&m2, ev[3 * t + 1], ev[3 * t + 2]));
-        sa += m1; sr += m2;
+        float m1 = 0;
+        HIPCHK(hipEventElapsedTime(&m1, ev[t], ev[t + 1]));
+        sa += m1;
     }
     for (auto& e : ev) hipEventDestroy(e);
-    mean_us[0] = sa * 1000.0 / T; mean_us[1] = sr * 1000.0 / T;
-    launches[0] = T; launches[1] = T;
+    mean_us[0] = sa * 1000.0 / T;
+    launches[0] = T;
     h->t = T;
     return SSME_OK;
 }
+
+}  // extern "C"
 
 // ---- device primitives for bit-parity tests ------------------------------------------------
 __global__ void k_test_math(int fn, const double* in, double* out, long n) {
@@ -531,19 +568,27 @@ __global__ void k_test_quantize(const double* in, int shift, u64* out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = rne_u52(dexp_scaled(in[i], shift));
 }
-__global__ __launch_bounds__(kThreads) void k_test_block_scan(const u64* in, u64* incl, u64* total) {
+__global__ void k_test_rescale(const u64* A, const double* dm, int shift, u64* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rint_to_u64((double)A[i] * dexp_scaled(dm[i], shift));
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void k_test_block_scan(const u64* in, u64* incl, u64* total) {
     __shared__ u64 lds_seg[16];
+    constexpr int NK = 1024 / NT;
     const int tid = threadIdx.x;
-    u64 q[4][2], inc[4][2], tot;
-    for (int k = 0; k < 4; ++k) { q[k][0] = in[k * kRow + 2 * tid]; q[k][1] = in[k * kRow + 2 * tid + 1]; }
-    block_scan_u64(q, inc, tot, lds_seg);
-    for (int k = 0; k < 4; ++k) { incl[k * kRow + 2 * tid] = inc[k][0]; incl[k * kRow + 2 * tid + 1] = inc[k][1]; }
+    u64 q[NK][2], inc[NK][2], tot;
+    for (int k = 0; k < NK; ++k) { q[k][0] = in[(k * NT + tid) * 2]; q[k][1] = in[(k * NT + tid) * 2 + 1]; }
+    block_scan_u64<NT>(q, inc, tot, lds_seg);
+    for (int k = 0; k < NK; ++k) { incl[(k * NT + tid) * 2] = inc[k][0]; incl[(k * NT + tid) * 2 + 1] = inc[k][1]; }
     if (tid == 0) *total = tot;
 }
 __global__ void k_test_gamma(uint32_t key0, uint32_t key1, uint32_t rep, int t, double shape, int n, double* out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < n) out[b] = gamma_draw((uint32_t)b, (uint32_t)t, rep, key0, key1, shape);
 }
+
+extern "C" {
 
 #define HIPCHK0(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = SSME_ERR_HIP; goto done; } } while (0)
 
@@ -597,14 +642,37 @@ done:
     return rc;
 }
 
-int ssme_pf_test_block_scan(int32_t device, const uint64_t* in, uint64_t* incl, uint64_t* total) {
+int ssme_pf_test_rescale(int32_t device, const uint64_t* tile_sums, const double* dm, int32_t shift, uint64_t* out, int64_t n) {
+    if (!tile_sums || !dm || !out || n < 1) return SSME_ERR_INVALID_ARG;
+    int rc = SSME_OK;
+    double* ddm = nullptr; u64 *dA = nullptr, *dout = nullptr;
+    HIPCHK0(hipSetDevice(device));
+    HIPCHK0(hipMalloc(&ddm, sizeof(double) * n));
+    HIPCHK0(hipMalloc(&dA, sizeof(u64) * n));
+    HIPCHK0(hipMalloc(&dout, sizeof(u64) * n));
+    HIPCHK0(hipMemcpy(ddm, dm, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHK0(hipMemcpy(dA, tile_sums, sizeof(u64) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_rescale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dA, ddm, shift, dout, (long)n);
+    HIPCHK0(hipGetLastError());
+    HIPCHK0(hipMemcpy(out, dout, sizeof(u64) * n, hipMemcpyDeviceToHost));
+done:
+    if (ddm) hipFree(ddm);
+    if (dA) hipFree(dA);
+    if (dout) hipFree(dout);
+    return rc;
+}
+
+int ssme_pf_test_block_scan(int32_t device, int32_t threads, const uint64_t* in, uint64_t* incl, uint64_t* total) {
     if (!in || !incl || !total) return SSME_ERR_INVALID_ARG;
+    if (threads != 256 && threads != 512 && threads != 1024) return SSME_ERR_INVALID_ARG;
     int rc = SSME_OK;
     u64* d = nullptr;
     HIPCHK0(hipSetDevice(device));
     HIPCHK0(hipMalloc(&d, sizeof(u64) * (2 * kTile + 1)));
     HIPCHK0(hipMemcpy(d, in, sizeof(u64) * kTile, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_test_block_scan, dim3(1), dim3(kThreads), 0, 0, d, d + kTile, d + 2 * kTile);
+    if (threads == 256) hipLaunchKernelGGL(k_test_block_scan<256>, dim3(1), dim3(256), 0, 0, d, d + kTile, d + 2 * kTile);
+    else if (threads == 512) hipLaunchKernelGGL(k_test_block_scan<512>, dim3(1), dim3(512), 0, 0, d, d + kTile, d + 2 * kTile);
+    else hipLaunchKernelGGL(k_test_block_scan<1024>, dim3(1), dim3(1024), 0, 0, d, d + kTile, d + 2 * kTile);
     HIPCHK0(hipGetLastError());
     HIPCHK0(hipMemcpy(incl, d + kTile, sizeof(u64) * kTile, hipMemcpyDeviceToHost));
     HIPCHK0(hipMemcpy(total, d + 2 * kTile, sizeof(u64), hipMemcpyDeviceToHost));

@@ -1,24 +1,23 @@
 // pf_kernels.h -- HIP kernels of the bootstrap-particle-filter step for gfx950 (wave64).
 //
-// One filter step = two kernels:
-//   KA propagate_weight : level-2 scan of the tile sums -> resampling targets -> search of the
-//                         weight cdf (tiles staged in LDS) -> gather ancestor state -> fSamp ->
-//                         logGEv -> store x, logw, per-tile max.
-//                         Replaces pf::BSFilter::filter's particle loop + the resampler's gather
-//                         (call site example/estimate_univ_svol.h:124; in-tree twin
-//                         include/ssme/liu_west_filter.h:1621-1640, :105-144).
-//   KR normalize_scan   : global max from the per-tile maxima -> q = rne(exp(logw - max) 2^r) ->
-//                         exact integer tile scan (cdf) + tile sums.
-//                         Replaces the log-sum-exp passes (twin :1652-1659) and the weight
-//                         normalisation of the resampler (:96-104).
-// Particles are a structure of arrays in HBM: x[R][Npad], logw[R][Npad] (fp64) and
-// cdf[R][Npad] (uint64 fixed point), one row per filter; a tile is 2048 consecutive particles
-// = 4 rows of 512 = 256 threads x 2 consecutive values, so every streaming access is one
-// 16-byte load/store per lane, fully coalesced.
+// One filter step = ONE kernel, k_filter_step.  Per 2048-particle tile:
+//   level-2: rescale + exact scan of the previous step's tile sums (per-tile weight scales, so no
+//            global max pass and no separate normalisation kernel)       twin liu_west_filter.h:1652-1659
+//   resampling targets (sorted uniforms by exponential spacings)          twin :105-139
+//   search of the previous step's integer weight cdf, tiles staged in LDS  twin :112-139
+//   gather ancestor state, fSamp, logGEv                                  example/univ_svol_bootstrap_filter.h:74-86
+//   tile max, q = rne(exp(logw - max_tile) 2^51), exact integer tile scan  twin :96-104
+// It replaces pf::BSFilter::filter (call site example/estimate_univ_svol.h:124).
 //
-// The weight cdf is EXACT integer arithmetic: sums are associative,
-// the cdf is monotone by construction and the ancestor of a target tau is the integer count
-// #{j : C_j < tau} -- independent of scan tree, search strategy, tile size or block shape.
+// Particles are a structure of arrays in HBM: x[R][Npad] (fp64, ping-pong), cdf[R][Npad] (uint64
+// fixed point, ping-pong), per-tile sums/maxima; one row per filter.  A tile is 2048 consecutive
+// particles = NT threads x (1024/NT) pairs, so every streaming access is one 16-byte load/store
+// per lane, fully coalesced.  Log-weights never leave registers (unless resampling is not every
+// step, or in debug mode).
+//
+// The weight cdf is EXACT integer arithmetic: sums are associative, the
+// cdf is monotone by construction and the ancestor of a target is an integer count --
+// independent of scan tree, search strategy and block shape.
 #pragma once
 #include "ssme_math.h"
 
@@ -26,18 +25,25 @@ namespace ssme {
 
 typedef unsigned long long u64;
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 256;            // helper kernels; KA/KR are templated on their block size
 constexpr int kWave = 64;
 constexpr int kRow = 512;
 constexpr int kTile = 2048;
 constexpr int kMaxTilesPerFilter = 2048;   // level-2 scan reuses the 2048-wide block scan
 constexpr int kStageTiles = 3;             // cdf tiles staged in LDS per output tile
 constexpr int kEShift = 45;                // exponential spacings: qE = rne(E * 2^45)
+constexpr int kTileShift = 51;             // tile-local fixed point: q = rne(exp(logw - m_tile) * 2^51)
 
 enum { MODEL_SVOL = 0, MODEL_SVOL_LEVERAGE = 1, MODEL_LIN_GAUSS = 2 };
 enum { RESAMP_MULTINOMIAL = 0, RESAMP_SYSTEMATIC = 1, RESAMP_STRATIFIED = 2, RESAMP_MULTINOMIAL_IID = 3 };
 
 #define SSME_HALF_LOG_2PI 0.91893853320467274178
+
+#ifdef SSME_ABLATE
+#define ABL(a, bit) (((a).ablate >> (bit)) & 1)
+#else
+#define ABL(a, bit) 0
+#endif
 
 // Derived per-filter constants (host computes them with the same ssme_math functions).
 struct ModelConst {
@@ -57,27 +63,31 @@ struct FilterScalars {
 };
 
 struct StepArgs {
-    const double* x_in;      // [R][Npad] particles of step t-1 (pre-resampling)
-    double* x_out;           // [R][Npad]
-    double* logw;            // [R][Npad]
-    u64* cdf;                // [R][Npad] tile-local inclusive integer sums of q
-    uint32_t* anc;           // [R][Npad] or null
-    u64* tile_sum;           // [R][Bs]
-    double* tile_max;        // [R][Bs]
-    FilterScalars* scal;     // [R]
-    const ModelConst* mc;    // [R]
-    const double* y;         // [T]
-    const double* z;         // [T] or null
-    double* per_step;        // [R][Tcap] or null
-    const double* gam;       // [nT][R][B] Gamma(n_b) draws          (multinomial)
-    const double* pgam;      // [nT][R][B] exclusive prefixes of gam
-    const double* gtot;      // [nT][R]    sum(gam) + E_{N+1}
+    const double* x_in;        // [R][Npad] particles of step t-1 (pre-resampling)
+    double* x_out;             // [R][Npad]
+    double* logw;              // [R][Npad] or null: only kept when resampling is not every step, or in debug mode
+    const u64* cdf_in;         // [R][Npad] tile-local inclusive integer sums of q, step t-1
+    u64* cdf_out;              // [R][Npad] step t
+    const u64* tsum_in;        // [R][Bs] tile sums A_b (tile scale), step t-1
+    u64* tsum_out;
+    const double* tmax_in;     // [R][Bs] tile maxima m_b, step t-1
+    double* tmax_out;
+    uint32_t* anc;             // [R][Npad] or null
+    FilterScalars* scal;       // [R]
+    const ModelConst* mc;      // [R]
+    const double* y;           // [T]
+    const double* z;           // [T] or null
+    double* per_step;          // [R][Tcap] or null
+    const double* gam;         // [nT][R][B] Gamma(n_b) draws          (multinomial)
+    const double* pgam;        // [nT][R][B] exclusive prefixes of gam
+    const double* gtot;        // [nT][R]    sum(gam) + E_{N+1}
     int32_t N, Npad, B, Bs, Bpow2, rshift, R;
-    int32_t t, yi, gi, Tcap;       // t: time index (RNG counter, schedule); yi / gi: rows of y / gamma tables
+    int32_t t, yi, gi, Tcap;   // t: time index (RNG counter, schedule); yi / gi: rows of y / gamma tables
     int32_t resampler, resamp_sched;
-    int32_t finalize_prev;   // KA: account log p(y_{t-1}|.) of the previous step
+    int32_t finalize_prev;     // account log p(y_{t-1}|.) of the previous step
     uint32_t key0, key1, first_filter;
     double logN;
+    int32_t ablate;            // measurement builds only (-DSSME_ABLATE): skip sections, results invalid
 };
 
 // ---------------------------------------------------------------------------------------
@@ -127,34 +137,42 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 }
 
 // Block max with NaN propagation: returns NaN if any thread passes nan = true.
-__device__ __forceinline__ double block_max_nanprop(double m, bool nan, double* lds4) {
+// lds: NT/64 doubles, not reused by the caller before its next barrier.  One barrier.
+template <int NT>
+__device__ __forceinline__ double block_max_nanprop(double m, bool nan, double* lds) {
     m = wave_max_f64(m);
-    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = m;
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
     const int any_nan = __syncthreads_or(nan ? 1 : 0);
-    const double r = dmaxnum(dmaxnum(lds4[0], lds4[1]), dmaxnum(lds4[2], lds4[3]));
-    __syncthreads();
+    double r = lds[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) r = dmaxnum(r, lds[w]);
     return any_nan ? dnan() : r;
 }
 
 // ---------------------------------------------------------------------------------------
-// Exact inclusive scan of 2048 uint64 values held as q[k][c] = value[k*512 + 2*tid + c].
+// Exact inclusive scan of 2048 uint64 values by a block of NT threads (NT = 256, 512, 1024).
+// Thread tid holds NK = 1024/NT pairs: q[k][c] = value[(k*NT + tid)*2 + c].
 // incl[k][c] = sum of all values up to and including that position; total = sum of all.
-// lds_seg: 16 u64.  Contains two __syncthreads().
+// lds_seg: 16 u64 private to this call (no trailing barrier).  One __syncthreads().
+// Integer addition is associative: any wave/segment decomposition gives the same sums.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void block_scan_u64(const u64 (&q)[4][2], u64 (&incl)[4][2], u64& total, u64* lds_seg) {
+template <int NT>
+__device__ __forceinline__ void block_scan_u64(const u64 (&q)[1024 / NT][2], u64 (&incl)[1024 / NT][2], u64& total,
+                                               u64* lds_seg) {
+    constexpr int NK = 1024 / NT, WPR = NT / 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    u64 s0[4], s1[4], exc[4];
+    u64 s0[NK], s1[NK], exc[NK];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NK; ++k) {
         s0[k] = q[k][0];
         s1[k] = s0[k] + q[k][1];
         const u64 inc = wave_incl_scan_u64(s1[k]);
         exc[k] = wave_shr1_u64(inc);
-        if (lane == 63) lds_seg[k * 4 + wave] = inc;
+        if (lane == 63) lds_seg[k * WPR + wave] = inc;
     }
     __syncthreads();
-    // 16 segment totals -> exclusive prefixes, scanned inside every 16-lane row
+    // 16 segment totals -> inclusive prefixes, scanned inside every 16-lane row
     u64 sv = lds_seg[lane & 15];
     sv += dpp_u64<0x111, 0xF>(sv);
     sv += dpp_u64<0x112, 0xF>(sv);
@@ -162,14 +180,13 @@ __device__ __forceinline__ void block_scan_u64(const u64 (&q)[4][2], u64 (&incl)
     sv += dpp_u64<0x118, 0xF>(sv);
     total = readlane_u64(sv, 15);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int seg = k * 4 + wave;
+    for (int k = 0; k < NK; ++k) {
+        const int seg = k * WPR + wave;
         const u64 pre = seg ? readlane_u64(sv, seg - 1) : 0ull;
         const u64 base = pre + exc[k];
         incl[k][0] = base + s0[k];
         incl[k][1] = base + s1[k];
     }
-    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -254,18 +271,70 @@ __device__ __forceinline__ int count_less_pow2(int n, u64 target, F get) {
     return pos;
 }
 
+__device__ __forceinline__ u64 rint_to_u64(double v) {
+    double c = __builtin_rint(v);
+    c = dminnum(dmaxnum(c, 0.0), 9.2e18);    // NaN -> 0
+    return (u64)c;
+}
+
+// gallop: #{ j < 2048 : tile[j] < target } given that every index < lo already is (lo <= count)
+__device__ __forceinline__ int count_less_gallop(const u64* tile, u64 target, int lo) {
+    int w = 1;
+    while (lo + w <= kTile && tile[lo + w - 1] < target) { lo += w; w <<= 1; }
+    for (w >>= 1; w >= 1; w >>= 1)
+        if (lo + w <= kTile && tile[lo + w - 1] < target) lo += w;
+    return lo < kTile - 1 ? lo : kTile - 1;
+}
+
+// Level-2 of one filter: global max m over the tile maxima (NaN propagating), rescaled integer
+// tile sums A'_b = rint(A_b exp(m_b - m) 2^(rg-51)), their exact inclusive scan.  Thread tid holds
+// entries j = (k*NT + tid)*2 + c.  Two barriers.  lds_d: NT/64 doubles, lds_seg: 16 u64.
+template <int NT>
+__device__ __forceinline__ void level2_scan(const u64 (&A)[1024 / NT][2], const double (&mb)[1024 / NT][2], int B, int rshift,
+                                            double& m, u64 (&Ap)[1024 / NT][2], u64 (&Tinc)[1024 / NT][2], u64& S,
+                                            double* lds_d, u64* lds_seg) {
+    constexpr int NK = 1024 / NT;
+    double mx = -dinf();
+    bool nan = false;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int j = (k * NT + threadIdx.x) * 2 + c;
+            if (j < B) { const double v = mb[k][c]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
+        }
+    }
+    m = block_max_nanprop<NT>(mx, nan, lds_d);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int j = (k * NT + threadIdx.x) * 2 + c;
+            Ap[k][c] = (j < B) ? rint_to_u64((double)A[k][c] * dexp_scaled(mb[k][c] - m, rshift - kTileShift)) : 0ull;
+        }
+    }
+    block_scan_u64<NT>(Ap, Tinc, S, lds_seg);
+}
+
 // ---------------------------------------------------------------------------------------
-// KA: propagate + weight (with fused resampling search/gather of the previous step)
-// grid = (B tiles, R filters), block = 256, dynamic LDS = (Bpow2 + 3*2048) * 8 bytes
+// k_filter_step: one bootstrap-filter step for every tile of every filter.
+// grid = (B tiles, R filters), block = NT (256/512/1024: NK = 1024/NT particle pairs per thread),
+// dynamic LDS = (2*max(Bpow2,2) + 3*2048) * 8 bytes
 // ---------------------------------------------------------------------------------------
-template <int MODEL>
-__global__ __launch_bounds__(kThreads) void ka_propagate_weight(const StepArgs a) {
+template <int MODEL, int NT>
+__global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
+    constexpr int NK = 1024 / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* lds_T = reinterpret_cast<u64*>(smem);                 // [Bpow2] inclusive tile prefixes
-    u64* lds_stage = lds_T + (a.Bpow2 < 2 ? 2 : a.Bpow2);      // [3][2048] staged cdf tiles, 16-byte aligned
-    __shared__ u64 lds_seg[16];
-    __shared__ u64 lds_x[4];
-    __shared__ double lds_d[4];
+    const int nT2 = a.Bpow2 < 2 ? 2 : a.Bpow2;
+    u64* lds_T = reinterpret_cast<u64*>(smem);                   // [Bpow2] inclusive prefixes of A'
+    double* lds_R = reinterpret_cast<double*>(lds_T + nT2);      // [Bpow2] A_b / A'_b
+    u64* lds_stage = lds_T + 2 * nT2;                            // [3][2048] staged cdf tiles, 16-byte aligned
+    __shared__ u64 lds_seg_a[16];
+    __shared__ u64 lds_seg_b[16];
+    __shared__ u64 lds_seg_c[16];
+    __shared__ u64 lds_x[2];
+    __shared__ double lds_d1[16];
+    __shared__ double lds_d2[16];
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x, r = blockIdx.y;
@@ -275,33 +344,82 @@ __global__ __launch_bounds__(kThreads) void ka_propagate_weight(const StepArgs a
     const double y = a.y[a.yi];
     const double zcov = a.z ? a.z[a.yi] : 0.0;
     const bool resampled = (a.t > 0) && (a.t % a.resamp_sched == 0);
+    const bool need_l2 = (a.t > 0) && (resampled || (b == 0 && a.finalize_prev));
 
-    // --- level-2: inclusive prefixes T_b of the previous step's tile sums, total S ---
-    u64 S = 0;
-    if (a.t > 0 && (resampled || (b == 0 && a.finalize_prev))) {
-        u64 v[4][2], inc[4][2];
-        const u64* ts = a.tile_sum + (size_t)r * a.Bs;
+    // --- issue the level-2 loads first: previous step's tile sums and maxima ---
+    u64 A2[NK][2];
+    double M2[NK][2];
+    if (need_l2) {
+        const u64* ts = a.tsum_in + (size_t)r * a.Bs;
+        const double* tm = a.tmax_in + (size_t)r * a.Bs;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = k * kRow + 2 * tid;
-            if (j < a.B) {       // Bs is even: j+1 < Bs, entries >= B are zero
+        for (int k = 0; k < NK; ++k) {
+            const int j = (k * NT + tid) * 2;
+            if (j < a.B) {       // Bs is even: j+1 < Bs
                 const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(ts + j);
-                v[k][0] = t2.x; v[k][1] = t2.y;
-            } else { v[k][0] = 0; v[k][1] = 0; }
+                const double2 m2 = *reinterpret_cast<const double2*>(tm + j);
+                A2[k][0] = t2.x; A2[k][1] = t2.y; M2[k][0] = m2.x; M2[k][1] = m2.y;
+            } else { A2[k][0] = 0; A2[k][1] = 0; M2[k][0] = 0.0; M2[k][1] = 0.0; }
         }
-        block_scan_u64(v, inc, S, lds_seg);
+    }
+    double gam = 0.0, pgam = 0.0, G = 1.0;
+    const bool multinomial = resampled && a.resampler == RESAMP_MULTINOMIAL;
+    if (multinomial) {
+        const size_t gidx = ((size_t)a.gi * a.R + r) * a.B + b;
+        gam = a.gam[gidx]; pgam = a.pgam[gidx]; G = a.gtot[(size_t)a.gi * a.R + r];
+    }
+
+    // --- standard normals for my particles ---
+    double zn[NK][2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = k * kRow + 2 * tid;
-            if (j < a.Bpow2) lds_T[j] = (j < a.B) ? inc[k][0] : ~0ull;
-            if (j + 1 < a.Bpow2) lds_T[j + 1] = (j + 1 < a.B) ? inc[k][1] : ~0ull;
+    for (int k = 0; k < NK; ++k) {
+        const uint32_t pair = (uint32_t)(b * (kTile / 2) + k * NT + tid);
+        if (ABL(a, 0)) { zn[k][0] = 0.25 + 1e-9 * (double)pair; zn[k][1] = -0.25; }
+        else normal_pair(pair, (uint32_t)a.t, rep, a.key0, a.key1, &zn[k][0], &zn[k][1]);
+    }
+
+    // --- exponential spacings of the multinomial resampler (liu_west_filter.h:105-139), exact tile scan ---
+    u64 le[NK][2], se = 1;
+    if (multinomial) {
+        u64 qe[NK][2];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int i0 = b * kTile + (k * NT + tid) * 2;
+            double e0, e1;
+            if (ABL(a, 1)) { e0 = 1.0 + 1e-6 * (double)(i0 & 1023); e1 = 1.0; }
+            else {
+                const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, a.key0, a.key1);
+                e0 = -dlog_pn(u01_oc(o.v0, o.v1)); e1 = -dlog_pn(u01_oc(o.v2, o.v3));
+            }
+            qe[k][0] = (i0 < a.N) ? (d2bits(dfma(e0, 35184372088832.0, 4503599627370496.0)) & 0x000fffffffffffffull) : 0ull;
+            qe[k][1] = (i0 + 1 < a.N) ? (d2bits(dfma(e1, 35184372088832.0, 4503599627370496.0)) & 0x000fffffffffffffull) : 0ull;
         }
-        __syncthreads();
+        block_scan_u64<NT>(qe, le, se, lds_seg_a);
+    }
+
+    // --- level-2: global max, rescaled tile sums A', inclusive prefixes T', total S' ---
+    u64 S = 0;
+    if (need_l2) {
+        u64 Ap[NK][2], Tinc[NK][2];
+        double m;
+        level2_scan<NT>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d1, lds_seg_b);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int j = (k * NT + tid) * 2 + c;
+                if (j < a.Bpow2) {
+                    lds_T[j] = (j < a.B) ? Tinc[k][c] : ~0ull;
+                    lds_R[j] = (double)A2[k][c] / (double)Ap[k][c];
+                }
+            }
+        }
         if (b == 0 && tid == 0 && a.finalize_prev) {
             FilterScalars* sc = a.scal + r;
             const double Sd = S ? dldexp((double)S, -a.rshift) : dnan();
-            const double lse = sc->m + dlog(Sd);
+            const double lse = m + dlog(Sd);
             const double ll = lse - sc->prev;
+            sc->m = m;
             sc->S = S;
             sc->last_ll = ll;
             sc->loglik = sc->loglik + ll;
@@ -310,48 +428,28 @@ __global__ __launch_bounds__(kThreads) void ka_propagate_weight(const StepArgs a
         }
     }
 
-    // --- standard normals for my 8 particles ---
-    double zn[4][2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t pair = (uint32_t)(b * (kTile / 2) + k * (kRow / 2) + tid);
-        normal_pair(pair, (uint32_t)a.t, rep, a.key0, a.key1, &zn[k][0], &zn[k][1]);
-    }
-
-    double xin[4][2], lw_old[4][2];
+    double xin[NK][2], lw_old[NK][2];
     if (a.t == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { xin[k][0] = 0.0; xin[k][1] = 0.0; lw_old[k][0] = 0.0; lw_old[k][1] = 0.0; }
+        for (int k = 0; k < NK; ++k) { xin[k][0] = 0.0; xin[k][1] = 0.0; lw_old[k][0] = 0.0; lw_old[k][1] = 0.0; }
     } else if (!resampled) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const size_t idx = rowoff + (size_t)b * kTile + k * kRow + 2 * tid;
+        for (int k = 0; k < NK; ++k) {
+            const size_t idx = rowoff + (size_t)b * kTile + (k * NT + tid) * 2;
             const double2 xv = *reinterpret_cast<const double2*>(a.x_in + idx);
             const double2 lv = *reinterpret_cast<const double2*>(a.logw + idx);
             xin[k][0] = xv.x; xin[k][1] = xv.y; lw_old[k][0] = lv.x; lw_old[k][1] = lv.y;
         }
     } else {
-        // --- integer resampling targets against the cdf of step t-1 ---
-        u64 tau[4][2];
+        // --- integer resampling targets in [0, S'] ---
+        u64 tau[NK][2];
         const double Sd = (double)S;
         if (a.resampler == RESAMP_MULTINOMIAL) {
-            // exponential spacings (liu_west_filter.h:105-139); per tile: Gamma_b * E_j / sum_tile(E)
-            u64 qe[4][2], le[4][2], se;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i0 = b * kTile + k * kRow + 2 * tid;
-                const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, a.key0, a.key1);
-                const double e0 = -dlog_pn(u01_oc(o.v0, o.v1)), e1 = -dlog_pn(u01_oc(o.v2, o.v3));
-                qe[k][0] = (i0 < a.N) ? (d2bits(dfma(e0, 35184372088832.0, 4503599627370496.0)) & 0x000fffffffffffffull) : 0ull;
-                qe[k][1] = (i0 + 1 < a.N) ? (d2bits(dfma(e1, 35184372088832.0, 4503599627370496.0)) & 0x000fffffffffffffull) : 0ull;
-            }
-            block_scan_u64(qe, le, se, lds_seg);
-            const size_t gidx = ((size_t)a.gi * a.R + r) * a.B + b;
-            const double gam = a.gam[gidx], pgam = a.pgam[gidx], G = a.gtot[(size_t)a.gi * a.R + r];
+            // per tile: Gamma_b * E_j / sum_tile(E)  
             const double ratio = gam / (double)se;
             const double scale = Sd / G;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NK; ++k) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const double t1 = ratio * (double)le[k][c];
@@ -364,16 +462,16 @@ __global__ __launch_bounds__(kThreads) void ka_propagate_weight(const StepArgs a
             const double u0 = u01_co(ox.v0, ox.v1);
             const double scale = Sd / (double)a.N;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i0 = b * kTile + k * kRow + 2 * tid;
+            for (int k = 0; k < NK; ++k) {
+                const int i0 = b * kTile + (k * NT + tid) * 2;
                 tau[k][0] = tau_to_u64(((double)i0 + u0) * scale);
                 tau[k][1] = tau_to_u64(((double)(i0 + 1) + u0) * scale);
             }
         } else {
             const double scale = Sd / (double)a.N;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i0 = b * kTile + k * kRow + 2 * tid;
+            for (int k = 0; k < NK; ++k) {
+                const int i0 = b * kTile + (k * NT + tid) * 2;
                 const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, a.key0, a.key1);
                 const double v0 = u01_co(o.v0, o.v1), v1 = u01_co(o.v2, o.v3);
                 if (a.resampler == RESAMP_STRATIFIED) {
@@ -386,21 +484,23 @@ __global__ __launch_bounds__(kThreads) void ka_propagate_weight(const StepArgs a
             }
         }
 
-        const u64* cdf_r = a.cdf + rowoff;
+        const u64* cdf_r = a.cdf_in + rowoff;
         const double* xin_r = a.x_in + rowoff;
         const int nvalid = a.N - b * kTile;      // valid outputs in this tile (>= 1)
+        const bool sorted = a.resampler != RESAMP_MULTINOMIAL_IID;
 
         // --- range of cdf tiles this output tile needs (targets are sorted except for iid) ---
-        int bb_min = 0, span = kStageTiles + 1;
-        if (a.resampler != RESAMP_MULTINOMIAL_IID) {
+        if (sorted) {
             if (tid == 0) lds_x[0] = tau[0][0];
-            // last valid output of the tile: index nvalid-1 (or 2047)
             const int last = (nvalid < kTile ? nvalid : kTile) - 1;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k * kRow + 2 * tid == (last & ~1)) lds_x[1] = tau[k][last & 1];
+            for (int k = 0; k < NK; ++k) {
+                if ((k * NT + tid) * 2 == (last & ~1)) lds_x[1] = tau[k][last & 1];
             }
-            __syncthreads();
+        }
+        __syncthreads();          // lds_T, lds_R and lds_x visible
+        int bb_min = 0, span = kStageTiles + 1;
+        if (sorted) {
             const u64 tf = lds_x[0], tl = lds_x[1];
             int lo = count_less_pow2(a.Bpow2, tf, [&](int j) { return lds_T[j]; });
             int hi = count_less_pow2(a.Bpow2, tl, [&](int j) { return lds_T[j]; });
@@ -415,29 +515,37 @@ __global__ __launch_bounds__(kThreads) void ka_propagate_weight(const StepArgs a
             for (int s = 0; s < span; ++s) {
                 const u64* src = cdf_r + (size_t)(bb_min + s) * kTile;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int j = k * kRow + 2 * tid;
+                for (int k = 0; k < NK; ++k) {
+                    const int j = (k * NT + tid) * 2;
                     *reinterpret_cast<ulonglong2*>(lds_stage + s * kTile + j) = *reinterpret_cast<const ulonglong2*>(src + j);
                 }
             }
+            const int b1 = bb_min + 1 < a.B ? bb_min + 1 : a.B - 1, b2 = bb_min + 2 < a.B ? bb_min + 2 : a.B - 1;
             const u64 T0 = lds_T[bb_min];
             const u64 T1 = (bb_min + 1 < a.B) ? lds_T[bb_min + 1] : ~0ull;
             const u64 Pm = bb_min ? lds_T[bb_min - 1] : 0ull;
+            const double R0 = lds_R[bb_min], R1 = lds_R[b1], R2 = lds_R[b2];
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NK; ++k) {
+                int sel_prev = -1, j_prev = 0;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const u64 target = tau[k][c];
                     int sel = (T0 < target ? 1 : 0) + (T1 < target ? 1 : 0);
                     sel = sel < span - 1 ? sel : span - 1;
                     const u64 Pb = sel == 0 ? Pm : (sel == 1 ? T0 : T1);
-                    const u64 tloc = target - Pb;
+                    const double Rb = sel == 0 ? R0 : (sel == 1 ? R1 : R2);
+                    const u64 tloc = tau_to_u64((double)(target - Pb) * Rb);
                     const u64* tile = lds_stage + sel * kTile;
-                    const int j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
+                    int j;
+                    if (ABL(a, 2)) j = (int)(tloc & 2047);
+                    else if (c == 1 && sel == sel_prev) j = count_less_gallop(tile, tloc, j_prev);   // sorted: count >= j_prev
+                    else j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
+                    sel_prev = sel; j_prev = j;
                     int anc = (bb_min + sel) * kTile + j;
                     anc = anc < a.N - 1 ? anc : a.N - 1;
-                    const int i = b * kTile + k * kRow + 2 * tid + c;
+                    const int i = b * kTile + (k * NT + tid) * 2 + c;
                     if (a.anc && i < a.N) a.anc[rowoff + i] = (uint32_t)anc;
                     xin[k][c] = xin_r[anc];
                     lw_old[k][c] = 0.0;
@@ -446,19 +554,19 @@ __global__ __launch_bounds__(kThreads) void ka_propagate_weight(const StepArgs a
         } else {
             // general path (iid multinomial, or an output tile spanning many cdf tiles): probes in L2
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NK; ++k) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const u64 target = tau[k][c];
                     int bb = count_less_pow2(a.Bpow2, target, [&](int j) { return lds_T[j]; });
                     bb = bb < a.B - 1 ? bb : a.B - 1;
                     const u64 Pb = bb ? lds_T[bb - 1] : 0ull;
-                    const u64 tloc = target - Pb;
+                    const u64 tloc = tau_to_u64((double)(target - Pb) * lds_R[bb]);
                     const u64* tile = cdf_r + (size_t)bb * kTile;
                     const int j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
                     int anc = bb * kTile + j;
                     anc = anc < a.N - 1 ? anc : a.N - 1;
-                    const int i = b * kTile + k * kRow + 2 * tid + c;
+                    const int i = b * kTile + (k * NT + tid) * 2 + c;
                     if (a.anc && i < a.N) a.anc[rowoff + i] = (uint32_t)anc;
                     xin[k][c] = xin_r[anc];
                     lw_old[k][c] = 0.0;
@@ -467,94 +575,86 @@ __global__ __launch_bounds__(kThreads) void ka_propagate_weight(const StepArgs a
         }
     }
 
-    // --- fSamp / q1Samp, logGEv, store, tile max ---
+    // --- fSamp / q1Samp, logGEv, tile max ---
+    double lg[NK][2];
     double mx = -dinf();
     bool nan = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i0 = b * kTile + k * kRow + 2 * tid;
-        double xo[2], lo[2];
+    for (int k = 0; k < NK; ++k) {
+        const int i0 = b * kTile + (k * NT + tid) * 2;
+        double xo[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const double xn = (a.t == 0) ? zn[k][c] * mc.a2 : model_prop<MODEL>(mc, xin[k][c], zn[k][c], zcov);
-            const double lg = lw_old[k][c] + model_logg<MODEL>(mc, y, xn);
+            const double l = lw_old[k][c] + (ABL(a, 3) ? -0.5 * xn * xn : model_logg<MODEL>(mc, y, xn));
             const bool valid = (i0 + c) < a.N;
             xo[c] = valid ? xn : 0.0;
-            lo[c] = valid ? lg : -dinf();
-            if (valid) { nan = nan || (lg != lg); mx = (lg > mx) ? lg : mx; }
+            lg[k][c] = valid ? l : -dinf();
+            if (valid) { nan = nan || (l != l); mx = (l > mx) ? l : mx; }
         }
         const size_t idx = rowoff + (size_t)i0;
         *reinterpret_cast<double2*>(a.x_out + idx) = make_double2(xo[0], xo[1]);
-        *reinterpret_cast<double2*>(a.logw + idx) = make_double2(lo[0], lo[1]);
+        if (a.logw) *reinterpret_cast<double2*>(a.logw + idx) = make_double2(lg[k][0], lg[k][1]);
     }
-    mx = block_max_nanprop(mx, nan, lds_d);
-    if (tid == 0) a.tile_max[(size_t)r * a.Bs + b] = mx;
-}
+    const double mb = block_max_nanprop<NT>(mx, nan, lds_d2);
 
-// ---------------------------------------------------------------------------------------
-// KR: normalise + exact integer tile scan.  grid = (B, R), block = 256
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void kr_normalize_scan(const StepArgs a) {
-    __shared__ u64 lds_seg[16];
-    __shared__ double lds_d[4];
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x, r = blockIdx.y;
-    const size_t rowoff = (size_t)r * a.Npad;
-
-    // global max over the per-tile maxima (NaN if any tile reported NaN)
-    double m = -dinf();
-    bool nan = false;
-    for (int j = tid; j < a.B; j += kThreads) {
-        const double v = a.tile_max[(size_t)r * a.Bs + j];
-        nan = nan || (v != v);
-        m = (v > m) ? v : m;
-    }
-    m = block_max_nanprop(m, nan, lds_d);
-
-    u64 q[4][2], inc[4][2], total;
+    // --- tile-local fixed-point weights and their exact inclusive scan (the next step's cdf) ---
+    u64 q[NK][2], inc[NK][2], total;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i0 = b * kTile + k * kRow + 2 * tid;
-        const double2 lv = *reinterpret_cast<const double2*>(a.logw + rowoff + i0);
-        q[k][0] = (i0 < a.N) ? rne_u52(dexp_scaled(lv.x - m, a.rshift)) : 0ull;
-        q[k][1] = (i0 + 1 < a.N) ? rne_u52(dexp_scaled(lv.y - m, a.rshift)) : 0ull;
+    for (int k = 0; k < NK; ++k) {
+        const int i0 = b * kTile + (k * NT + tid) * 2;
+        if (ABL(a, 4)) { q[k][0] = d2bits(lg[k][0] - mb) >> 24; q[k][1] = d2bits(lg[k][1] - mb) >> 24; }
+        else {
+            q[k][0] = (i0 < a.N) ? rne_u52(dexp_scaled(lg[k][0] - mb, kTileShift)) : 0ull;
+            q[k][1] = (i0 + 1 < a.N) ? rne_u52(dexp_scaled(lg[k][1] - mb, kTileShift)) : 0ull;
+        }
     }
-    block_scan_u64(q, inc, total, lds_seg);
+    if (ABL(a, 5)) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i0 = b * kTile + k * kRow + 2 * tid;
-        *reinterpret_cast<ulonglong2*>(a.cdf + rowoff + i0) = make_ulonglong2(inc[k][0], inc[k][1]);
+        for (int k = 0; k < NK; ++k) { inc[k][0] = q[k][0]; inc[k][1] = q[k][0] + q[k][1]; }
+        total = inc[0][1] + 0x100000;
+    } else block_scan_u64<NT>(q, inc, total, lds_seg_c);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int i0 = b * kTile + (k * NT + tid) * 2;
+        *reinterpret_cast<ulonglong2*>(a.cdf_out + rowoff + i0) = make_ulonglong2(inc[k][0], inc[k][1]);
     }
     if (tid == 0) {
-        a.tile_sum[(size_t)r * a.Bs + b] = total;
-        if (b == 0) a.scal[r].m = m;
+        a.tsum_out[(size_t)r * a.Bs + b] = total;
+        a.tmax_out[(size_t)r * a.Bs + b] = mb;
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// KF: account the last step's log conditional likelihood.  grid = (R), block = 256
+// KF: account the last step's log conditional likelihood.  grid = (R), block = 256.
+// Reads the tile sums / maxima the last k_filter_step wrote (passed as tsum_in / tmax_in).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void kf_finalize(const StepArgs a) {
     __shared__ u64 lds_seg[16];
+    __shared__ double lds_d[16];
     const int tid = threadIdx.x;
     const int r = blockIdx.x;
-    u64 v[4][2], inc[4][2], S;
-    const u64* ts = a.tile_sum + (size_t)r * a.Bs;
+    u64 A2[4][2], Ap[4][2], Tinc[4][2], S;
+    double M2[4][2], m;
+    const u64* ts = a.tsum_in + (size_t)r * a.Bs;
+    const double* tm = a.tmax_in + (size_t)r * a.Bs;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int j = k * kRow + 2 * tid;
+        const int j = (k * kThreads + tid) * 2;
         if (j < a.B) {
             const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(ts + j);
-            v[k][0] = t2.x; v[k][1] = t2.y;
-        } else { v[k][0] = 0; v[k][1] = 0; }
+            const double2 m2 = *reinterpret_cast<const double2*>(tm + j);
+            A2[k][0] = t2.x; A2[k][1] = t2.y; M2[k][0] = m2.x; M2[k][1] = m2.y;
+        } else { A2[k][0] = 0; A2[k][1] = 0; M2[k][0] = 0.0; M2[k][1] = 0.0; }
     }
-    block_scan_u64(v, inc, S, lds_seg);
+    level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
     if (tid == 0) {
         FilterScalars* sc = a.scal + r;
         const bool resample_now = ((a.t + 1) % a.resamp_sched == 0);
         const double Sd = S ? dldexp((double)S, -a.rshift) : dnan();
-        const double lse = sc->m + dlog(Sd);
+        const double lse = m + dlog(Sd);
         const double ll = lse - sc->prev;
+        sc->m = m;
         sc->S = S;
         sc->last_ll = ll;
         sc->loglik = sc->loglik + ll;
@@ -592,16 +692,23 @@ __global__ __launch_bounds__(kThreads) void k_gamma_prefix(const double* gam, do
 // ---------------------------------------------------------------------------------------
 // Weighted expectation of a built-in functional with the last step's weights
 // (getExpectations(); twin liu_west_filter.h:1662-1683).  grid = (R), block = 256.
-// Partial sums: per-thread strided, wave shuffle tree, 4 waves in order (deterministic).
+// Weights are the fixed-point weights the resampler uses: w_j = q_j * exp(m_tile - m),
+// q_j = cdf_j - cdf_{j-1}.  Partial sums: per-thread strided, wave tree, 4 waves in order.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_expectation(const double* x, const double* logw, const FilterScalars* scal,
-                                                          int N, int Npad, int functional, double* out) {
+__global__ __launch_bounds__(kThreads) void k_expectation(const double* x, const u64* cdf, const double* tmax, int N, int Npad,
+                                                          int B, int Bs, int functional, double* out) {
     __shared__ double lds_n[4], lds_d[4];
+    __shared__ double lds_m[16];
     const int tid = threadIdx.x, r = blockIdx.x;
-    const double m = scal[r].m;
+    double mx = -dinf();
+    bool nan = false;
+    for (int j = tid; j < B; j += kThreads) { const double v = tmax[(size_t)r * Bs + j]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
+    const double m = block_max_nanprop<kThreads>(mx, nan, lds_m);
     double num = 0.0, den = 0.0;
     for (int i = tid; i < N; i += kThreads) {
-        const double w = dexp(logw[(size_t)r * Npad + i] - m);
+        const u64 c1 = cdf[(size_t)r * Npad + i];
+        const u64 c0 = (i & (kTile - 1)) ? cdf[(size_t)r * Npad + i - 1] : 0ull;
+        const double w = (double)(c1 - c0) * dexp(tmax[(size_t)r * Bs + i / kTile] - m);
         const double xv = x[(size_t)r * Npad + i];
         const double hv = functional == 0 ? xv : functional == 1 ? xv * xv : functional == 2 ? dexp(0.5 * xv) : 42.0;
         num = num + hv * w;

@@ -57,11 +57,15 @@ class ParticleFilterBank:
     def reset(self):
         self._chk(capi.lib().ssme_pf_reset(self._h))
 
-    def set_debug(self, record_ancestors=True):
-        self._chk(capi.lib().ssme_pf_set_debug(self._h, int(record_ancestors)))
+    def set_debug(self, record_ancestors=True, keep_logw=True):
+        """Parity/debug: record ancestor indices and/or keep the log-weights in device memory."""
+        self._chk(capi.lib().ssme_pf_set_debug(self._h, (1 if record_ancestors else 0) | (2 if keep_logw else 0)))
 
     def set_graph_mode(self, on=True):
         self._chk(capi.lib().ssme_pf_set_graph_mode(self._h, int(on)))
+
+    def set_tuning(self, threads_per_tile=512):
+        self._chk(capi.lib().ssme_pf_set_tuning(self._h, int(threads_per_tile)))
 
     def step(self, y, z=None):
         """One filter(y[, z]) on every filter; returns the R log conditional likelihoods."""
@@ -101,19 +105,21 @@ class ParticleFilterBank:
         self._chk(capi.lib().ssme_pf_get_expectations(self._h, functional, capi.dptr(out)))
         return out
 
-    def state(self, f=0, ancestors=False):
+    def state(self, f=0, ancestors=False, logw=True):
         """Parity/debug view of filter f after the last step (cdf and tile sums are exact uint64)."""
         n = self.n
-        x, lw = np.empty(n), np.empty(n)
+        x = np.empty(n)
+        lw = np.empty(n) if logw else None
         cdf = np.empty(n, dtype=np.uint64)
         anc = np.empty(n, dtype=np.uint32) if ancestors else None
         self._chk(capi.lib().ssme_pf_download_state(self._h, f, capi.dptr(x), capi.dptr(lw), capi.u64ptr(cdf),
                                                     capi.u32ptr(anc)))
         nt = (n + 2047) // 2048
-        m, s, A, rs = np.empty(1), np.zeros(1, dtype=np.uint64), np.empty(nt, dtype=np.uint64), C.c_int32()
+        m, s, rs = np.empty(1), np.zeros(1, dtype=np.uint64), C.c_int32()
+        A, mb = np.empty(nt, dtype=np.uint64), np.empty(nt)
         self._chk(capi.lib().ssme_pf_download_scalars(self._h, f, capi.dptr(m), capi.u64ptr(s), capi.u64ptr(A),
-                                                      C.byref(rs)))
-        return dict(x=x, logw=lw, cdf=cdf, anc=anc, m=float(m[0]), S=int(s[0]), A=A, rshift=rs.value)
+                                                      capi.dptr(mb), C.byref(rs)))
+        return dict(x=x, logw=lw, cdf=cdf, anc=anc, m=float(m[0]), S=int(s[0]), A=A, mb=mb, rshift=rs.value)
 
     def last_elapsed_ms(self):
         ms = C.c_float()
@@ -121,13 +127,14 @@ class ParticleFilterBank:
         return ms.value
 
     def profile_series(self, y, z=None):
+        """Mean launch duration (us) of the step kernel, HIP events on the handle's stream."""
         yv = capi.as_f64(y)
         zv = None if z is None else capi.as_f64(z)
-        us = np.empty(2)
-        cnt = np.zeros(2, dtype=np.int32)
+        us = np.empty(1)
+        cnt = np.zeros(1, dtype=np.int32)
         self._chk(capi.lib().ssme_pf_profile_series(self._h, capi.dptr(yv), capi.dptr(zv), yv.size, capi.dptr(us),
                                                     cnt.ctypes.data_as(C.POINTER(C.c_int32))))
-        return {"propagate_weight_us": float(us[0]), "normalize_scan_us": float(us[1]), "launches": int(cnt[0])}
+        return {"filter_step_us": float(us[0]), "launches": int(cnt[0])}
 
 
 class _SingleFilter:

@@ -110,11 +110,22 @@ def test_quantize_and_exact_cdf(oracle, spy):
     for t in range(4):
         f.step(spy[t])
     st = f.state()
-    q = oracle.quantize(st["logw"] - st["m"], st["rshift"])
-    tiles = [np.cumsum(q[i:i + 2048], dtype=np.uint64) for i in range(0, 5000, 2048)]
+    # per-tile scales: q = rne(exp(logw - m_tile) 2^51), exact tile-local prefix sums
+    tiles, sums = [], []
+    for b, i in enumerate(range(0, 5000, 2048)):
+        lw = st["logw"][i:i + 2048]
+        assert st["mb"][b] == lw.max()
+        c = np.cumsum(oracle.quantize(lw - st["mb"][b], 51), dtype=np.uint64)
+        tiles.append(c)
+        sums.append(c[-1])
     np.testing.assert_array_equal(st["cdf"], np.concatenate(tiles))
-    np.testing.assert_array_equal(st["A"], [t[-1] for t in tiles])
-    assert st["S"] == int(sum(int(t[-1]) for t in tiles)) and st["rshift"] == 62 - 13
+    np.testing.assert_array_equal(st["A"], sums)
+    assert st["m"] == st["mb"].max() and st["rshift"] == 62 - 13
+    Ap = oracle.rescale(st["A"], st["mb"] - st["m"], st["rshift"] - 51)
+    assert st["S"] == int(sum(int(v) for v in Ap))
+    # log-sum-exp from the integers agrees with the floating-point one to ~1e-13
+    lse_fp = st["m"] + np.log(np.exp(st["logw"] - st["m"]).sum())
+    assert abs(st["m"] + np.log(st["S"] * 2.0 ** -st["rshift"]) - lse_fp) < 1e-12
     # ancestors of the (sorted) multinomial resampler are sorted and in range
     a = st["anc"].astype(np.int64)
     assert (np.diff(a) >= 0).all() and a.max() < 5000

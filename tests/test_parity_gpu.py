@@ -85,7 +85,8 @@ def test_device_quantize_bit_exact(sa, oracle):
         np.testing.assert_array_equal(q, oracle.quantize(x, shift))
 
 
-def test_device_block_scan_exact(sa):
+@pytest.mark.parametrize("threads", [256, 512, 1024])
+def test_device_block_scan_exact(sa, threads):
     """DPP wave scans + segment prefixes == numpy's exact uint64 cumulative sum (wrap-around included)."""
     from ssme_amd import _capi
     rng = np.random.default_rng(4)
@@ -93,10 +94,22 @@ def test_device_block_scan_exact(sa):
         v = rng.integers(0, hi, 2048, dtype=np.uint64)
         v[rng.integers(0, 2048, 100)] = 0
         incl, tot = np.empty(2048, dtype=np.uint64), np.zeros(1, dtype=np.uint64)
-        _capi.check(_capi.lib().ssme_pf_test_block_scan(0, _capi.u64ptr(v), _capi.u64ptr(incl), _capi.u64ptr(tot)))
+        _capi.check(_capi.lib().ssme_pf_test_block_scan(0, threads, _capi.u64ptr(v), _capi.u64ptr(incl), _capi.u64ptr(tot)))
         ref = np.cumsum(v, dtype=np.uint64)
         np.testing.assert_array_equal(incl, ref)
         assert tot[0] == ref[-1]
+
+
+def test_device_rescale_bit_exact(sa, oracle):
+    """A'_b = rint((double)A_b exp(m_b - m) 2^(rg-51)): the only floating-point step across tiles."""
+    from ssme_amd import _capi
+    rng = np.random.default_rng(6)
+    A = rng.integers(0, 1 << 62, 20000, dtype=np.uint64)
+    dm = np.concatenate([-rng.exponential(3.0, 19990), [0.0, -0.0, -800.0, -np.inf, np.nan, -1e-300, -745.0, -30.0, -1.0, -2.0]])
+    for shift in (-9, -2, 0):
+        out = np.empty(A.size, dtype=np.uint64)
+        _capi.check(_capi.lib().ssme_pf_test_rescale(0, _capi.u64ptr(A), _capi.dptr(dm), shift, _capi.u64ptr(out), A.size))
+        np.testing.assert_array_equal(out, oracle.rescale(A, dm, shift))
 
 
 def test_device_gamma_bit_exact(sa, oracle):
@@ -108,13 +121,15 @@ def test_device_gamma_bit_exact(sa, oracle):
 
 
 # ---- filter parity vs oracle ------------------------------------------------------------------------
-def _compare_state(bank, of, what, ancestors=True):
-    g = bank.state(0, ancestors=ancestors)
+def _compare_state(bank, of, what, ancestors=True, logw=True):
+    g = bank.state(0, ancestors=ancestors, logw=logw)
     o = of.state()
     assert_bits_equal(g["x"], o["x"], what + " particles")
-    assert_bits_equal(g["logw"], o["logw"], what + " log-weights")
+    if logw:
+        assert_bits_equal(g["logw"], o["logw"], what + " log-weights")
     np.testing.assert_array_equal(g["cdf"], o["cdf"], err_msg=what + " integer cdf")
     np.testing.assert_array_equal(g["A"], o["A"], err_msg=what + " tile sums")
+    assert_bits_equal(g["mb"], o["mb"], what + " tile maxima")
     assert_bits_equal([g["m"]], [o["m"]], what + " max log-weight")
     assert g["S"] == o["S"] and g["rshift"] == o["rshift"], what + " integer weight sum"
     return g, o
@@ -175,7 +190,7 @@ def test_series_matches_oracle_and_step_api(sa, oracle, spy):
         assert_bits_equal(bank.per_step()[0], per_o, "per-step log-lik")
         # a second run on the same handle (graph replay) reproduces it
         assert bank.run_series(spy[:T])[0] == ll_o
-        _compare_state(bank, of, "after series", ancestors=False)
+        _compare_state(bank, of, "after series", ancestors=False, logw=False)
         bank.close()
     bank = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, seed)
     bank.set_params(th)
@@ -183,6 +198,23 @@ def test_series_matches_oracle_and_step_api(sa, oracle, spy):
     for t in range(T):
         s += bank.step(spy[t])[0]
     assert bank.loglik()[0] == ll_o
+    bank.close()
+
+
+def test_block_size_tuning_is_result_invariant(sa, oracle, spy):
+    """Exact integer cdf: the kernel's block shape cannot change any result bit."""
+    th = [1.0, 0.95, 0.25]
+    n, seed, T = 9000, 12, 25
+    of = oracle.Filter(oracle.MODEL_SVOL, n, th, seed)
+    ll_o, per_o = of.run_series(spy[:T])
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, seed)
+    bank.set_debug(True)
+    bank.set_params(th)
+    for nt in (256, 512, 1024):
+        bank.set_tuning(nt)
+        assert bank.run_series(spy[:T])[0] == ll_o, nt
+        g, o = _compare_state(bank, of, f"nt={nt}")
+        np.testing.assert_array_equal(g["anc"], o["anc"])
     bank.close()
 
 

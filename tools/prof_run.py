@@ -18,6 +18,8 @@ ap.add_argument("--resampler", type=int, default=0)
 ap.add_argument("--filters", type=int, default=1)
 ap.add_argument("--model", type=int, default=0)
 ap.add_argument("--eager", action="store_true")
+ap.add_argument("--nt", type=int, default=0)
+ap.add_argument("--sweep", action="store_true")
 a = ap.parse_args()
 y = np.loadtxt(os.path.join(ROOT, "tests", "golden", "spy_returns.csv"))[:a.T]
 z = np.concatenate([[0.0], y[:-1]]) if a.model == 1 else None
@@ -26,7 +28,14 @@ bank = ssme_amd.ParticleFilterBank(a.model, a.n, a.filters, 20260101, a.resample
 if a.eager:
     bank.set_graph_mode(False)
 bank.set_params(th)
-for _ in range(a.passes):
-    ll = bank.run_series(y, z)
-print("loglik", ll[:4], "ms", bank.last_elapsed_ms(), "p-s/s", a.n * a.filters * a.T / (bank.last_elapsed_ms() * 1e-3))
+combos = [256, 512, 1024] if a.sweep else [a.nt or 512]
+for nt in combos:
+    bank.set_tuning(nt)
+    best = 1e9
+    for _ in range(a.passes):
+        ll = bank.run_series(y, z)
+        best = min(best, bank.last_elapsed_ms())
+    prof = bank.profile_series(y, z) if a.sweep else {}
+    print(f"nt={nt} loglik {ll[:2]} best ms {best:.3f} us/step {best*1e3/a.T:.2f} p-s/s {a.n * a.filters * a.T / (best * 1e-3):.4g}",
+          {k: round(v, 2) for k, v in prof.items()})
 bank.close()
