@@ -157,6 +157,8 @@ int ssme_pf_test_rescale(int32_t device, const uint64_t* tile_sums, const double
 /* exact inclusive scan of 2048 uint64 values by one block of 256/512/1024 threads (DPP wave scans) */
 int ssme_pf_test_block_scan(int32_t device, int32_t threads, const uint64_t* in2048, uint64_t* incl2048,
                             uint64_t* total);
+/* measurement aid: `repeats` streaming copies of n doubles with 16-byte-per-lane accesses (counter calibration) */
+int ssme_pf_test_copy(int32_t device, int64_t n_doubles, int32_t repeats);
 /* n Gamma(shape) draws for tiles 0..n-1 at time t of filter `rep` */
 int ssme_pf_test_gamma(int32_t device, uint64_t seed, uint32_t rep, int32_t t, double shape, int32_t n, double* out);
 

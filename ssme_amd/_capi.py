@@ -24,7 +24,7 @@ EXPORTS = [
     "ssme_pf_log_mean_exp", "ssme_pf_download_state", "ssme_pf_download_scalars", "ssme_pf_set_debug",
     "ssme_pf_set_graph_mode", "ssme_pf_set_tuning", "ssme_pf_last_elapsed_ms", "ssme_pf_profile_series", "ssme_pf_test_math",
     "ssme_pf_test_philox", "ssme_pf_test_quantize", "ssme_pf_test_rescale", "ssme_pf_test_block_scan",
-    "ssme_pf_test_gamma",
+    "ssme_pf_test_copy", "ssme_pf_test_gamma",
     "ssme_pf_strerror", "ssme_pf_last_error",
     "ssme_pf_version",
 ]
@@ -79,6 +79,7 @@ def lib():
         L.ssme_pf_test_quantize.argtypes = [C.c_int32, dp, C.c_int32, u64p, C.c_int64]
         L.ssme_pf_test_block_scan.argtypes = [C.c_int32, C.c_int32, u64p, u64p, u64p]
         L.ssme_pf_test_rescale.argtypes = [C.c_int32, u64p, dp, C.c_int32, u64p, C.c_int64]
+        L.ssme_pf_test_copy.argtypes = [C.c_int32, C.c_int64, C.c_int32]
         L.ssme_pf_test_gamma.argtypes = [C.c_int32, C.c_uint64, C.c_uint32, C.c_int32, C.c_double, C.c_int32, dp]
         L.ssme_pf_strerror.restype = C.c_char_p
         L.ssme_pf_strerror.argtypes = [C.c_int]

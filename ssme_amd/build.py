@@ -36,7 +36,18 @@ def build(force=False, verbose=False, extra=(), out=None):
     cmd = [hipcc()] + FLAGS + list(extra) + SOURCES + ["-o", out or SO]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    res = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout)
+        raise subprocess.CalledProcessError(res.returncode, cmd)
+    # no kernel may touch scratch memory: a spilled array silently doubles the HBM traffic of the step kernel
+    name = None
+    for line in res.stdout.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split()[0]
+        if "ScratchSize [bytes/lane]:" in line and int(line.split("ScratchSize [bytes/lane]:")[1].split()[0]) != 0:
+            if name and "k_test" not in name:
+                raise RuntimeError(f"kernel {name} uses scratch memory: {line.strip()}")
     return out or SO
 
 

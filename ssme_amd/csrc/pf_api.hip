@@ -104,6 +104,20 @@ static StepArgs step_args(ssme_pf_handle h) {
     a.logN = dlog((double)h->N);
 #ifdef SSME_ABLATE
     { const char* e = getenv("SSME_ABLATE_MASK"); a.ablate = e ? atoi(e) : 0; }
+    {
+        static unsigned long long* g_stamps = nullptr;       // diagnostic build only
+        if (getenv("SSME_STAMPS")) {
+            if (!g_stamps) { hipMalloc(&g_stamps, sizeof(unsigned long long) * 16 * (size_t)h->B * h->R); }
+            a.stamps = g_stamps;
+            if (getenv("SSME_STAMPS_DUMP")) {   // dump the stamps of the last launch (call after a sync)
+                std::vector<unsigned long long> hs(16 * (size_t)h->B * h->R);
+                hipMemcpy(hs.data(), g_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+                FILE* f = fopen(getenv("SSME_STAMPS_DUMP"), "w");
+                for (size_t i = 0; i < hs.size(); i += 16) { for (int k = 0; k < 16; ++k) fprintf(f, "%llu ", hs[i + k]); fprintf(f, "\n"); }
+                fclose(f);
+            }
+        }
+    }
 #endif
     return a;
 }
@@ -583,6 +597,11 @@ __global__ __launch_bounds__(NT) void k_test_block_scan(const u64* in, u64* incl
     for (int k = 0; k < NK; ++k) { incl[(k * NT + tid) * 2] = inc[k][0]; incl[(k * NT + tid) * 2 + 1] = inc[k][1]; }
     if (tid == 0) *total = tot;
 }
+// streaming copy with the step kernel's access shape (16 B per lane): calibrates FETCH_SIZE / WRITE_SIZE
+__global__ __launch_bounds__(512) void k_calib_copy(const double* in, double* out, long n2) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<double2*>(out)[i] = reinterpret_cast<const double2*>(in)[i];
+}
 __global__ void k_test_gamma(uint32_t key0, uint32_t key1, uint32_t rep, int t, double shape, int n, double* out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < n) out[b] = gamma_draw((uint32_t)b, (uint32_t)t, rep, key0, key1, shape);
@@ -678,6 +697,24 @@ int ssme_pf_test_block_scan(int32_t device, int32_t threads, const uint64_t* in,
     HIPCHK0(hipMemcpy(total, d + 2 * kTile, sizeof(u64), hipMemcpyDeviceToHost));
 done:
     if (d) hipFree(d);
+    return rc;
+}
+
+int ssme_pf_test_copy(int32_t device, int64_t n_doubles, int32_t repeats) {
+    if (n_doubles < 2 || repeats < 1) return SSME_ERR_INVALID_ARG;
+    int rc = SSME_OK;
+    double *a = nullptr, *b = nullptr;
+    HIPCHK0(hipSetDevice(device));
+    HIPCHK0(hipMalloc(&a, sizeof(double) * n_doubles));
+    HIPCHK0(hipMalloc(&b, sizeof(double) * n_doubles));
+    HIPCHK0(hipMemset(a, 0, sizeof(double) * n_doubles));
+    for (int i = 0; i < repeats; ++i)
+        hipLaunchKernelGGL(k_calib_copy, dim3(512), dim3(512), 0, 0, (i & 1) ? b : a, (i & 1) ? a : b, (long)(n_doubles / 2));
+    HIPCHK0(hipGetLastError());
+    HIPCHK0(hipDeviceSynchronize());
+done:
+    if (a) hipFree(a);
+    if (b) hipFree(b);
     return rc;
 }
 

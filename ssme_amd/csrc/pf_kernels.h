@@ -41,8 +41,11 @@ enum { RESAMP_MULTINOMIAL = 0, RESAMP_SYSTEMATIC = 1, RESAMP_STRATIFIED = 2, RES
 
 #ifdef SSME_ABLATE
 #define ABL(a, bit) (((a).ablate >> (bit)) & 1)
+// diagnostic phase stamps (100 MHz constant clock), one row of 16 per block; never in the product build
+#define STAMP(a, i) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define ABL(a, bit) 0
+#define STAMP(a, i) do {} while (0)
 #endif
 
 // Derived per-filter constants (host computes them with the same ssme_math functions).
@@ -88,6 +91,7 @@ struct StepArgs {
     uint32_t key0, key1, first_filter;
     double logN;
     int32_t ablate;            // measurement builds only (-DSSME_ABLATE): skip sections, results invalid
+    unsigned long long* stamps;  // measurement builds only: phase time stamps
 };
 
 // ---------------------------------------------------------------------------------------
@@ -233,6 +237,20 @@ __device__ __forceinline__ void normal_pair(uint32_t pair, uint32_t t, uint32_t 
     *z1 = rad * sn;
 }
 
+// the same in two halves, so that memory latency can be hidden between them
+__device__ __forceinline__ void normal_pair_radius(uint32_t pair, uint32_t t, uint32_t rep, uint32_t k0, uint32_t k1,
+                                                   double* rad, double* u2) {
+    const u32x4 o = philox4x32_10(pair, t, rep, STREAM_PROP, k0, k1);
+    *rad = dsqrt(-2.0 * dlog_pn(u01_oc(o.v0, o.v1)));
+    *u2 = u01_co(o.v2, o.v3);
+}
+__device__ __forceinline__ void normal_pair_angle(double rad, double u2, double* z0, double* z1) {
+    double sn, cs;
+    dsincos2pi(u2, &sn, &cs);
+    *z0 = rad * cs;
+    *z1 = rad * sn;
+}
+
 // Gamma(shape) draw, Marsaglia & Tsang (2000), attempts driven by the Philox counter
 __device__ __forceinline__ double gamma_draw(uint32_t b, uint32_t t, uint32_t rep, uint32_t k0, uint32_t k1, double shape) {
     const double d = shape - 0.3333333333333333;
@@ -288,29 +306,51 @@ __device__ __forceinline__ int count_less_gallop(const u64* tile, u64 target, in
 
 // Level-2 of one filter: global max m over the tile maxima (NaN propagating), rescaled integer
 // tile sums A'_b = rint(A_b exp(m_b - m) 2^(rg-51)), their exact inclusive scan.  Thread tid holds
-// entries j = (k*NT + tid)*2 + c.  Two barriers.  lds_d: NT/64 doubles, lds_seg: 16 u64.
+// entries j = (k*NT + tid)*2 + c; rows and waves without live entries (j >= B) skip the arithmetic.
+// Two barriers.  lds_d: NT/64 doubles, lds_seg: 16 u64.
+template <int NT>
+__device__ __forceinline__ void level2_load(const u64* ts, const double* tm, int B, u64 (&A)[1024 / NT][2],
+                                            double (&mb)[1024 / NT][2]) {
+    constexpr int NK = 1024 / NT;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int j = (k * NT + threadIdx.x) * 2;
+        if (j < B) {       // Bs is even: j+1 < Bs
+            const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(ts + j);
+            const double2 m2 = *reinterpret_cast<const double2*>(tm + j);
+            A[k][0] = t2.x; A[k][1] = t2.y; mb[k][0] = m2.x; mb[k][1] = m2.y;
+        } else { A[k][0] = 0; A[k][1] = 0; mb[k][0] = 0.0; mb[k][1] = 0.0; }
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void level2_scan(const u64 (&A)[1024 / NT][2], const double (&mb)[1024 / NT][2], int B, int rshift,
                                             double& m, u64 (&Ap)[1024 / NT][2], u64 (&Tinc)[1024 / NT][2], u64& S,
                                             double* lds_d, u64* lds_seg) {
     constexpr int NK = 1024 / NT;
+    const int wave_j0 = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 128);   // first entry of my wave in row 0
     double mx = -dinf();
     bool nan = false;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
+        if (k * NT * 2 + wave_j0 < B) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int j = (k * NT + threadIdx.x) * 2 + c;
-            if (j < B) { const double v = mb[k][c]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
+            for (int c = 0; c < 2; ++c) {
+                const int j = (k * NT + threadIdx.x) * 2 + c;
+                if (j < B) { const double v = mb[k][c]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
+            }
         }
     }
     m = block_max_nanprop<NT>(mx, nan, lds_d);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
+        Ap[k][0] = 0; Ap[k][1] = 0;
+        if (k * NT * 2 + wave_j0 < B) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int j = (k * NT + threadIdx.x) * 2 + c;
-            Ap[k][c] = (j < B) ? rint_to_u64((double)A[k][c] * dexp_scaled(mb[k][c] - m, rshift - kTileShift)) : 0ull;
+            for (int c = 0; c < 2; ++c) {
+                const int j = (k * NT + threadIdx.x) * 2 + c;
+                if (j < B) Ap[k][c] = rint_to_u64((double)A[k][c] * dexp_scaled(mb[k][c] - m, rshift - kTileShift));
+            }
         }
     }
     block_scan_u64<NT>(Ap, Tinc, S, lds_seg);
@@ -319,7 +359,10 @@ __device__ __forceinline__ void level2_scan(const u64 (&A)[1024 / NT][2], const 
 // ---------------------------------------------------------------------------------------
 // k_filter_step: one bootstrap-filter step for every tile of every filter.
 // grid = (B tiles, R filters), block = NT (256/512/1024: NK = 1024/NT particle pairs per thread),
-// dynamic LDS = (2*max(Bpow2,2) + 3*2048) * 8 bytes
+// dynamic LDS = (2*max(Bpow2,2) + 3*2048) * 8 bytes.
+// Phase order is chosen so that arithmetic hides memory latency: the cdf tiles are requested,
+// then the Box-Muller radii are computed while they arrive; the ancestor states are requested,
+// then the Box-Muller angles are computed while they arrive.
 // ---------------------------------------------------------------------------------------
 template <int MODEL, int NT>
 __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
@@ -332,7 +375,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     __shared__ u64 lds_seg_a[16];
     __shared__ u64 lds_seg_b[16];
     __shared__ u64 lds_seg_c[16];
-    __shared__ u64 lds_x[2];
+    __shared__ int lds_cnt[2];
     __shared__ double lds_d1[16];
     __shared__ double lds_d2[16];
 
@@ -345,46 +388,129 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     const double zcov = a.z ? a.z[a.yi] : 0.0;
     const bool resampled = (a.t > 0) && (a.t % a.resamp_sched == 0);
     const bool need_l2 = (a.t > 0) && (resampled || (b == 0 && a.finalize_prev));
+    const bool sorted = a.resampler != RESAMP_MULTINOMIAL_IID;
+    const int i_first = b * kTile;
+    const int nvalid = (a.N - i_first) < kTile ? (a.N - i_first) : kTile;    // valid outputs in this tile (>= 1)
 
+    STAMP(a, 0);
     // --- issue the level-2 loads first: previous step's tile sums and maxima ---
     u64 A2[NK][2];
     double M2[NK][2];
-    if (need_l2) {
-        const u64* ts = a.tsum_in + (size_t)r * a.Bs;
-        const double* tm = a.tmax_in + (size_t)r * a.Bs;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int j = (k * NT + tid) * 2;
-            if (j < a.B) {       // Bs is even: j+1 < Bs
-                const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(ts + j);
-                const double2 m2 = *reinterpret_cast<const double2*>(tm + j);
-                A2[k][0] = t2.x; A2[k][1] = t2.y; M2[k][0] = m2.x; M2[k][1] = m2.y;
-            } else { A2[k][0] = 0; A2[k][1] = 0; M2[k][0] = 0.0; M2[k][1] = 0.0; }
-        }
-    }
-    double gam = 0.0, pgam = 0.0, G = 1.0;
+    if (need_l2) level2_load<NT>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
+    if (tid == 0) { lds_cnt[0] = 0; lds_cnt[1] = 0; }
+    double gam = 0.0, pgam = 0.0, pgam_next = 0.0, G = 1.0;
     const bool multinomial = resampled && a.resampler == RESAMP_MULTINOMIAL;
     if (multinomial) {
         const size_t gidx = ((size_t)a.gi * a.R + r) * a.B + b;
         gam = a.gam[gidx]; pgam = a.pgam[gidx]; G = a.gtot[(size_t)a.gi * a.R + r];
+        pgam_next = (b + 1 < a.B) ? a.pgam[gidx + 1] : G;
     }
 
-    // --- standard normals for my particles ---
-    double zn[NK][2];
+    STAMP(a, 1);
+    // --- level-2: global max, rescaled tile sums A', inclusive prefixes T', total S'; tile range of my targets ---
+    u64 S = 0;
+    double t_scale = 0.0, u0 = 0.0;
+    if (need_l2) {
+        u64 Ap[NK][2], Tinc[NK][2];
+        double m;
+        level2_scan<NT>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d1, lds_seg_b);
+        // bounds [t_lo, t_hi] of this tile's targets, known to every thread without the spacings
+        const double Sd = (double)S;
+        u64 t_lo = 0, t_hi = ~0ull;
+        if (a.resampler == RESAMP_MULTINOMIAL) {
+            t_scale = Sd / G;                          // targets: (pgam + Gamma_b E_cum/E_tile) * S'/G  
+            t_lo = tau_to_u64(pgam * t_scale);
+            t_hi = tau_to_u64(pgam_next * t_scale) + (S >> 40) + 2;   // slack covers the rounding of ratio*E_tile vs Gamma_b
+        } else if (a.resampler == RESAMP_SYSTEMATIC) {
+            const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, a.key0, a.key1);
+            u0 = u01_co(ox.v0, ox.v1);
+            t_scale = Sd / (double)a.N;
+            t_lo = tau_to_u64(((double)i_first + u0) * t_scale);
+            t_hi = tau_to_u64(((double)(i_first + nvalid - 1) + u0) * t_scale);
+        } else {
+            t_scale = Sd / (double)a.N;
+            t_lo = tau_to_u64((double)i_first * t_scale);
+            t_hi = tau_to_u64((double)(i_first + nvalid) * t_scale);
+        }
+        const int wave_j0 = __builtin_amdgcn_readfirstlane((tid >> 6) * 128);
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const uint32_t pair = (uint32_t)(b * (kTile / 2) + k * NT + tid);
-        if (ABL(a, 0)) { zn[k][0] = 0.25 + 1e-9 * (double)pair; zn[k][1] = -0.25; }
-        else normal_pair(pair, (uint32_t)a.t, rep, a.key0, a.key1, &zn[k][0], &zn[k][1]);
+        for (int k = 0; k < NK; ++k) {
+            if (k * NT * 2 + wave_j0 < a.Bpow2) {
+                int c_lo = 0, c_hi = 0;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int j = (k * NT + tid) * 2 + c;
+                    if (j < a.Bpow2) {
+                        lds_T[j] = (j < a.B) ? Tinc[k][c] : ~0ull;
+                        lds_R[j] = (j < a.B) ? (double)A2[k][c] / (double)Ap[k][c] : 0.0;
+                    }
+                    c_lo += (j < a.B && Tinc[k][c] < t_lo) ? 1 : 0;
+                    c_hi += (j < a.B && Tinc[k][c] < t_hi) ? 1 : 0;
+                }
+                if (resampled && sorted) {
+                    // #{T'_j < t_lo}, #{T'_j < t_hi}: wave popcounts, one LDS atomic per wave
+                    const int w_lo = __popcll(__ballot(c_lo & 1)) + 2 * __popcll(__ballot(c_lo >> 1));
+                    const int w_hi = __popcll(__ballot(c_hi & 1)) + 2 * __popcll(__ballot(c_hi >> 1));
+                    if ((tid & 63) == 0) { if (w_lo) atomicAdd(&lds_cnt[0], w_lo); if (w_hi) atomicAdd(&lds_cnt[1], w_hi); }
+                }
+            }
+        }
+        if (b == 0 && tid == 0 && a.finalize_prev) {
+            FilterScalars* sc = a.scal + r;
+            const double Sdd = S ? dldexp((double)S, -a.rshift) : dnan();
+            const double lse = m + dlog(Sdd);
+            const double ll = lse - sc->prev;
+            sc->m = m;
+            sc->S = S;
+            sc->last_ll = ll;
+            sc->loglik = sc->loglik + ll;
+            sc->prev = resampled ? a.logN : lse;
+            if (a.per_step) a.per_step[(size_t)r * a.Tcap + (a.t - 1)] = ll;
+        }
     }
+    STAMP(a, 2);
 
-    // --- exponential spacings of the multinomial resampler (liu_west_filter.h:105-139), exact tile scan ---
+    // --- request the cdf tiles my targets fall into (coalesced 16-byte loads into registers) ---
+    int bb_min = 0, span = kStageTiles + 1;
+    // three explicitly named register tiles (a runtime-indexed array would be placed in scratch memory)
+    ulonglong2 stg0[NK], stg1[NK], stg2[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { stg0[k] = make_ulonglong2(0, 0); stg1[k] = stg0[k]; stg2[k] = stg0[k]; }
+    const u64* cdf_r = a.cdf_in + rowoff;
+    const double* xin_r = a.x_in + rowoff;
+    if (resampled) {
+        __syncthreads();          // lds_T, lds_R, lds_cnt visible
+        if (sorted) {
+            int lo = lds_cnt[0], hi = lds_cnt[1];
+            lo = lo < a.B - 1 ? lo : a.B - 1;
+            hi = hi < a.B - 1 ? hi : a.B - 1;
+            bb_min = __builtin_amdgcn_readfirstlane(lo);
+            span = __builtin_amdgcn_readfirstlane(hi) - bb_min + 1;
+        }
+        if (span <= kStageTiles) {
+            const u64* src = cdf_r + (size_t)bb_min * kTile + tid * 2;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) stg0[k] = *reinterpret_cast<const ulonglong2*>(src + k * NT * 2);
+            if (span >= 2) {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) stg1[k] = *reinterpret_cast<const ulonglong2*>(src + kTile + k * NT * 2);
+            }
+            if (span >= 3) {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) stg2[k] = *reinterpret_cast<const ulonglong2*>(src + 2 * kTile + k * NT * 2);
+            }
+        }
+    }
+    STAMP(a, 3);
+
+    // --- exponential spacings of the multinomial resampler (liu_west_filter.h:105-139), exact tile scan;
+    //     this arithmetic hides the latency of the tile loads ---
     u64 le[NK][2], se = 1;
     if (multinomial) {
         u64 qe[NK][2];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            const int i0 = b * kTile + (k * NT + tid) * 2;
+            const int i0 = i_first + (k * NT + tid) * 2;
             double e0, e1;
             if (ABL(a, 1)) { e0 = 1.0 + 1e-6 * (double)(i0 & 1023); e1 = 1.0; }
             else {
@@ -396,37 +522,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         }
         block_scan_u64<NT>(qe, le, se, lds_seg_a);
     }
-
-    // --- level-2: global max, rescaled tile sums A', inclusive prefixes T', total S' ---
-    u64 S = 0;
-    if (need_l2) {
-        u64 Ap[NK][2], Tinc[NK][2];
-        double m;
-        level2_scan<NT>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d1, lds_seg_b);
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int j = (k * NT + tid) * 2 + c;
-                if (j < a.Bpow2) {
-                    lds_T[j] = (j < a.B) ? Tinc[k][c] : ~0ull;
-                    lds_R[j] = (double)A2[k][c] / (double)Ap[k][c];
-                }
-            }
-        }
-        if (b == 0 && tid == 0 && a.finalize_prev) {
-            FilterScalars* sc = a.scal + r;
-            const double Sd = S ? dldexp((double)S, -a.rshift) : dnan();
-            const double lse = m + dlog(Sd);
-            const double ll = lse - sc->prev;
-            sc->m = m;
-            sc->S = S;
-            sc->last_ll = ll;
-            sc->loglik = sc->loglik + ll;
-            sc->prev = resampled ? a.logN : lse;
-            if (a.per_step) a.per_step[(size_t)r * a.Tcap + (a.t - 1)] = ll;
-        }
-    }
+    STAMP(a, 4);
 
     double xin[NK][2], lw_old[NK][2];
     if (a.t == 0) {
@@ -435,7 +531,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     } else if (!resampled) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            const size_t idx = rowoff + (size_t)b * kTile + (k * NT + tid) * 2;
+            const size_t idx = rowoff + (size_t)i_first + (k * NT + tid) * 2;
             const double2 xv = *reinterpret_cast<const double2*>(a.x_in + idx);
             const double2 lv = *reinterpret_cast<const double2*>(a.logw + idx);
             xin[k][0] = xv.x; xin[k][1] = xv.y; lw_old[k][0] = lv.x; lw_old[k][1] = lv.y;
@@ -443,81 +539,47 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     } else {
         // --- integer resampling targets in [0, S'] ---
         u64 tau[NK][2];
-        const double Sd = (double)S;
-        if (a.resampler == RESAMP_MULTINOMIAL) {
-            // per tile: Gamma_b * E_j / sum_tile(E)  
-            const double ratio = gam / (double)se;
-            const double scale = Sd / G;
+        const double ratio = gam / (double)se;          // per tile: Gamma_b * E_j / sum_tile(E)
 #pragma unroll
-            for (int k = 0; k < NK; ++k) {
+        for (int k = 0; k < NK; ++k) {
+            const int i0 = i_first + (k * NT + tid) * 2;
+            if (a.resampler == RESAMP_MULTINOMIAL) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const double t1 = ratio * (double)le[k][c];
                     const double t2 = pgam + t1;
-                    tau[k][c] = tau_to_u64(t2 * scale);
+                    tau[k][c] = tau_to_u64(t2 * t_scale);
                 }
-            }
-        } else if (a.resampler == RESAMP_SYSTEMATIC) {
-            const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, a.key0, a.key1);
-            const double u0 = u01_co(ox.v0, ox.v1);
-            const double scale = Sd / (double)a.N;
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int i0 = b * kTile + (k * NT + tid) * 2;
-                tau[k][0] = tau_to_u64(((double)i0 + u0) * scale);
-                tau[k][1] = tau_to_u64(((double)(i0 + 1) + u0) * scale);
-            }
-        } else {
-            const double scale = Sd / (double)a.N;
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int i0 = b * kTile + (k * NT + tid) * 2;
+            } else if (a.resampler == RESAMP_SYSTEMATIC) {
+                tau[k][0] = tau_to_u64(((double)i0 + u0) * t_scale);
+                tau[k][1] = tau_to_u64(((double)(i0 + 1) + u0) * t_scale);
+            } else {
                 const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, a.key0, a.key1);
                 const double v0 = u01_co(o.v0, o.v1), v1 = u01_co(o.v2, o.v3);
                 if (a.resampler == RESAMP_STRATIFIED) {
-                    tau[k][0] = tau_to_u64(((double)i0 + v0) * scale);
-                    tau[k][1] = tau_to_u64(((double)(i0 + 1) + v1) * scale);
+                    tau[k][0] = tau_to_u64(((double)i0 + v0) * t_scale);
+                    tau[k][1] = tau_to_u64(((double)(i0 + 1) + v1) * t_scale);
                 } else {
+                    const double Sd = (double)S;
                     tau[k][0] = tau_to_u64(v0 * Sd);
                     tau[k][1] = tau_to_u64(v1 * Sd);
                 }
             }
         }
 
-        const u64* cdf_r = a.cdf_in + rowoff;
-        const double* xin_r = a.x_in + rowoff;
-        const int nvalid = a.N - b * kTile;      // valid outputs in this tile (>= 1)
-        const bool sorted = a.resampler != RESAMP_MULTINOMIAL_IID;
-
-        // --- range of cdf tiles this output tile needs (targets are sorted except for iid) ---
-        if (sorted) {
-            if (tid == 0) lds_x[0] = tau[0][0];
-            const int last = (nvalid < kTile ? nvalid : kTile) - 1;
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                if ((k * NT + tid) * 2 == (last & ~1)) lds_x[1] = tau[k][last & 1];
-            }
-        }
-        __syncthreads();          // lds_T, lds_R and lds_x visible
-        int bb_min = 0, span = kStageTiles + 1;
-        if (sorted) {
-            const u64 tf = lds_x[0], tl = lds_x[1];
-            int lo = count_less_pow2(a.Bpow2, tf, [&](int j) { return lds_T[j]; });
-            int hi = count_less_pow2(a.Bpow2, tl, [&](int j) { return lds_T[j]; });
-            lo = lo < a.B - 1 ? lo : a.B - 1;
-            hi = hi < a.B - 1 ? hi : a.B - 1;
-            bb_min = __builtin_amdgcn_readfirstlane(lo);
-            span = __builtin_amdgcn_readfirstlane(hi) - bb_min + 1;
-        }
-
         if (span <= kStageTiles) {
-            // stage the needed cdf tiles (coalesced 16-byte loads), then search in LDS
-            for (int s = 0; s < span; ++s) {
-                const u64* src = cdf_r + (size_t)(bb_min + s) * kTile;
+            // --- staged tiles -> LDS, then count-search in LDS ---
+            {
+                u64* dst = lds_stage + tid * 2;
 #pragma unroll
-                for (int k = 0; k < NK; ++k) {
-                    const int j = (k * NT + tid) * 2;
-                    *reinterpret_cast<ulonglong2*>(lds_stage + s * kTile + j) = *reinterpret_cast<const ulonglong2*>(src + j);
+                for (int k = 0; k < NK; ++k) *reinterpret_cast<ulonglong2*>(dst + k * NT * 2) = stg0[k];
+                if (span >= 2) {
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) *reinterpret_cast<ulonglong2*>(dst + kTile + k * NT * 2) = stg1[k];
+                }
+                if (span >= 3) {
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) *reinterpret_cast<ulonglong2*>(dst + 2 * kTile + k * NT * 2) = stg2[k];
                 }
             }
             const int b1 = bb_min + 1 < a.B ? bb_min + 1 : a.B - 1, b2 = bb_min + 2 < a.B ? bb_min + 2 : a.B - 1;
@@ -526,6 +588,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             const u64 Pm = bb_min ? lds_T[bb_min - 1] : 0ull;
             const double R0 = lds_R[bb_min], R1 = lds_R[b1], R2 = lds_R[b2];
             __syncthreads();
+            STAMP(a, 5);
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
                 int sel_prev = -1, j_prev = 0;
@@ -545,7 +608,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                     sel_prev = sel; j_prev = j;
                     int anc = (bb_min + sel) * kTile + j;
                     anc = anc < a.N - 1 ? anc : a.N - 1;
-                    const int i = b * kTile + (k * NT + tid) * 2 + c;
+                    const int i = i_first + (k * NT + tid) * 2 + c;
                     if (a.anc && i < a.N) a.anc[rowoff + i] = (uint32_t)anc;
                     xin[k][c] = xin_r[anc];
                     lw_old[k][c] = 0.0;
@@ -566,7 +629,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                     const int j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
                     int anc = bb * kTile + j;
                     anc = anc < a.N - 1 ? anc : a.N - 1;
-                    const int i = b * kTile + (k * NT + tid) * 2 + c;
+                    const int i = i_first + (k * NT + tid) * 2 + c;
                     if (a.anc && i < a.N) a.anc[rowoff + i] = (uint32_t)anc;
                     xin[k][c] = xin_r[anc];
                     lw_old[k][c] = 0.0;
@@ -574,6 +637,17 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             }
         }
     }
+    STAMP(a, 6);
+
+    // --- standard normals (Box-Muller); this arithmetic hides the latency of the ancestor gather ---
+    double zn[NK][2];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const uint32_t pair = (uint32_t)(b * (kTile / 2) + k * NT + tid);
+        if (ABL(a, 0)) { zn[k][0] = 0.25 + 1e-9 * (double)pair; zn[k][1] = -0.25; }
+        else normal_pair(pair, (uint32_t)a.t, rep, a.key0, a.key1, &zn[k][0], &zn[k][1]);
+    }
+    STAMP(a, 7);
 
     // --- fSamp / q1Samp, logGEv, tile max ---
     double lg[NK][2];
@@ -581,7 +655,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     bool nan = false;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const int i0 = b * kTile + (k * NT + tid) * 2;
+        const int i0 = i_first + (k * NT + tid) * 2;
         double xo[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -596,13 +670,15 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         *reinterpret_cast<double2*>(a.x_out + idx) = make_double2(xo[0], xo[1]);
         if (a.logw) *reinterpret_cast<double2*>(a.logw + idx) = make_double2(lg[k][0], lg[k][1]);
     }
+    STAMP(a, 8);
     const double mb = block_max_nanprop<NT>(mx, nan, lds_d2);
+    STAMP(a, 9);
 
     // --- tile-local fixed-point weights and their exact inclusive scan (the next step's cdf) ---
     u64 q[NK][2], inc[NK][2], total;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const int i0 = b * kTile + (k * NT + tid) * 2;
+        const int i0 = i_first + (k * NT + tid) * 2;
         if (ABL(a, 4)) { q[k][0] = d2bits(lg[k][0] - mb) >> 24; q[k][1] = d2bits(lg[k][1] - mb) >> 24; }
         else {
             q[k][0] = (i0 < a.N) ? rne_u52(dexp_scaled(lg[k][0] - mb, kTileShift)) : 0ull;
@@ -614,15 +690,21 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         for (int k = 0; k < NK; ++k) { inc[k][0] = q[k][0]; inc[k][1] = q[k][0] + q[k][1]; }
         total = inc[0][1] + 0x100000;
     } else block_scan_u64<NT>(q, inc, total, lds_seg_c);
+    STAMP(a, 12);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const int i0 = b * kTile + (k * NT + tid) * 2;
+        const int i0 = i_first + (k * NT + tid) * 2;
         *reinterpret_cast<ulonglong2*>(a.cdf_out + rowoff + i0) = make_ulonglong2(inc[k][0], inc[k][1]);
     }
+    STAMP(a, 10);
     if (tid == 0) {
         a.tsum_out[(size_t)r * a.Bs + b] = total;
         a.tmax_out[(size_t)r * a.Bs + b] = mb;
     }
+#ifdef SSME_ABLATE
+    __syncthreads();
+    STAMP(a, 11);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -636,17 +718,7 @@ __global__ __launch_bounds__(kThreads) void kf_finalize(const StepArgs a) {
     const int r = blockIdx.x;
     u64 A2[4][2], Ap[4][2], Tinc[4][2], S;
     double M2[4][2], m;
-    const u64* ts = a.tsum_in + (size_t)r * a.Bs;
-    const double* tm = a.tmax_in + (size_t)r * a.Bs;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int j = (k * kThreads + tid) * 2;
-        if (j < a.B) {
-            const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(ts + j);
-            const double2 m2 = *reinterpret_cast<const double2*>(tm + j);
-            A2[k][0] = t2.x; A2[k][1] = t2.y; M2[k][0] = m2.x; M2[k][1] = m2.y;
-        } else { A2[k][0] = 0; A2[k][1] = 0; M2[k][0] = 0.0; M2[k][1] = 0.0; }
-    }
+    level2_load<kThreads>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
     level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
     if (tid == 0) {
         FilterScalars* sc = a.scal + r;
