@@ -105,16 +105,10 @@ def main():
         dev_ms += bank.last_elapsed_ms()
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    lls = torch.tensor([ll], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        gathered = [torch.zeros_like(lls) for _ in range(world)]
-        dist.all_gather(gathered, lls)
-        lls = torch.cat(gathered)
-    dt = float(tmax.item())
-    lls = lls.cpu().numpy()
-    lme = float(lls.max() + np.log(np.exp(lls - lls.max()).sum()) - np.log(len(lls)))   # thread_pool.h:263-268
+    from ssme_amd import parallel
+    dt = parallel.max_over_ranks(dt)                              # MAX over ranks
+    lls = parallel.gather_logliks([ll], world)                    # the one small collective of a pass
+    lme = parallel.log_mean_exp(lls)                              # thread_pool.h:263-268
 
     if rank == 0:
         psteps_per_pass = float(n) * T * world

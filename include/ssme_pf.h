@@ -139,9 +139,9 @@ int ssme_pf_set_graph_mode(ssme_pf_handle h, int32_t mode);
  * 8*T-byte upload of y and the 8*R-byte download of the result excluded). */
 int ssme_pf_last_elapsed_ms(ssme_pf_handle h, float* ms);
 
-/* Measurement aid for bench.py: runs a T-step series eagerly with a HIP event between consecutive
- * launches of the step kernel (k_filter_step) on the handle's stream; returns the mean launch
- * duration in microseconds (mean_us_out[0]) and the launch count (launches_out[0]). */
+/* Measurement aid for bench.py: runs a T-step series eagerly (no graph) with a HIP event on the handle's
+ * stream after every 32 launches of the step kernel (k_filter_step); returns the mean launch duration in
+ * microseconds (mean_us_out[0]) and the launch count (launches_out[0]). */
 int ssme_pf_profile_series(ssme_pf_handle h, const double* y, const double* z, int32_t T,
                            double* mean_us_out /*1*/, int32_t* launches_out /*1*/);
 

@@ -70,10 +70,13 @@ inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
     out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
 }
 
-// 53 random bits from two words -> [0,1) and (0,1]
-inline uint64_t bits53(uint32_t a, uint32_t b) { return ((uint64_t)a << 21) | (uint64_t)(b >> 11); }
-inline double u01_co(uint32_t a, uint32_t b) { return (double)bits53(a, b) * 0x1.0p-53; }          // [0,1)
-inline double u01_oc(uint32_t a, uint32_t b) { return (double)(bits53(a, b) + 1) * 0x1.0p-53; }    // (0,1]
+// 52 random bits from two words -> [0,1) and (0,1]
+inline double u12(uint32_t a, uint32_t b) {                       // 52 random bits as the mantissa of a double in [1,2)
+    const uint64_t u = 0x3ff0000000000000ull | ((((uint64_t)a << 32) | b) >> 12);
+    double d; std::memcpy(&d, &u, 8); return d;
+}
+inline double u01_co(uint32_t a, uint32_t b) { return u12(a, b) - 1.0; }          // [0,1)
+inline double u01_oc(uint32_t a, uint32_t b) { return 2.0 - u12(a, b); }          // (0,1]
 
 enum { STREAM_PROP = 0, STREAM_RESAMP = 1, STREAM_RESAMP_EXTRA = 2 };
 
@@ -140,11 +143,11 @@ double o_log(double x) {
     const double dk = (double)k;
     const double z = s * s;
     const double w = z * z;
-    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double t1 = w * std::fma(w, std::fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * std::fma(w, std::fma(w, std::fma(w, Lg7, Lg5), Lg3), Lg1);
     const double R = t2 + t1;
     const double hfsq = (0.5 * f) * f;
-    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+    return dk * LN2_HI - ((hfsq - std::fma(s, hfsq + R, dk * LN2_LO)) - f);
 }
 
 // sin(2*pi*u), cos(2*pi*u) for u in [0,1)
@@ -164,15 +167,18 @@ void o_sincos2pi(double u, double* sn, double* cs) {
     const double a = r * PIO2_HI;
     const double al = std::fma(r, PIO2_HI, -a) + r * PIO2_LO;
     const double z = a * a;
-    // sine kernel
+    // sine kernel (fdlibm k_sin polynomial as an fma Horner chain)
     const double v = z * a;
-    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    const double s0 = a - ((z * (0.5 * al - v * rs) - al) - v * S1);
-    // cosine kernel
-    const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double rs = std::fma(z, std::fma(z, std::fma(z, std::fma(z, S6, S5), S4), S3), S2);
+    const double u1 = std::fma(-v, rs, 0.5 * al);
+    const double u2 = std::fma(z, u1, -al);
+    const double u3 = std::fma(-v, S1, u2);
+    const double s0 = a - u3;
+    // cosine kernel (fdlibm k_cos polynomial as an fma Horner chain)
+    const double rc = z * std::fma(z, std::fma(z, std::fma(z, std::fma(z, std::fma(z, C6, C5), C4), C3), C2), C1);
     const double hz = 0.5 * z;
     const double wv = 1.0 - hz;
-    const double c0 = wv + (((1.0 - wv) - hz) + (z * rc - a * al));
+    const double c0 = wv + (((1.0 - wv) - hz) + std::fma(z, rc, -(a * al)));
     switch (q & 3) {
         case 0: *sn = s0;  *cs = c0;  break;
         case 1: *sn = c0;  *cs = -s0; break;

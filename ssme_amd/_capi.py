@@ -53,6 +53,13 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise OSError(f"{SO_PATH} not built: run `python -m ssme_amd.build` (hipcc --offload-arch=gfx950); "
                           "there is no CPU fallback")
+        # PyTorch-ROCm wheels bundle their own libamdhip64; when this process also uses torch (bench.py, tests),
+        # torch must load its HIP runtime first so that one runtime serves both (the loader then resolves our
+        # libamdhip64.so.7 dependency to the copy already mapped).  C/C++ callers without torch use /opt/rocm's.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(SO_PATH)
         dp, u32p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
         u64p = C.POINTER(C.c_uint64)

@@ -4,9 +4,9 @@
 // rounded sqrt and division) plus integer bit moves, so the same source gives the same bits
 // in device code and in this library's host code (derived model constants).  The operation
 // order is the specification; build with -ffp-contract=off.
-//   exp   : Cody-Waite reduction by ln2 (hi/lo), Taylor degree 13 on |r| <= ln2/2
-//   log   : frexp to [sqrt(1/2), sqrt(2)), s = f/(2+f), degree-7 even polynomial (fdlibm form)
-//   sincos: exact octant reduction of 4u, then the fdlibm sine/cosine kernels on r*pi/2
+//   exp   : Cody-Waite reduction by ln2 (hi/lo), Taylor degree 13 on |r| <= ln2/2 (fma Horner)
+//   log   : frexp to [sqrt(1/2), sqrt(2)), s = f/(2+f), fdlibm's degree-7 even polynomial as fma Horner chains
+//   sincos: exact octant reduction of 4u, then fdlibm's sine/cosine kernel polynomials on r*pi/2 as fma Horner chains
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,6 +30,17 @@ SSME_HD uint64_t d2bits(double d) {
 #endif
 }
 SSME_HD double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// fma(a, b, C) with a compile-time constant addend.  hipcc lowers this Horner step to v_fmac_f64 plus two
+// v_mov_b32 that re-materialise C in the accumulator VGPRs every time; v_fma_f64 takes C from an SGPR pair.
+SSME_HD double dfma_c(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+#else
+    return __builtin_fma(a, b, c);
+#endif
+}
 SSME_HD double dinf() { return bits2d(0x7ff0000000000000ull); }
 SSME_HD double dnan() { return bits2d(0x7ff8000000000000ull); }
 SSME_HD double pow2i(int n) { return bits2d((uint64_t)(n + 1023) << 52); }
@@ -50,9 +61,10 @@ SSME_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, 
     return u32x4{c0, c1, c2, c3};
 }
 
-SSME_HD uint64_t bits53(uint32_t a, uint32_t b) { return ((uint64_t)a << 21) | (uint64_t)(b >> 11); }
-SSME_HD double u01_co(uint32_t a, uint32_t b) { return (double)bits53(a, b) * 0x1.0p-53; }        // [0,1)
-SSME_HD double u01_oc(uint32_t a, uint32_t b) { return (double)(bits53(a, b) + 1) * 0x1.0p-53; }  // (0,1]
+// 52 random bits (the top 52 of the 64-bit word a:b) as the mantissa of a double in [1,2)
+SSME_HD double u12(uint32_t a, uint32_t b) { return bits2d(0x3ff0000000000000ull | ((((uint64_t)a << 32) | b) >> 12)); }
+SSME_HD double u01_co(uint32_t a, uint32_t b) { return u12(a, b) - 1.0; }    // [0,1)   multiples of 2^-52
+SSME_HD double u01_oc(uint32_t a, uint32_t b) { return 2.0 - u12(a, b); }    // (0,1]
 
 enum { STREAM_PROP = 0, STREAM_RESAMP = 1, STREAM_RESAMP_EXTRA = 2, STREAM_GAMMA = 16 };
 
@@ -68,22 +80,22 @@ SSME_HD double dexp_scaled(double x, int sc) {
     const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
     const double SH = 6755399441055744.0;  // 1.5 * 2^52
     const double xc = dminnum(dmaxnum(x, -746.0), 710.0);
-    const double kf = dfma(xc, LOG2E, SH) - SH;
+    const double kf = dfma_c(xc, LOG2E, SH) - SH;
     const int k = (int)kf;
     double r = dfma(-kf, LN2_HI, xc);
     r = dfma(-kf, LN2_LO, r);
     double q = 1.6059043836821613e-10;
-    q = dfma(q, r, 2.08767569878681e-09);
-    q = dfma(q, r, 2.505210838544172e-08);
-    q = dfma(q, r, 2.755731922398589e-07);
-    q = dfma(q, r, 2.7557319223985893e-06);
-    q = dfma(q, r, 2.48015873015873e-05);
-    q = dfma(q, r, 0.0001984126984126984);
-    q = dfma(q, r, 0.001388888888888889);
-    q = dfma(q, r, 0.008333333333333333);
-    q = dfma(q, r, 0.041666666666666664);
-    q = dfma(q, r, 0.16666666666666666);
-    q = dfma(q, r, 0.5);
+    q = dfma_c(q, r, 2.08767569878681e-09);
+    q = dfma_c(q, r, 2.505210838544172e-08);
+    q = dfma_c(q, r, 2.755731922398589e-07);
+    q = dfma_c(q, r, 2.7557319223985893e-06);
+    q = dfma_c(q, r, 2.48015873015873e-05);
+    q = dfma_c(q, r, 0.0001984126984126984);
+    q = dfma_c(q, r, 0.001388888888888889);
+    q = dfma_c(q, r, 0.008333333333333333);
+    q = dfma_c(q, r, 0.041666666666666664);
+    q = dfma_c(q, r, 0.16666666666666666);
+    q = dfma_c(q, r, 0.5);
     const double e = dfma(r * r, q, r);
     const double p = 1.0 + e;
     return dldexp(p, k + sc);
@@ -114,11 +126,11 @@ SSME_HD double dlog_core(double x, int kadj) {
     const double dk = (double)k;
     const double z = s * s;
     const double w = z * z;
-    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double t1 = w * dfma_c(w, dfma_c(w, Lg6, Lg4), Lg2);
+    const double t2 = z * dfma_c(w, dfma_c(w, dfma_c(w, Lg7, Lg5), Lg3), Lg1);
     const double R = t2 + t1;
     const double hfsq = (0.5 * f) * f;
-    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+    return dk * LN2_HI - ((hfsq - dfma(s, hfsq + R, dk * LN2_LO)) - f);
 }
 
 // positive normal inputs only: every uniform in (0,1] and every Gamma-test argument is one
@@ -154,12 +166,15 @@ SSME_HD void dsincos2pi(double u, double* sn, double* cs) {
     const double al = dfma(r, PIO2_HI, -a) + r * PIO2_LO;
     const double z = a * a;
     const double v = z * a;
-    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    const double s0 = a - ((z * (0.5 * al - v * rs) - al) - v * S1);
-    const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double rs = dfma_c(z, dfma_c(z, dfma_c(z, dfma_c(z, S6, S5), S4), S3), S2);
+    const double u1 = dfma(-v, rs, 0.5 * al);
+    const double u2 = dfma(z, u1, -al);
+    const double u3 = dfma(-v, S1, u2);
+    const double s0 = a - u3;
+    const double rc = z * dfma_c(z, dfma_c(z, dfma_c(z, dfma_c(z, dfma_c(z, C6, C5), C4), C3), C2), C1);
     const double hz = 0.5 * z;
     const double wv = 1.0 - hz;
-    const double c0 = wv + (((1.0 - wv) - hz) + (z * rc - a * al));
+    const double c0 = wv + (((1.0 - wv) - hz) + dfma(z, rc, -(a * al)));
     const int qq = q & 3;
     const double ss = (qq & 1) ? c0 : s0;
     const double cc = (qq & 1) ? s0 : c0;

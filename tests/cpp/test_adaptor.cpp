@@ -1,0 +1,53 @@
+// Compiles the header-only adaptor against stand-ins for the reference's Eigen-based types (Eigen is absent
+// here) and drives it like the reference's callers: estimate_univ_svol.h:119-127, pswarm_filter.h:380-388.
+// Prints the log-likelihoods; tests/test_cpp_adaptor.py compares them with the oracle.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <vector>
+
+#include "../../include/ssme_gpu/bsfilter_gpu.hpp"
+
+struct vec1 {                          // stand-in for Eigen::Matrix<double,1,1>
+    double v;
+    double operator()(int) const { return v; }
+};
+struct pack3 {                         // stand-in for param::pack<double,3>::get_untrans_params(i,i)
+    double p[3];
+    vec1 get_untrans_params(unsigned a, unsigned) const { return vec1{p[a]}; }
+};
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    std::vector<vec1> data;
+    std::ifstream f(argv[1]);
+    double v;
+    while (f >> v && data.size() < 64) data.push_back(vec1{v});
+    ssme_gpu::gpu_options o;
+    o.seed = 77;
+    // (1) the log_like_eval loop with the model object (estimate_univ_svol.h:119-127)
+    pack3 theta{{1.0, 0.95, 0.0625}};                    // beta, phi, ss
+    ssme_gpu::svol_bs_gpu<500, double> mod(theta, o);
+    double logLike = 0.0;
+    for (size_t row = 0; row < data.size(); ++row) {
+        mod.filter(data[row]);
+        logLike += mod.getLogCondLike();
+    }
+    std::printf("svol_bs %.17g\n", logLike);
+    // (2) replicate-batched evaluation
+    std::printf("log_like_eval_gpu %.17g\n", ssme_gpu::log_like_eval_gpu(theta, data, 500, 4, o));
+    // (3) covariate model as Swarm::comp_func calls it (pswarm_filter.h:380-388)
+    ssme_gpu::svol_leverage_gpu<1000> lev(0.9, 0.0, 1.0, -0.1, 0, o, 3), lev2;
+    lev2 = lev;                                          // copy-assignable, default-constructible
+    double ll = 0.0;
+    for (size_t row = 0; row < 8; ++row) {
+        lev2.filter(data[row], vec1{row ? data[row - 1].v : 0.0}, {SSME_H_CONST42, SSME_H_X});
+        ll += lev2.getLogCondLike();
+    }
+    std::printf("svol_leverage %.17g\n", ll);
+    std::printf("expect42 %.17g\n", lev2.getExpectations()[0]);
+    // (4) error mapping
+    try { std::vector<vec1> empty; ssme_gpu::log_like_eval_gpu(theta, empty, 100, 1, o); std::printf("no-throw\n"); }
+    catch (const std::length_error&) { std::printf("length_error ok\n"); }
+    return 0;
+}

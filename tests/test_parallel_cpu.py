@@ -1,0 +1,72 @@
+"""CPU suite: the N > 1 host path (sharding of independent filters + one all_gather) on gloo, world_size 2."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_filters_partition():
+    from ssme_amd.parallel import shard_filters
+    for n in (0, 1, 7, 8, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            ids = []
+            for r in range(world):
+                first, cnt = shard_filters(n, world, r)
+                ids += list(range(first, first + cnt))
+            assert ids == list(range(n))
+            sizes = [shard_filters(n, world, r)[1] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_filters(4096, 8, 3) == (1536, 512)      # BASELINE.json configs[3]: 512 filters per GPU
+    with pytest.raises(ValueError):
+        shard_filters(4, 2, 2)
+
+
+def test_log_mean_exp_matches_reference_kat():
+    from ssme_amd.parallel import log_mean_exp
+    assert abs(log_mean_exp(np.full(10000, 3.0)) - 3.0) < 1e-3     # test/test_thread_pool.cpp:39-46
+    assert np.isnan(log_mean_exp([1.0, np.nan]))
+    assert log_mean_exp([-np.inf, -np.inf]) == -np.inf
+
+
+def _worker(rank, world, port, n_filters, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from ssme_amd.parallel import gather_logliks, log_mean_exp, max_over_ranks, shard_filters
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, cnt = shard_filters(n_filters, world, rank)
+    local = -100.0 - 0.25 * np.arange(first, first + cnt)        # stand-in for this rank's filter log-likelihoods
+    allv = gather_logliks(local, n_filters)
+    tmax = max_over_ranks(1.0 + rank)
+    q.put((rank, allv.tolist(), log_mean_exp(allv), tmax))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_filters", [2, 5])
+def test_gather_logliks_gloo_world2(n_filters):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_filters, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = (-100.0 - 0.25 * np.arange(n_filters)).tolist()
+    from ssme_amd.parallel import log_mean_exp
+    for rank, allv, lme, tmax in res:
+        assert allv == expect                       # every rank sees all filters, in filter-id order
+        assert lme == log_mean_exp(expect)
+        assert tmax == 2.0                          # MAX over ranks, as bench.py does for the timing

@@ -28,3 +28,17 @@ for k in order[1:]:
     d = (s[:, k] - s[:, prev]) / 100.0
     print(f"  {names[k]:28s} mean {d.mean():6.2f} us  max {d.max():6.2f}   (ends at mean {((s[:, k] - t0) / 100).mean():6.2f} us)")
     prev = k
+
+dur = (s[:, 11] - s[:, 0]) / 100.0
+print("block duration percentiles (us): ", {p: round(float(np.percentile(dur, p)), 2) for p in (0, 10, 50, 90, 99, 100)})
+endt = (s[:, 11] - t0) / 100.0
+print("block end-time percentiles (us): ", {p: round(float(np.percentile(endt, p)), 2) for p in (0, 10, 50, 90, 99, 100)})
+# slowest blocks: which phases are slow?
+idx = np.argsort(dur)[-8:]
+prev = 0
+print("slowest 8 blocks, per-phase us:")
+for k in order[1:]:
+    d = (s[idx, k] - s[idx, prev]) / 100.0
+    print(f"  {names[k]:28s}", np.round(d, 2))
+    prev = k
+print("  block ids", idx)
