@@ -116,13 +116,13 @@ int ssme_pf_log_mean_exp(ssme_pf_handle h, double* out);
 /* Parity/debug: state of one filter after the last step.  Any pointer may be NULL.
  * x: N pre-resampling particles; logw: their log-weights (only kept in memory after
  * set_debug(flags & 2), or when resamp_sched > 1); cdf: N tile-local inclusive sums of the
- * fixed-point weights q_i = rne(exp(logw_i - max_tile) * 2^51) (exact uint64 arithmetic);
+ * fixed-point weights q_i = rne(exp(logw_i - max_tile) * 2^41) (exact integers < 2^53, carried in fp64 on the device);
  * ancestors: N indices used by the last step (requires set_debug(flags & 1)). */
 int ssme_pf_download_state(ssme_pf_handle h, int32_t filter, double* x, double* logw, uint64_t* cdf,
                            uint32_t* ancestors);
 /* max_logw: max log-weight of the last step; sum_q: exact integer sum of the rescaled tile sums;
  * tile_sums / tile_max: one integer weight sum and one max log-weight per 2048-particle tile;
- * rshift: the fixed-point exponent rg = 62 - ceil(log2(Npad)) of sum_q. */
+ * rshift: the fixed-point exponent rg = 52 - ceil(log2(Npad)) of sum_q. */
 int ssme_pf_download_scalars(ssme_pf_handle h, int32_t filter, double* max_logw, uint64_t* sum_q,
                              uint64_t* tile_sums, double* tile_max, int32_t* rshift);
 /* flags: bit 0 = record ancestor indices, bit 1 = keep log-weights in memory (parity tests). */
@@ -154,7 +154,7 @@ int ssme_pf_test_quantize(int32_t device, const double* in, int32_t shift, uint6
 /* out = rint((double)tile_sum * exp(dm) * 2^shift): the cross-tile rescaling of tile sums */
 int ssme_pf_test_rescale(int32_t device, const uint64_t* tile_sums, const double* dm, int32_t shift, uint64_t* out,
                          int64_t n);
-/* exact inclusive scan of 2048 uint64 values by one block of 256/512/1024 threads (DPP wave scans) */
+/* exact inclusive scan of 2048 integers (< 2^53 in total) by one block of 256/512/1024 threads (fp64 DPP wave scans) */
 int ssme_pf_test_block_scan(int32_t device, int32_t threads, const uint64_t* in2048, uint64_t* incl2048,
                             uint64_t* total);
 /* measurement aid: `repeats` streaming copies of n doubles with 16-byte-per-lane accesses (counter calibration) */

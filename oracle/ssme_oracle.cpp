@@ -268,11 +268,12 @@ inline double m_logg(const ModelConst& c, double y, double x) {
 
 // ---------------------------------------------------------------------------------------
 // Exact fixed-point weight cdf with per-tile scales.
-//   tile b (2048 particles):  m_b = max logw,  q_i = rne( exp(logw_i - m_b) * 2^51 )
+//   tile b (2048 particles):  m_b = max logw,  q_i = rne( exp(logw_i - m_b) * 2^41 )
 //                             loc_j = sum_{i<=j in tile} q_i      (uint64, EXACT, monotone)
 //                             A_b   = loc_last
-//   across tiles:             m = max_b m_b,  A'_b = rint( (double)A_b * exp(m_b - m) * 2^(rg-51) ),
-//                             rg = 62 - ceil(log2(Npad)),  T'_b = sum_{c<=b} A'_c (exact),  S' = T'_last
+//   across tiles:             m = max_b m_b,  A'_b = rint( A_b * exp(m_b - m) * 2^(rg-41) ),
+//                             rg = 52 - ceil(log2(Npad)),  T'_b = sum_{c<=b} A'_c (exact),  S' = T'_last
+//   every integer stays below 2^53, so the device carries them EXACTLY in fp64 registers
 //   log-sum-exp:              m + log(S' * 2^-rg)
 //   ancestor of target tau in [0, S']:
 //       b* = min(#{b : T'_b < tau}, B-1);  d = tau - (T'_b* - A'_b*)
@@ -283,14 +284,14 @@ inline double m_logg(const ModelConst& c, double y, double x) {
 // device runs ONE kernel per filter step.
 // ---------------------------------------------------------------------------------------
 constexpr int TILE = 2048;
-constexpr int TILE_SHIFT = 51;                // tile-local fixed point: q <= 2^51, tile sums <= 2^62
-constexpr int E_SHIFT = 45;                   // exponential spacings: qE = round(E * 2^45)
+constexpr int TILE_SHIFT = 41;                // tile-local fixed point: q <= 2^41, tile sums <= 2^52 (exact in fp64)
+constexpr int E_SHIFT = 35;                   // exponential spacings: qE = round(E * 2^35)
 constexpr double TWO52 = 4503599627370496.0;
 constexpr uint64_t MASK52 = (1ull << 52) - 1;
 
 inline int ceil_log2(int n) { int k = 0; while ((1ll << k) < n) ++k; return k; }
 // round-to-nearest-even of v in [0, 2^52) via the 2^52 trick (same two ops on the device)
-inline uint64_t rne_u64(double v) { return double_to_bits(v + TWO52) & MASK52; }
+inline uint64_t rne_u64(double v) { return (uint64_t)std::rint(v); }     // v in [0, 2^52): integer-valued double
 inline uint64_t tau_to_u64(double tau) {
     double c = std::ceil(tau);
     c = std::fmin(std::fmax(c, 0.0), 9.2e18);          // NaN -> 0
@@ -326,7 +327,7 @@ struct Filter {
         key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32); rep = rep_;
         mc = derive(model, th);
         B = (N + TILE - 1) / TILE; Npad = B * TILE;
-        rshift = 62 - ceil_log2(Npad);
+        rshift = 52 - ceil_log2(Npad);
         x.assign(Npad, 0.0); xprev.assign(Npad, 0.0); logw.assign(Npad, 0.0); loc.assign(Npad, 0);
         A.assign(B, 0); Ap.assign(B, 0); Tincl.assign(B, 0); mb.assign(B, 0.0);
         anc.assign(Npad, 0u);
@@ -403,7 +404,7 @@ struct Filter {
                 for (int j = 0; j < nb; ++j) {
                     uint32_t wa, wb; resamp_words(b * TILE + j, tt, &wa, &wb);
                     const double E = -o_log(u01_oc(wa, wb));
-                    s += double_to_bits(std::fma(E, 35184372088832.0 /* 2^45 */, TWO52)) & MASK52;
+                    s += (uint64_t)std::rint(E * 34359738368.0 /* 2^35 */);
                     locE[j] = s;
                 }
                 const double ratio = gam[b] / (double)s;

@@ -28,8 +28,8 @@ struct ssme_pf_s {
     float last_ms;
     // device state; [2] = ping-pong (step t reads cur, writes cur ^ 1)
     double* x[2];
-    u64* cdf[2];
-    u64* tsum[2];
+    double* cdf[2];          // integer-valued doubles (< 2^53)
+    double* tsum[2];
     double* tmax[2];
     double *logw, *ybuf, *zbuf, *per_step, *scratchR;
     double *gam, *pgam, *gtot;   // Gamma tables of the multinomial resampler, gcap time rows
@@ -260,8 +260,8 @@ int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) {
     h->cfg = *cfg;
     h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * kTile;
     h->Bs = (B + 1) & ~1; h->Bpow2 = next_pow2(B);
-    h->rshift = 62 - ceil_log2(h->Npad);
-    h->lds_bytes = sizeof(u64) * (2 * (size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2) + (size_t)kStageTiles * kTile);
+    h->rshift = 52 - ceil_log2(h->Npad);
+    h->lds_bytes = sizeof(double) * (2 * (size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2) + (size_t)kStageTiles * kTile);
     h->graph_mode = 1;
     h->nt = 512;
     hipError_t e = hipSetDevice(cfg->device);
@@ -273,12 +273,12 @@ int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) {
         const size_t np = (size_t)h->R * h->Npad, nb = (size_t)h->R * h->Bs;
         for (int i = 0; i < 2; ++i) {
             HIPCHK(hipMalloc(&h->x[i], sizeof(double) * np));
-            HIPCHK(hipMalloc(&h->cdf[i], sizeof(u64) * np));
-            HIPCHK(hipMalloc(&h->tsum[i], sizeof(u64) * nb));
+            HIPCHK(hipMalloc(&h->cdf[i], sizeof(double) * np));
+            HIPCHK(hipMalloc(&h->tsum[i], sizeof(double) * nb));
             HIPCHK(hipMalloc(&h->tmax[i], sizeof(double) * nb));
             HIPCHK(hipMemset(h->x[i], 0, sizeof(double) * np));
-            HIPCHK(hipMemset(h->cdf[i], 0, sizeof(u64) * np));
-            HIPCHK(hipMemset(h->tsum[i], 0, sizeof(u64) * nb));
+            HIPCHK(hipMemset(h->cdf[i], 0, sizeof(double) * np));
+            HIPCHK(hipMemset(h->tsum[i], 0, sizeof(double) * nb));
             HIPCHK(hipMemset(h->tmax[i], 0, sizeof(double) * nb));
         }
         HIPCHK(set_lds<MODEL_SVOL>(h->lds_bytes));
@@ -487,12 +487,16 @@ int ssme_pf_download_state(ssme_pf_handle h, int32_t f, double* x, double* logw,
         if (!h->logw || !logw_needed(h)) return SSME_ERR_STATE;      // set_debug(2) before stepping
         HIPCHK(hipMemcpyAsync(logw, h->logw + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
     }
-    if (cdf) HIPCHK(hipMemcpyAsync(cdf, h->cdf[h->cur] + off, sizeof(u64) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (cdf) HIPCHK(hipMemcpyAsync(cdf, h->cdf[h->cur] + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
     if (anc) {
         if (!h->anc) return SSME_ERR_STATE;
         HIPCHK(hipMemcpyAsync(anc, h->anc + off, sizeof(uint32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (cdf) {   // the device holds the integers in fp64 registers/memory; hand them out as integers
+        double dv;
+        for (int i = 0; i < h->N; ++i) { std::memcpy(&dv, &cdf[i], 8); cdf[i] = (uint64_t)dv; }
+    }
     return SSME_OK;
 }
 
@@ -502,13 +506,14 @@ int ssme_pf_download_scalars(ssme_pf_handle h, int32_t f, double* max_logw, uint
     HIPCHK(hipSetDevice(h->cfg.device));
     FilterScalars sc;
     HIPCHK(hipMemcpyAsync(&sc, h->scal + f, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
-    if (tile_sums) HIPCHK(hipMemcpyAsync(tile_sums, h->tsum[h->cur] + (size_t)f * h->Bs, sizeof(u64) * h->B,
+    if (tile_sums) HIPCHK(hipMemcpyAsync(tile_sums, h->tsum[h->cur] + (size_t)f * h->Bs, sizeof(double) * h->B,
                                          hipMemcpyDeviceToHost, h->stream));
     if (tile_max) HIPCHK(hipMemcpyAsync(tile_max, h->tmax[h->cur] + (size_t)f * h->Bs, sizeof(double) * h->B,
                                         hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (tile_sums) { double dv; for (int i = 0; i < h->B; ++i) { std::memcpy(&dv, &tile_sums[i], 8); tile_sums[i] = (uint64_t)dv; } }
     if (max_logw) *max_logw = sc.m;
-    if (sum_q) *sum_q = sc.S;
+    if (sum_q) *sum_q = (sc.S == sc.S && sc.S > 0.0) ? (uint64_t)sc.S : 0;
     if (rshift) *rshift = h->rshift;
     return SSME_OK;
 }
@@ -583,22 +588,22 @@ __global__ void k_test_philox(const uint32_t* ctr, const uint32_t* key, uint32_t
 }
 __global__ void k_test_quantize(const double* in, int shift, u64* out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = rne_u52(dexp_scaled(in[i], shift));
+    if (i < n) out[i] = (u64)__builtin_rint(dexp_scaled(in[i], shift));
 }
 __global__ void k_test_rescale(const u64* A, const double* dm, int shift, u64* out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = rint_to_u64((double)A[i] * dexp_scaled(dm[i], shift));
+    if (i < n) out[i] = (u64)__builtin_rint((double)A[i] * dexp_scaled(dm[i], shift));
 }
 template <int NT>
 __global__ __launch_bounds__(NT) void k_test_block_scan(const u64* in, u64* incl, u64* total) {
-    __shared__ u64 lds_seg[16];
+    __shared__ double lds_seg[16];
     constexpr int NK = 1024 / NT;
     const int tid = threadIdx.x;
-    u64 q[NK][2], inc[NK][2], tot;
-    for (int k = 0; k < NK; ++k) { q[k][0] = in[(k * NT + tid) * 2]; q[k][1] = in[(k * NT + tid) * 2 + 1]; }
-    block_scan_u64<NT>(q, inc, tot, lds_seg);
-    for (int k = 0; k < NK; ++k) { incl[(k * NT + tid) * 2] = inc[k][0]; incl[(k * NT + tid) * 2 + 1] = inc[k][1]; }
-    if (tid == 0) *total = tot;
+    double q[NK][2], inc[NK][2], tot;
+    for (int k = 0; k < NK; ++k) { q[k][0] = (double)in[(k * NT + tid) * 2]; q[k][1] = (double)in[(k * NT + tid) * 2 + 1]; }
+    block_scan_f64<NT>(q, inc, tot, lds_seg);
+    for (int k = 0; k < NK; ++k) { incl[(k * NT + tid) * 2] = (u64)inc[k][0]; incl[(k * NT + tid) * 2 + 1] = (u64)inc[k][1]; }
+    if (tid == 0) *total = (u64)tot;
 }
 // streaming copy with the step kernel's access shape (16 B per lane): calibrates FETCH_SIZE / WRITE_SIZE
 __global__ __launch_bounds__(512) void k_calib_copy(const double* in, double* out, long n2) {

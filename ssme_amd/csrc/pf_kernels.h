@@ -9,15 +9,16 @@
 //   tile max, q = rne(exp(logw - max_tile) 2^51), exact integer tile scan  twin :96-104
 // It replaces pf::BSFilter::filter (call site example/estimate_univ_svol.h:124).
 //
-// Particles are a structure of arrays in HBM: x[R][Npad] (fp64, ping-pong), cdf[R][Npad] (uint64
-// fixed point, ping-pong), per-tile sums/maxima; one row per filter.  A tile is 2048 consecutive
+// Particles are a structure of arrays in HBM: x[R][Npad] (fp64, ping-pong), cdf[R][Npad] (fixed point:
+// integers < 2^53 held exactly in fp64, ping-pong), per-tile sums/maxima; one row per filter.  A tile is 2048 consecutive
 // particles = NT threads x (1024/NT) pairs, so every streaming access is one 16-byte load/store
 // per lane, fully coalesced.  Log-weights never leave registers (unless resampling is not every
 // step, or in debug mode).
 //
-// The weight cdf is EXACT integer arithmetic: sums are associative, the
-// cdf is monotone by construction and the ancestor of a target is an integer count --
-// independent of scan tree, search strategy and block shape.
+// The weight cdf is EXACT integer arithmetic: every value is an integer below
+// 2^53 carried in an fp64 register, so v_add_f64 adds exactly; sums are associative, the cdf is
+// monotone by construction and the ancestor of a target is an integer count -- independent of scan
+// tree, search strategy and block shape.
 #pragma once
 #include "ssme_math.h"
 
@@ -31,8 +32,8 @@ constexpr int kRow = 512;
 constexpr int kTile = 2048;
 constexpr int kMaxTilesPerFilter = 2048;   // level-2 scan reuses the 2048-wide block scan
 constexpr int kStageTiles = 3;             // cdf tiles staged in LDS per output tile
-constexpr int kEShift = 45;                // exponential spacings: qE = rne(E * 2^45)
-constexpr int kTileShift = 51;             // tile-local fixed point: q = rne(exp(logw - m_tile) * 2^51)
+constexpr int kEShift = 35;                // exponential spacings: qE = rne(E * 2^35)
+constexpr int kTileShift = 41;             // tile-local fixed point: q = rne(exp(logw - m_tile) * 2^41), tile sums <= 2^52
 
 enum { MODEL_SVOL = 0, MODEL_SVOL_LEVERAGE = 1, MODEL_LIN_GAUSS = 2 };
 enum { RESAMP_MULTINOMIAL = 0, RESAMP_SYSTEMATIC = 1, RESAMP_STRATIFIED = 2, RESAMP_MULTINOMIAL_IID = 3 };
@@ -58,7 +59,7 @@ struct ModelConst {
 // Per-filter scalars living in device memory.
 struct FilterScalars {
     double m;        // max log-weight of the last step (NaN if any log-weight is NaN)
-    u64 S;           // exact integer sum of the quantised weights of the last step
+    double S;        // exact integer sum of the rescaled tile sums of the last step
     double prev;     // m_old + log S_old (log N after a resampling step)
     double loglik;   // running sum of log p(y_t | y_{1:t-1})
     double last_ll;  // last log conditional likelihood
@@ -69,10 +70,10 @@ struct StepArgs {
     const double* x_in;        // [R][Npad] particles of step t-1 (pre-resampling)
     double* x_out;             // [R][Npad]
     double* logw;              // [R][Npad] or null: only kept when resampling is not every step, or in debug mode
-    const u64* cdf_in;         // [R][Npad] tile-local inclusive integer sums of q, step t-1
-    u64* cdf_out;              // [R][Npad] step t
-    const u64* tsum_in;        // [R][Bs] tile sums A_b (tile scale), step t-1
-    u64* tsum_out;
+    const double* cdf_in;      // [R][Npad] tile-local inclusive integer sums of q, step t-1
+    double* cdf_out;           // [R][Npad] step t
+    const double* tsum_in;     // [R][Bs] tile sums A_b (tile scale), step t-1
+    double* tsum_out;
     const double* tmax_in;     // [R][Bs] tile maxima m_b, step t-1
     double* tmax_out;
     uint32_t* anc;             // [R][Npad] or null
@@ -111,6 +112,31 @@ __device__ __forceinline__ double dpp_f64_neginf(double v) {    // fill = -inf
     const int hi = __builtin_amdgcn_update_dpp((int)0xfff00000, (int)(uint32_t)(b >> 32), CTRL, ROWMASK, 0xF, false);
     return bits2d(((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo);
 }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64_zero(double v) {      // fill = +0.0
+    const u64 b = d2bits(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROWMASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROWMASK, 0xF, false);
+    return bits2d(((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo);
+}
+// inclusive wave scan of integer-valued doubles (exact while every partial sum < 2^53)
+__device__ __forceinline__ double wave_incl_scan_f64(double v) {
+    v = v + dpp_f64_zero<0x111, 0xF>(v);
+    v = v + dpp_f64_zero<0x112, 0xF>(v);
+    v = v + dpp_f64_zero<0x114, 0xF>(v);
+    v = v + dpp_f64_zero<0x118, 0xF>(v);
+    v = v + dpp_f64_zero<0x142, 0xA>(v);
+    v = v + dpp_f64_zero<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ double wave_shr1_f64(double v) { return dpp_f64_zero<0x138, 0xF>(v); }
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const u64 b = d2bits(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+    return bits2d(((u64)hi << 32) | lo);
+}
+
 // row_shr:n = 0x110+n ; row_bcast:15 = 0x142 ; row_bcast:31 = 0x143 ; wave_shr:1 = 0x138
 __device__ __forceinline__ u64 wave_incl_scan_u64(u64 v) {
     v += dpp_u64<0x111, 0xF>(v);
@@ -188,6 +214,39 @@ __device__ __forceinline__ void block_scan_u64(const u64 (&q)[1024 / NT][2], u64
         const int seg = k * WPR + wave;
         const u64 pre = seg ? readlane_u64(sv, seg - 1) : 0ull;
         const u64 base = pre + exc[k];
+        incl[k][0] = base + s0[k];
+        incl[k][1] = base + s1[k];
+    }
+}
+
+// The same for integer-valued doubles (every partial sum < 2^53, so each v_add_f64 is exact).
+template <int NT>
+__device__ __forceinline__ void block_scan_f64(const double (&q)[1024 / NT][2], double (&incl)[1024 / NT][2], double& total,
+                                               double* lds_seg) {
+    constexpr int NK = 1024 / NT, WPR = NT / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double s0[NK], s1[NK], exc[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        s0[k] = q[k][0];
+        s1[k] = s0[k] + q[k][1];
+        const double inc = wave_incl_scan_f64(s1[k]);
+        exc[k] = wave_shr1_f64(inc);
+        if (lane == 63) lds_seg[k * WPR + wave] = inc;
+    }
+    __syncthreads();
+    double sv = lds_seg[lane & 15];
+    sv = sv + dpp_f64_zero<0x111, 0xF>(sv);
+    sv = sv + dpp_f64_zero<0x112, 0xF>(sv);
+    sv = sv + dpp_f64_zero<0x114, 0xF>(sv);
+    sv = sv + dpp_f64_zero<0x118, 0xF>(sv);
+    total = readlane_f64(sv, 15);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int seg = k * WPR + wave;
+        const double pre = seg ? readlane_f64(sv, seg - 1) : 0.0;
+        const double base = pre + exc[k];
         incl[k][0] = base + s0[k];
         incl[k][1] = base + s1[k];
     }
@@ -273,15 +332,9 @@ __device__ __forceinline__ double gamma_draw(uint32_t b, uint32_t t, uint32_t re
     return d;
 }
 
-__device__ __forceinline__ u64 tau_to_u64(double tau) {
-    double c = __builtin_ceil(tau);
-    c = dminnum(dmaxnum(c, 0.0), 9.2e18);    // NaN -> 0
-    return (u64)c;
-}
-
-// #{ j < n : get(j) < target } for monotone get, n = 2^k
+// #{ j < n : get(j) < target } for monotone get, n = 2^k (a NaN target counts nothing)
 template <class F>
-__device__ __forceinline__ int count_less_pow2(int n, u64 target, F get) {
+__device__ __forceinline__ int count_less_pow2(int n, double target, F get) {
     int pos = 0;
     for (int step = n >> 1; step >= 1; step >>= 1)
         if (get(pos + step - 1) < target) pos += step;
@@ -289,14 +342,8 @@ __device__ __forceinline__ int count_less_pow2(int n, u64 target, F get) {
     return pos;
 }
 
-__device__ __forceinline__ u64 rint_to_u64(double v) {
-    double c = __builtin_rint(v);
-    c = dminnum(dmaxnum(c, 0.0), 9.2e18);    // NaN -> 0
-    return (u64)c;
-}
-
 // gallop: #{ j < 2048 : tile[j] < target } given that every index < lo already is (lo <= count)
-__device__ __forceinline__ int count_less_gallop(const u64* tile, u64 target, int lo) {
+__device__ __forceinline__ int count_less_gallop(const double* tile, double target, int lo) {
     int w = 1;
     while (lo + w <= kTile && tile[lo + w - 1] < target) { lo += w; w <<= 1; }
     for (w >>= 1; w >= 1; w >>= 1)
@@ -305,28 +352,28 @@ __device__ __forceinline__ int count_less_gallop(const u64* tile, u64 target, in
 }
 
 // Level-2 of one filter: global max m over the tile maxima (NaN propagating), rescaled integer
-// tile sums A'_b = rint(A_b exp(m_b - m) 2^(rg-51)), their exact inclusive scan.  Thread tid holds
+// tile sums A'_b = rint(A_b exp(m_b - m) 2^(rg-41)), their exact inclusive scan.  Thread tid holds
 // entries j = (k*NT + tid)*2 + c; rows and waves without live entries (j >= B) skip the arithmetic.
 // Two barriers.  lds_d: NT/64 doubles, lds_seg: 16 u64.
 template <int NT>
-__device__ __forceinline__ void level2_load(const u64* ts, const double* tm, int B, u64 (&A)[1024 / NT][2],
+__device__ __forceinline__ void level2_load(const double* ts, const double* tm, int B, double (&A)[1024 / NT][2],
                                             double (&mb)[1024 / NT][2]) {
     constexpr int NK = 1024 / NT;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int j = (k * NT + threadIdx.x) * 2;
         if (j < B) {       // Bs is even: j+1 < Bs
-            const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(ts + j);
+            const double2 t2 = *reinterpret_cast<const double2*>(ts + j);
             const double2 m2 = *reinterpret_cast<const double2*>(tm + j);
             A[k][0] = t2.x; A[k][1] = t2.y; mb[k][0] = m2.x; mb[k][1] = m2.y;
-        } else { A[k][0] = 0; A[k][1] = 0; mb[k][0] = 0.0; mb[k][1] = 0.0; }
+        } else { A[k][0] = 0.0; A[k][1] = 0.0; mb[k][0] = 0.0; mb[k][1] = 0.0; }
     }
 }
 
 template <int NT>
-__device__ __forceinline__ void level2_scan(const u64 (&A)[1024 / NT][2], const double (&mb)[1024 / NT][2], int B, int rshift,
-                                            double& m, u64 (&Ap)[1024 / NT][2], u64 (&Tinc)[1024 / NT][2], u64& S,
-                                            double* lds_d, u64* lds_seg) {
+__device__ __forceinline__ void level2_scan(const double (&A)[1024 / NT][2], const double (&mb)[1024 / NT][2], int B, int rshift,
+                                            double& m, double (&Ap)[1024 / NT][2], double (&Tinc)[1024 / NT][2], double& S,
+                                            double* lds_d, double* lds_seg) {
     constexpr int NK = 1024 / NT;
     const int wave_j0 = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 128);   // first entry of my wave in row 0
     double mx = -dinf();
@@ -344,16 +391,17 @@ __device__ __forceinline__ void level2_scan(const u64 (&A)[1024 / NT][2], const 
     m = block_max_nanprop<NT>(mx, nan, lds_d);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        Ap[k][0] = 0; Ap[k][1] = 0;
+        Ap[k][0] = 0.0; Ap[k][1] = 0.0;
         if (k * NT * 2 + wave_j0 < B) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int j = (k * NT + threadIdx.x) * 2 + c;
-                if (j < B) Ap[k][c] = rint_to_u64((double)A[k][c] * dexp_scaled(mb[k][c] - m, rshift - kTileShift));
+                // NaN (m or m_b NaN) is squashed to 0 by dexp_scaled's clamp: A' = rint(A * 0) = 0
+                if (j < B) Ap[k][c] = __builtin_rint(A[k][c] * dexp_scaled(mb[k][c] - m, rshift - kTileShift));
             }
         }
     }
-    block_scan_u64<NT>(Ap, Tinc, S, lds_seg);
+    block_scan_f64<NT>(Ap, Tinc, S, lds_seg);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -369,12 +417,12 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     constexpr int NK = 1024 / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nT2 = a.Bpow2 < 2 ? 2 : a.Bpow2;
-    u64* lds_T = reinterpret_cast<u64*>(smem);                   // [Bpow2] inclusive prefixes of A'
-    double* lds_R = reinterpret_cast<double*>(lds_T + nT2);      // [Bpow2] A_b / A'_b
-    u64* lds_stage = lds_T + 2 * nT2;                            // [3][2048] staged cdf tiles, 16-byte aligned
-    __shared__ u64 lds_seg_a[16];
-    __shared__ u64 lds_seg_b[16];
-    __shared__ u64 lds_seg_c[16];
+    double* lds_T = reinterpret_cast<double*>(smem);             // [Bpow2] inclusive prefixes of A'
+    double* lds_R = lds_T + nT2;                                 // [Bpow2] A_b / A'_b
+    double* lds_stage = lds_T + 2 * nT2;                         // [3][2048] staged cdf tiles, 16-byte aligned
+    __shared__ double lds_seg_a[16];
+    __shared__ double lds_seg_b[16];
+    __shared__ double lds_seg_c[16];
     __shared__ int lds_cnt[2];
     __shared__ double lds_d1[16];
     __shared__ double lds_d2[16];
@@ -394,8 +442,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 
     STAMP(a, 0);
     // --- issue the level-2 loads first: previous step's tile sums and maxima ---
-    u64 A2[NK][2];
-    double M2[NK][2];
+    double A2[NK][2], M2[NK][2];
     if (need_l2) level2_load<NT>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
     if (tid == 0) { lds_cnt[0] = 0; lds_cnt[1] = 0; }
     double gam = 0.0, pgam = 0.0, pgam_next = 0.0, G = 1.0;
@@ -408,29 +455,29 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 
     STAMP(a, 1);
     // --- level-2: global max, rescaled tile sums A', inclusive prefixes T', total S'; tile range of my targets ---
-    u64 S = 0;
+    double S = 0.0;
     double t_scale = 0.0, u0 = 0.0;
     if (need_l2) {
-        u64 Ap[NK][2], Tinc[NK][2];
+        double Ap[NK][2], Tinc[NK][2];
         double m;
         level2_scan<NT>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d1, lds_seg_b);
         // bounds [t_lo, t_hi] of this tile's targets, known to every thread without the spacings
-        const double Sd = (double)S;
-        u64 t_lo = 0, t_hi = ~0ull;
+        const double Sd = S;
+        double t_lo = 0.0, t_hi = dinf();
         if (a.resampler == RESAMP_MULTINOMIAL) {
             t_scale = Sd / G;                          // targets: (pgam + Gamma_b E_cum/E_tile) * S'/G  
-            t_lo = tau_to_u64(pgam * t_scale);
-            t_hi = tau_to_u64(pgam_next * t_scale) + (S >> 40) + 2;   // slack covers the rounding of ratio*E_tile vs Gamma_b
+            t_lo = __builtin_ceil(pgam * t_scale);
+            t_hi = __builtin_ceil(pgam_next * t_scale) + (S * 0x1.0p-40 + 2.0);   // slack covers the rounding of ratio*E_tile vs Gamma_b
         } else if (a.resampler == RESAMP_SYSTEMATIC) {
             const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, a.key0, a.key1);
             u0 = u01_co(ox.v0, ox.v1);
             t_scale = Sd / (double)a.N;
-            t_lo = tau_to_u64(((double)i_first + u0) * t_scale);
-            t_hi = tau_to_u64(((double)(i_first + nvalid - 1) + u0) * t_scale);
+            t_lo = __builtin_ceil(((double)i_first + u0) * t_scale);
+            t_hi = __builtin_ceil(((double)(i_first + nvalid - 1) + u0) * t_scale);
         } else {
             t_scale = Sd / (double)a.N;
-            t_lo = tau_to_u64((double)i_first * t_scale);
-            t_hi = tau_to_u64((double)(i_first + nvalid) * t_scale);
+            t_lo = __builtin_ceil((double)i_first * t_scale);
+            t_hi = __builtin_ceil((double)(i_first + nvalid) * t_scale);
         }
         const int wave_j0 = __builtin_amdgcn_readfirstlane((tid >> 6) * 128);
 #pragma unroll
@@ -441,8 +488,8 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                 for (int c = 0; c < 2; ++c) {
                     const int j = (k * NT + tid) * 2 + c;
                     if (j < a.Bpow2) {
-                        lds_T[j] = (j < a.B) ? Tinc[k][c] : ~0ull;
-                        lds_R[j] = (j < a.B) ? (double)A2[k][c] / (double)Ap[k][c] : 0.0;
+                        lds_T[j] = (j < a.B) ? Tinc[k][c] : dinf();
+                        lds_R[j] = (j < a.B) ? A2[k][c] / Ap[k][c] : 0.0;
                     }
                     c_lo += (j < a.B && Tinc[k][c] < t_lo) ? 1 : 0;
                     c_hi += (j < a.B && Tinc[k][c] < t_hi) ? 1 : 0;
@@ -457,7 +504,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         }
         if (b == 0 && tid == 0 && a.finalize_prev) {
             FilterScalars* sc = a.scal + r;
-            const double Sdd = S ? dldexp((double)S, -a.rshift) : dnan();
+            const double Sdd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
             const double lse = m + dlog(Sdd);
             const double ll = lse - sc->prev;
             sc->m = m;
@@ -473,10 +520,10 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     // --- request the cdf tiles my targets fall into (coalesced 16-byte loads into registers) ---
     int bb_min = 0, span = kStageTiles + 1;
     // three explicitly named register tiles (a runtime-indexed array would be placed in scratch memory)
-    ulonglong2 stg0[NK], stg1[NK], stg2[NK];
+    double2 stg0[NK], stg1[NK], stg2[NK];
 #pragma unroll
-    for (int k = 0; k < NK; ++k) { stg0[k] = make_ulonglong2(0, 0); stg1[k] = stg0[k]; stg2[k] = stg0[k]; }
-    const u64* cdf_r = a.cdf_in + rowoff;
+    for (int k = 0; k < NK; ++k) { stg0[k] = make_double2(0.0, 0.0); stg1[k] = stg0[k]; stg2[k] = stg0[k]; }
+    const double* cdf_r = a.cdf_in + rowoff;
     const double* xin_r = a.x_in + rowoff;
     if (resampled) {
         __syncthreads();          // lds_T, lds_R, lds_cnt visible
@@ -488,16 +535,16 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             span = __builtin_amdgcn_readfirstlane(hi) - bb_min + 1;
         }
         if (span <= kStageTiles) {
-            const u64* src = cdf_r + (size_t)bb_min * kTile + tid * 2;
+            const double* src = cdf_r + (size_t)bb_min * kTile + tid * 2;
 #pragma unroll
-            for (int k = 0; k < NK; ++k) stg0[k] = *reinterpret_cast<const ulonglong2*>(src + k * NT * 2);
+            for (int k = 0; k < NK; ++k) stg0[k] = *reinterpret_cast<const double2*>(src + k * NT * 2);
             if (span >= 2) {
 #pragma unroll
-                for (int k = 0; k < NK; ++k) stg1[k] = *reinterpret_cast<const ulonglong2*>(src + kTile + k * NT * 2);
+                for (int k = 0; k < NK; ++k) stg1[k] = *reinterpret_cast<const double2*>(src + kTile + k * NT * 2);
             }
             if (span >= 3) {
 #pragma unroll
-                for (int k = 0; k < NK; ++k) stg2[k] = *reinterpret_cast<const ulonglong2*>(src + 2 * kTile + k * NT * 2);
+                for (int k = 0; k < NK; ++k) stg2[k] = *reinterpret_cast<const double2*>(src + 2 * kTile + k * NT * 2);
             }
         }
     }
@@ -505,9 +552,9 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 
     // --- exponential spacings of the multinomial resampler (liu_west_filter.h:105-139), exact tile scan;
     //     this arithmetic hides the latency of the tile loads ---
-    u64 le[NK][2], se = 1;
+    double le[NK][2], se = 1.0;
     if (multinomial) {
-        u64 qe[NK][2];
+        double qe[NK][2];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int i0 = i_first + (k * NT + tid) * 2;
@@ -517,10 +564,10 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                 const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, a.key0, a.key1);
                 e0 = -dlog_pn(u01_oc(o.v0, o.v1)); e1 = -dlog_pn(u01_oc(o.v2, o.v3));
             }
-            qe[k][0] = (i0 < a.N) ? (d2bits(dfma(e0, 35184372088832.0, 4503599627370496.0)) & 0x000fffffffffffffull) : 0ull;
-            qe[k][1] = (i0 + 1 < a.N) ? (d2bits(dfma(e1, 35184372088832.0, 4503599627370496.0)) & 0x000fffffffffffffull) : 0ull;
+            qe[k][0] = (i0 < a.N) ? __builtin_rint(e0 * 34359738368.0 /* 2^35 */) : 0.0;
+            qe[k][1] = (i0 + 1 < a.N) ? __builtin_rint(e1 * 34359738368.0) : 0.0;
         }
-        block_scan_u64<NT>(qe, le, se, lds_seg_a);
+        block_scan_f64<NT>(qe, le, se, lds_seg_a);
     }
     STAMP(a, 4);
 
@@ -538,31 +585,30 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         }
     } else {
         // --- integer resampling targets in [0, S'] ---
-        u64 tau[NK][2];
-        const double ratio = gam / (double)se;          // per tile: Gamma_b * E_j / sum_tile(E)
+        double tau[NK][2];
+        const double ratio = gam / se;                  // per tile: Gamma_b * E_j / sum_tile(E)
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int i0 = i_first + (k * NT + tid) * 2;
             if (a.resampler == RESAMP_MULTINOMIAL) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const double t1 = ratio * (double)le[k][c];
+                    const double t1 = ratio * le[k][c];
                     const double t2 = pgam + t1;
-                    tau[k][c] = tau_to_u64(t2 * t_scale);
+                    tau[k][c] = __builtin_ceil(t2 * t_scale);
                 }
             } else if (a.resampler == RESAMP_SYSTEMATIC) {
-                tau[k][0] = tau_to_u64(((double)i0 + u0) * t_scale);
-                tau[k][1] = tau_to_u64(((double)(i0 + 1) + u0) * t_scale);
+                tau[k][0] = __builtin_ceil(((double)i0 + u0) * t_scale);
+                tau[k][1] = __builtin_ceil(((double)(i0 + 1) + u0) * t_scale);
             } else {
                 const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, a.key0, a.key1);
                 const double v0 = u01_co(o.v0, o.v1), v1 = u01_co(o.v2, o.v3);
                 if (a.resampler == RESAMP_STRATIFIED) {
-                    tau[k][0] = tau_to_u64(((double)i0 + v0) * t_scale);
-                    tau[k][1] = tau_to_u64(((double)(i0 + 1) + v1) * t_scale);
+                    tau[k][0] = __builtin_ceil(((double)i0 + v0) * t_scale);
+                    tau[k][1] = __builtin_ceil(((double)(i0 + 1) + v1) * t_scale);
                 } else {
-                    const double Sd = (double)S;
-                    tau[k][0] = tau_to_u64(v0 * Sd);
-                    tau[k][1] = tau_to_u64(v1 * Sd);
+                    tau[k][0] = __builtin_ceil(v0 * S);
+                    tau[k][1] = __builtin_ceil(v1 * S);
                 }
             }
         }
@@ -570,22 +616,22 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         if (span <= kStageTiles) {
             // --- staged tiles -> LDS, then count-search in LDS ---
             {
-                u64* dst = lds_stage + tid * 2;
+                double* dst = lds_stage + tid * 2;
 #pragma unroll
-                for (int k = 0; k < NK; ++k) *reinterpret_cast<ulonglong2*>(dst + k * NT * 2) = stg0[k];
+                for (int k = 0; k < NK; ++k) *reinterpret_cast<double2*>(dst + k * NT * 2) = stg0[k];
                 if (span >= 2) {
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) *reinterpret_cast<ulonglong2*>(dst + kTile + k * NT * 2) = stg1[k];
+                    for (int k = 0; k < NK; ++k) *reinterpret_cast<double2*>(dst + kTile + k * NT * 2) = stg1[k];
                 }
                 if (span >= 3) {
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) *reinterpret_cast<ulonglong2*>(dst + 2 * kTile + k * NT * 2) = stg2[k];
+                    for (int k = 0; k < NK; ++k) *reinterpret_cast<double2*>(dst + 2 * kTile + k * NT * 2) = stg2[k];
                 }
             }
             const int b1 = bb_min + 1 < a.B ? bb_min + 1 : a.B - 1, b2 = bb_min + 2 < a.B ? bb_min + 2 : a.B - 1;
-            const u64 T0 = lds_T[bb_min];
-            const u64 T1 = (bb_min + 1 < a.B) ? lds_T[bb_min + 1] : ~0ull;
-            const u64 Pm = bb_min ? lds_T[bb_min - 1] : 0ull;
+            const double T0 = lds_T[bb_min];
+            const double T1 = (bb_min + 1 < a.B) ? lds_T[bb_min + 1] : dinf();
+            const double Pm = bb_min ? lds_T[bb_min - 1] : 0.0;
             const double R0 = lds_R[bb_min], R1 = lds_R[b1], R2 = lds_R[b2];
             __syncthreads();
             STAMP(a, 5);
@@ -594,15 +640,15 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                 int sel_prev = -1, j_prev = 0;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const u64 target = tau[k][c];
+                    const double target = tau[k][c];
                     int sel = (T0 < target ? 1 : 0) + (T1 < target ? 1 : 0);
                     sel = sel < span - 1 ? sel : span - 1;
-                    const u64 Pb = sel == 0 ? Pm : (sel == 1 ? T0 : T1);
+                    const double Pb = sel == 0 ? Pm : (sel == 1 ? T0 : T1);
                     const double Rb = sel == 0 ? R0 : (sel == 1 ? R1 : R2);
-                    const u64 tloc = tau_to_u64((double)(target - Pb) * Rb);
-                    const u64* tile = lds_stage + sel * kTile;
+                    const double tloc = __builtin_ceil((target - Pb) * Rb);
+                    const double* tile = lds_stage + sel * kTile;
                     int j;
-                    if (ABL(a, 2)) j = (int)(tloc & 2047);
+                    if (ABL(a, 2)) j = (int)(d2bits(tloc) >> 20) & 2047;
                     else if (c == 1 && sel == sel_prev) j = count_less_gallop(tile, tloc, j_prev);   // sorted: count >= j_prev
                     else j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
                     sel_prev = sel; j_prev = j;
@@ -620,12 +666,12 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             for (int k = 0; k < NK; ++k) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const u64 target = tau[k][c];
+                    const double target = tau[k][c];
                     int bb = count_less_pow2(a.Bpow2, target, [&](int j) { return lds_T[j]; });
                     bb = bb < a.B - 1 ? bb : a.B - 1;
-                    const u64 Pb = bb ? lds_T[bb - 1] : 0ull;
-                    const u64 tloc = tau_to_u64((double)(target - Pb) * lds_R[bb]);
-                    const u64* tile = cdf_r + (size_t)bb * kTile;
+                    const double Pb = bb ? lds_T[bb - 1] : 0.0;
+                    const double tloc = __builtin_ceil((target - Pb) * lds_R[bb]);
+                    const double* tile = cdf_r + (size_t)bb * kTile;
                     const int j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
                     int anc = bb * kTile + j;
                     anc = anc < a.N - 1 ? anc : a.N - 1;
@@ -675,26 +721,26 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     STAMP(a, 9);
 
     // --- tile-local fixed-point weights and their exact inclusive scan (the next step's cdf) ---
-    u64 q[NK][2], inc[NK][2], total;
+    double q[NK][2], inc[NK][2], total;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int i0 = i_first + (k * NT + tid) * 2;
-        if (ABL(a, 4)) { q[k][0] = d2bits(lg[k][0] - mb) >> 24; q[k][1] = d2bits(lg[k][1] - mb) >> 24; }
+        if (ABL(a, 4)) { q[k][0] = (double)(d2bits(lg[k][0] - mb) >> 24); q[k][1] = (double)(d2bits(lg[k][1] - mb) >> 24); }
         else {
-            q[k][0] = (i0 < a.N) ? rne_u52(dexp_scaled(lg[k][0] - mb, kTileShift)) : 0ull;
-            q[k][1] = (i0 + 1 < a.N) ? rne_u52(dexp_scaled(lg[k][1] - mb, kTileShift)) : 0ull;
+            q[k][0] = (i0 < a.N) ? __builtin_rint(dexp_scaled(lg[k][0] - mb, kTileShift)) : 0.0;
+            q[k][1] = (i0 + 1 < a.N) ? __builtin_rint(dexp_scaled(lg[k][1] - mb, kTileShift)) : 0.0;
         }
     }
     if (ABL(a, 5)) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) { inc[k][0] = q[k][0]; inc[k][1] = q[k][0] + q[k][1]; }
-        total = inc[0][1] + 0x100000;
-    } else block_scan_u64<NT>(q, inc, total, lds_seg_c);
+        total = inc[0][1] + 1048576.0;
+    } else block_scan_f64<NT>(q, inc, total, lds_seg_c);
     STAMP(a, 12);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int i0 = i_first + (k * NT + tid) * 2;
-        *reinterpret_cast<ulonglong2*>(a.cdf_out + rowoff + i0) = make_ulonglong2(inc[k][0], inc[k][1]);
+        *reinterpret_cast<double2*>(a.cdf_out + rowoff + i0) = make_double2(inc[k][0], inc[k][1]);
     }
     STAMP(a, 10);
     if (tid == 0) {
@@ -712,18 +758,18 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 // Reads the tile sums / maxima the last k_filter_step wrote (passed as tsum_in / tmax_in).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void kf_finalize(const StepArgs a) {
-    __shared__ u64 lds_seg[16];
+    __shared__ double lds_seg[16];
     __shared__ double lds_d[16];
     const int tid = threadIdx.x;
     const int r = blockIdx.x;
-    u64 A2[4][2], Ap[4][2], Tinc[4][2], S;
+    double A2[4][2], Ap[4][2], Tinc[4][2], S;
     double M2[4][2], m;
     level2_load<kThreads>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
     level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
     if (tid == 0) {
         FilterScalars* sc = a.scal + r;
         const bool resample_now = ((a.t + 1) % a.resamp_sched == 0);
-        const double Sd = S ? dldexp((double)S, -a.rshift) : dnan();
+        const double Sd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
         const double lse = m + dlog(Sd);
         const double ll = lse - sc->prev;
         sc->m = m;
@@ -767,7 +813,7 @@ __global__ __launch_bounds__(kThreads) void k_gamma_prefix(const double* gam, do
 // Weights are the fixed-point weights the resampler uses: w_j = q_j * exp(m_tile - m),
 // q_j = cdf_j - cdf_{j-1}.  Partial sums: per-thread strided, wave tree, 4 waves in order.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_expectation(const double* x, const u64* cdf, const double* tmax, int N, int Npad,
+__global__ __launch_bounds__(kThreads) void k_expectation(const double* x, const double* cdf, const double* tmax, int N, int Npad,
                                                           int B, int Bs, int functional, double* out) {
     __shared__ double lds_n[4], lds_d[4];
     __shared__ double lds_m[16];
@@ -778,9 +824,9 @@ __global__ __launch_bounds__(kThreads) void k_expectation(const double* x, const
     const double m = block_max_nanprop<kThreads>(mx, nan, lds_m);
     double num = 0.0, den = 0.0;
     for (int i = tid; i < N; i += kThreads) {
-        const u64 c1 = cdf[(size_t)r * Npad + i];
-        const u64 c0 = (i & (kTile - 1)) ? cdf[(size_t)r * Npad + i - 1] : 0ull;
-        const double w = (double)(c1 - c0) * dexp(tmax[(size_t)r * Bs + i / kTile] - m);
+        const double c1 = cdf[(size_t)r * Npad + i];
+        const double c0 = (i & (kTile - 1)) ? cdf[(size_t)r * Npad + i - 1] : 0.0;
+        const double w = (c1 - c0) * dexp(tmax[(size_t)r * Bs + i / kTile] - m);
         const double xv = x[(size_t)r * Npad + i];
         const double hv = functional == 0 ? xv : functional == 1 ? xv * xv : functional == 2 ? dexp(0.5 * xv) : 42.0;
         num = num + hv * w;

@@ -79,7 +79,7 @@ def test_device_quantize_bit_exact(sa, oracle):
     from ssme_amd import _capi
     rng = np.random.default_rng(2)
     x = np.concatenate([-rng.exponential(8.0, 300000), [0.0, -0.0, -745.0, -800.0, -np.inf, np.nan]])
-    for shift in (42, 49, 51):
+    for shift in (30, 38, 41):
         q = np.empty(x.size, dtype=np.uint64)
         _capi.check(_capi.lib().ssme_pf_test_quantize(0, _capi.dptr(x), shift, _capi.u64ptr(q), x.size))
         np.testing.assert_array_equal(q, oracle.quantize(x, shift))
@@ -87,10 +87,10 @@ def test_device_quantize_bit_exact(sa, oracle):
 
 @pytest.mark.parametrize("threads", [256, 512, 1024])
 def test_device_block_scan_exact(sa, threads):
-    """DPP wave scans + segment prefixes == numpy's exact uint64 cumulative sum (wrap-around included)."""
+    """fp64 DPP wave scans + segment prefixes of integers == numpy's exact integer cumulative sum."""
     from ssme_amd import _capi
     rng = np.random.default_rng(4)
-    for hi in (1 << 20, 1 << 51, (1 << 64) - 1):
+    for hi in (1 << 10, 1 << 30, 1 << 41):
         v = rng.integers(0, hi, 2048, dtype=np.uint64)
         v[rng.integers(0, 2048, 100)] = 0
         incl, tot = np.empty(2048, dtype=np.uint64), np.zeros(1, dtype=np.uint64)
@@ -104,7 +104,7 @@ def test_device_rescale_bit_exact(sa, oracle):
     """A'_b = rint((double)A_b exp(m_b - m) 2^(rg-51)): the only floating-point step across tiles."""
     from ssme_amd import _capi
     rng = np.random.default_rng(6)
-    A = rng.integers(0, 1 << 62, 20000, dtype=np.uint64)
+    A = rng.integers(0, 1 << 52, 20000, dtype=np.uint64)
     dm = np.concatenate([-rng.exponential(3.0, 19990), [0.0, -0.0, -800.0, -np.inf, np.nan, -1e-300, -745.0, -30.0, -1.0, -2.0]])
     for shift in (-9, -2, 0):
         out = np.empty(A.size, dtype=np.uint64)
