@@ -353,55 +353,67 @@ __device__ __forceinline__ int count_less_gallop(const double* tile, double targ
 
 // Level-2 of one filter: global max m over the tile maxima (NaN propagating), rescaled integer
 // tile sums A'_b = rint(A_b exp(m_b - m) 2^(rg-41)), their exact inclusive scan.  Thread tid holds
-// entries j = (k*NT + tid)*2 + c; rows and waves without live entries (j >= B) skip the arithmetic.
-// Two barriers.  lds_d: NT/64 doubles, lds_seg: 16 u64.
+// entries j = e*NT + tid, e < NE = 2048/NT: at B <= NT every wave owns live entries, so the serial
+// exp / divide per entry is spread over the whole block.  Rows without live entries are skipped.
+// 1 + nrows barriers.  lds_d: NT/64 doubles, lds_seg: 16 doubles per row (4 rows).
 template <int NT>
-__device__ __forceinline__ void level2_load(const double* ts, const double* tm, int B, double (&A)[1024 / NT][2],
-                                            double (&mb)[1024 / NT][2]) {
-    constexpr int NK = 1024 / NT;
+__device__ __forceinline__ void level2_load(const double* ts, const double* tm, int B, double (&A)[2048 / NT],
+                                            double (&mb)[2048 / NT]) {
+    constexpr int NE = 2048 / NT;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int j = (k * NT + threadIdx.x) * 2;
-        if (j < B) {       // Bs is even: j+1 < Bs
-            const double2 t2 = *reinterpret_cast<const double2*>(ts + j);
-            const double2 m2 = *reinterpret_cast<const double2*>(tm + j);
-            A[k][0] = t2.x; A[k][1] = t2.y; mb[k][0] = m2.x; mb[k][1] = m2.y;
-        } else { A[k][0] = 0.0; A[k][1] = 0.0; mb[k][0] = 0.0; mb[k][1] = 0.0; }
+    for (int e = 0; e < NE; ++e) {
+        const int j = e * NT + threadIdx.x;
+        if (j < B) { A[e] = ts[j]; mb[e] = tm[j]; } else { A[e] = 0.0; mb[e] = 0.0; }
     }
 }
 
 template <int NT>
-__device__ __forceinline__ void level2_scan(const double (&A)[1024 / NT][2], const double (&mb)[1024 / NT][2], int B, int rshift,
-                                            double& m, double (&Ap)[1024 / NT][2], double (&Tinc)[1024 / NT][2], double& S,
+__device__ __forceinline__ void level2_scan(const double (&A)[2048 / NT], const double (&mb)[2048 / NT], int B, int rshift,
+                                            double& m, double (&Ap)[2048 / NT], double (&Tinc)[2048 / NT], double& S,
                                             double* lds_d, double* lds_seg) {
-    constexpr int NK = 1024 / NT;
-    const int wave_j0 = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 128);   // first entry of my wave in row 0
+    constexpr int NE = 2048 / NT, NW = NT / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double mx = -dinf();
     bool nan = false;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        if (k * NT * 2 + wave_j0 < B) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int j = (k * NT + threadIdx.x) * 2 + c;
-                if (j < B) { const double v = mb[k][c]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
-            }
+    for (int e = 0; e < NE; ++e) {
+        if (e * NT < B) {
+            const int j = e * NT + threadIdx.x;
+            if (j < B) { const double v = mb[e]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
         }
     }
     m = block_max_nanprop<NT>(mx, nan, lds_d);
+    double inc[NE];
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        Ap[k][0] = 0.0; Ap[k][1] = 0.0;
-        if (k * NT * 2 + wave_j0 < B) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int j = (k * NT + threadIdx.x) * 2 + c;
-                // NaN (m or m_b NaN) is squashed to 0 by dexp_scaled's clamp: A' = rint(A * 0) = 0
-                if (j < B) Ap[k][c] = __builtin_rint(A[k][c] * dexp_scaled(mb[k][c] - m, rshift - kTileShift));
-            }
+    for (int e = 0; e < NE; ++e) {
+        Ap[e] = 0.0; inc[e] = 0.0;
+        if (e * NT < B) {
+            const int j = e * NT + threadIdx.x;
+            // NaN (m or m_b NaN) is squashed to 0 by dexp_scaled's clamp: A' = rint(A * 0) = 0
+            if (j < B) Ap[e] = __builtin_rint(A[e] * dexp_scaled(mb[e] - m, rshift - kTileShift));
+            inc[e] = wave_incl_scan_f64(Ap[e]);
+            if (lane == 63) lds_seg[e * 16 + wave] = inc[e];
         }
     }
-    block_scan_f64<NT>(Ap, Tinc, S, lds_seg);
+    __syncthreads();
+    double carry = 0.0;
+    S = 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        Tinc[e] = 0.0;
+        if (e * NT < B) {
+            double sv = (lane & 15) < NW ? lds_seg[e * 16 + (lane & 15)] : 0.0;
+            sv = sv + dpp_f64_zero<0x111, 0xF>(sv);
+            sv = sv + dpp_f64_zero<0x112, 0xF>(sv);
+            sv = sv + dpp_f64_zero<0x114, 0xF>(sv);
+            sv = sv + dpp_f64_zero<0x118, 0xF>(sv);
+            const double pre = wave ? readlane_f64(sv, wave - 1) : 0.0;
+            Tinc[e] = (carry + pre) + inc[e];
+            carry = carry + readlane_f64(sv, 15);
+        }
+    }
+    S = carry;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -421,7 +433,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     double* lds_R = lds_T + nT2;                                 // [Bpow2] A_b / A'_b
     double* lds_stage = lds_T + 2 * nT2;                         // [3][2048] staged cdf tiles, 16-byte aligned
     __shared__ double lds_seg_a[16];
-    __shared__ double lds_seg_b[16];
+    __shared__ double lds_seg_l2[64];
     __shared__ double lds_seg_c[16];
     __shared__ int lds_cnt[2];
     __shared__ double lds_d1[16];
@@ -442,7 +454,8 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 
     STAMP(a, 0);
     // --- issue the level-2 loads first: previous step's tile sums and maxima ---
-    double A2[NK][2], M2[NK][2];
+    constexpr int NE = 2048 / NT;
+    double A2[NE], M2[NE];
     if (need_l2) level2_load<NT>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
     if (tid == 0) { lds_cnt[0] = 0; lds_cnt[1] = 0; }
     double gam = 0.0, pgam = 0.0, pgam_next = 0.0, G = 1.0;
@@ -458,9 +471,14 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     double S = 0.0;
     double t_scale = 0.0, u0 = 0.0;
     if (need_l2) {
-        double Ap[NK][2], Tinc[NK][2];
+        double Ap[NE], Tinc[NE];
         double m;
-        level2_scan<NT>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d1, lds_seg_b);
+#ifdef SSME_ABLATE
+        if (a.stamps) { asm volatile("" :: "v"(A2[0]), "v"(M2[0])); }   // force the loads to have landed
+        STAMP(a, 13);
+#endif
+        level2_scan<NT>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d1, lds_seg_l2);
+        STAMP(a, 14);
         // bounds [t_lo, t_hi] of this tile's targets, known to every thread without the spacings
         const double Sd = S;
         double t_lo = 0.0, t_hi = dinf();
@@ -479,29 +497,23 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             t_lo = __builtin_ceil((double)i_first * t_scale);
             t_hi = __builtin_ceil((double)(i_first + nvalid) * t_scale);
         }
-        const int wave_j0 = __builtin_amdgcn_readfirstlane((tid >> 6) * 128);
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            if (k * NT * 2 + wave_j0 < a.Bpow2) {
-                int c_lo = 0, c_hi = 0;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int j = (k * NT + tid) * 2 + c;
-                    if (j < a.Bpow2) {
-                        lds_T[j] = (j < a.B) ? Tinc[k][c] : dinf();
-                        lds_R[j] = (j < a.B) ? A2[k][c] / Ap[k][c] : 0.0;
-                    }
-                    c_lo += (j < a.B && Tinc[k][c] < t_lo) ? 1 : 0;
-                    c_hi += (j < a.B && Tinc[k][c] < t_hi) ? 1 : 0;
+        for (int e = 0; e < NE; ++e) {
+            if (e * NT < a.Bpow2) {
+                const int j = e * NT + tid;
+                if (j < a.Bpow2) {
+                    lds_T[j] = (j < a.B) ? Tinc[e] : dinf();
+                    lds_R[j] = (j < a.B) ? A2[e] / Ap[e] : 0.0;
                 }
                 if (resampled && sorted) {
                     // #{T'_j < t_lo}, #{T'_j < t_hi}: wave popcounts, one LDS atomic per wave
-                    const int w_lo = __popcll(__ballot(c_lo & 1)) + 2 * __popcll(__ballot(c_lo >> 1));
-                    const int w_hi = __popcll(__ballot(c_hi & 1)) + 2 * __popcll(__ballot(c_hi >> 1));
+                    const int w_lo = __popcll(__ballot(j < a.B && Tinc[e] < t_lo));
+                    const int w_hi = __popcll(__ballot(j < a.B && Tinc[e] < t_hi));
                     if ((tid & 63) == 0) { if (w_lo) atomicAdd(&lds_cnt[0], w_lo); if (w_hi) atomicAdd(&lds_cnt[1], w_hi); }
                 }
             }
         }
+        STAMP(a, 15);
         if (b == 0 && tid == 0 && a.finalize_prev) {
             FilterScalars* sc = a.scal + r;
             const double Sdd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
@@ -758,12 +770,11 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 // Reads the tile sums / maxima the last k_filter_step wrote (passed as tsum_in / tmax_in).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void kf_finalize(const StepArgs a) {
-    __shared__ double lds_seg[16];
+    __shared__ double lds_seg[128];
     __shared__ double lds_d[16];
     const int tid = threadIdx.x;
     const int r = blockIdx.x;
-    double A2[4][2], Ap[4][2], Tinc[4][2], S;
-    double M2[4][2], m;
+    double A2[8], Ap[8], Tinc[8], M2[8], S, m;
     level2_load<kThreads>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
     level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
     if (tid == 0) {

@@ -36,6 +36,7 @@ print("block end-time percentiles (us): ", {p: round(float(np.percentile(endt, p
 # slowest blocks: which phases are slow?
 idx = np.argsort(dur)[-8:]
 prev = 0
+print("level-2 detail (us): loads landed at", round(((s[:,13]-s[:,0])/100).mean(),2), " scan done +", round(((s[:,14]-s[:,13])/100).mean(),2), " LDS/ballots +", round(((s[:,15]-s[:,14])/100).mean(),2), " finalize+rest +", round(((s[:,2]-s[:,15])/100).mean(),2))
 print("slowest 8 blocks, per-phase us:")
 for k in order[1:]:
     d = (s[idx, k] - s[idx, prev]) / 100.0
