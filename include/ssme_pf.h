@@ -162,6 +162,43 @@ int ssme_pf_test_copy(int32_t device, int64_t n_doubles, int32_t repeats);
 /* n Gamma(shape) draws for tiles 0..n-1 at time t of filter `rep` */
 int ssme_pf_test_gamma(int32_t device, uint64_t seed, uint32_t rep, int32_t t, double shape, int32_t n, double* out);
 
+/* ============================================================================================
+ * Liu-West filter: LWFilterWithCovs<nparts,1,1,1,4,float_t>::filter (include/ssme/liu_west_filter.h:971-1159)
+ * with the model of svol_lw_1_par (test/test_liu_west.cpp:22-157): parameters (phi, mu, sigma, rho), one
+ * transform per parameter (parameters.h:27 enum order: 0 null, 1 twice_fisher, 2 logit, 3 log), uniform priors,
+ * shrinkage a = (3 delta - 1) / (2 delta), resampling of states and parameters every step (:91-145).
+ * ============================================================================================ */
+typedef struct ssme_lw_s* ssme_lw_handle;
+typedef struct ssme_lw_config {
+    int32_t  n_particles;       /* N per filter                                                        */
+    int32_t  n_filters;         /* independent filters in this handle                                   */
+    uint64_t seed;
+    int32_t  device;
+    uint32_t first_filter_id;
+    double   delta;             /* discount factor, ctor argument `delta` (liu_west_filter.h:954-960)    */
+    int32_t  transforms[4];     /* ctor argument `transforms`; svol_lw_1_par: logit, null, log, twice_fisher */
+    double   prior_lo[4];       /* paramPriorSamp(): theta_d ~ U(lo_d, hi_d), test_liu_west.cpp:140-150  */
+    double   prior_hi[4];
+} ssme_lw_config;
+
+int ssme_lw_create(const ssme_lw_config* cfg, ssme_lw_handle* out);
+int ssme_lw_destroy(ssme_lw_handle h);
+int ssme_lw_reset(ssme_lw_handle h);
+/* filter(y_t, z_t): one step on every filter; logcondlike_out (R values) = getLogCondLike() */
+int ssme_lw_step(ssme_lw_handle h, const double* y, const double* z, double* logcondlike_out);
+/* T steps; loglik_out (R values) = sum of the log conditional likelihoods */
+int ssme_lw_run_series(ssme_lw_handle h, const double* y, const double* z, int32_t T, double* loglik_out);
+int ssme_lw_get_per_step(ssme_lw_handle h, double* out, int32_t T);
+/* weighted means of the untransformed parameters under the last step's weights: out[r*4 + d] */
+int ssme_lw_get_param_means(ssme_lw_handle h, double* out);
+/* parity/debug: particles, transformed parameters theta[d*N + i] (getParamSamples()), k indices and resampling
+ * ancestors of the last step (after set_debug(1)), theta-bar and the Cholesky factor of (1 - a^2) V (row-major 4x4) */
+int ssme_lw_download_state(ssme_lw_handle h, int32_t filter, double* x, double* theta, uint32_t* kidx, uint32_t* ancestors,
+                           double* thetabar, double* chol);
+int ssme_lw_set_debug(ssme_lw_handle h, int32_t flags);
+int ssme_lw_last_elapsed_ms(ssme_lw_handle h, float* ms);
+const char* ssme_lw_last_error(ssme_lw_handle h);
+
 const char* ssme_pf_strerror(int status);
 const char* ssme_pf_last_error(ssme_pf_handle h);
 int ssme_pf_version(void);

@@ -69,6 +69,18 @@ def lib():
         L.orc_log_jacobian.argtypes = [C.c_int, C.c_double]
         L.orc_kalman_loglik.restype = C.c_double
         L.orc_kalman_loglik.argtypes = [C.c_double, C.c_double, C.c_double, dp, C.c_int, dp]
+        i32p = C.POINTER(C.c_int32)
+        L.orc_lw_create.restype = C.c_void_p
+        L.orc_lw_create.argtypes = [C.c_int, C.c_uint64, C.c_uint32, i32p, dp, dp, C.c_double]
+        L.orc_lw_destroy.argtypes = [C.c_void_p]
+        L.orc_lw_step.restype = C.c_double
+        L.orc_lw_step.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_lw_loglik.restype = C.c_double
+        L.orc_lw_loglik.argtypes = [C.c_void_p]
+        L.orc_lw_param_means.argtypes = [C.c_void_p, dp]
+        L.orc_lw_state.argtypes = [C.c_void_p, dp, dp, dp, u32p, u32p, dp, dp]
+        L.orc_lw_ref_run.restype = C.c_double
+        L.orc_lw_ref_run.argtypes = [C.c_int, i32p, dp, dp, C.c_double, dp, dp, C.c_int, C.c_uint32, dp, dp]
         _lib = L
     return _lib
 
@@ -222,3 +234,62 @@ def kalman_loglik(phi, sigma, tau, y):
     y = np.ascontiguousarray(y, dtype=np.float64)
     per = np.empty(y.size)
     return lib().orc_kalman_loglik(phi, sigma, tau, _dp(y), y.size, _dp(per)), per
+
+
+# ---- Liu-West (include/ssme/liu_west_filter.h:971-1159; model test/test_liu_west.cpp:82-157) ----
+TR_NULL, TR_TWICE_FISHER, TR_LOGIT, TR_LOG = 0, 1, 2, 3
+LW_TRANSFORMS = (TR_LOGIT, TR_NULL, TR_LOG, TR_TWICE_FISHER)          # phi, mu, sigma, rho (test_liu_west.cpp:70)
+LW_PRIOR_LO = (0.8, -0.1, 0.01, -0.5)                                  # test_liu_west.cpp:165
+LW_PRIOR_HI = (0.99, 0.1, 0.1, -0.01)
+
+
+def _i32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class LWFilter:
+    """Kernel-matched Liu-West oracle (auxiliary form with covariates), one filter."""
+
+    def __init__(self, n, seed, rep=0, delta=0.99, transforms=LW_TRANSFORMS, lo=LW_PRIOR_LO, hi=LW_PRIOR_HI):
+        self.n = int(n)
+        tr = np.ascontiguousarray(transforms, dtype=np.int32)
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        hi = np.ascontiguousarray(hi, dtype=np.float64)
+        self._h = lib().orc_lw_create(n, seed, rep, _i32p(tr), _dp(lo), _dp(hi), float(delta))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_lw_destroy(self._h)
+            self._h = None
+
+    def step(self, y, z=0.0):
+        return lib().orc_lw_step(self._h, float(y), float(z))
+
+    @property
+    def loglik(self):
+        return lib().orc_lw_loglik(self._h)
+
+    def param_means(self):
+        out = np.empty(4)
+        lib().orc_lw_param_means(self._h, _dp(out))
+        return out
+
+    def state(self):
+        n = self.n
+        x, th, lw = np.empty(n), np.empty((4, n)), np.empty(n)
+        k, a = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32)
+        tb, L = np.empty(4), np.empty((4, 4))
+        lib().orc_lw_state(self._h, _dp(x), _dp(th), _dp(lw), _u32p(k), _u32p(a), _dp(tb), _dp(L))
+        return dict(x=x, theta=th, logw=lw, kidx=k, anc=a, thetabar=tb, L=L)
+
+
+def lw_ref_run(n, y, z, seed=1, delta=0.99, transforms=LW_TRANSFORMS, lo=LW_PRIOR_LO, hi=LW_PRIOR_HI):
+    """Mode A: reference-faithful Liu-West (mt19937). Returns (loglik, per-step, posterior means of phi, mu, sigma, rho)."""
+    tr = np.ascontiguousarray(transforms, dtype=np.int32)
+    lo = np.ascontiguousarray(lo, dtype=np.float64)
+    hi = np.ascontiguousarray(hi, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    per, means = np.empty(y.size), np.empty(4)
+    ll = lib().orc_lw_ref_run(n, _i32p(tr), _dp(lo), _dp(hi), float(delta), _dp(y), _dp(z), y.size, seed, _dp(per), _dp(means))
+    return ll, per, means

@@ -38,6 +38,7 @@
 // pf-internal details that cannot be read here are marked [pf-recollection].
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -344,22 +345,22 @@ struct Filter {
         double sn, cs; o_sincos2pi(u2, &sn, &cs);
         return (i & 1) ? rad * sn : rad * cs;
     }
-    void resamp_words(int i, int tt, uint32_t* a, uint32_t* b) const {
-        const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, STREAM_RESAMP};
+    void resamp_words(int i, int tt, uint32_t* a, uint32_t* b, int stream = STREAM_RESAMP) const {
+        const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, (uint32_t)stream};
         uint32_t o[4]; philox4x32_10(ctr, key, o);
         *a = o[2 * (i & 1)]; *b = o[2 * (i & 1) + 1];
     }
-    void extra_words(int tt, uint32_t o[4]) const {
-        const uint32_t ctr[4] = {0u, (uint32_t)tt, rep, STREAM_RESAMP_EXTRA};
+    void extra_words(int tt, uint32_t o[4], int stream = STREAM_RESAMP_EXTRA) const {
+        const uint32_t ctr[4] = {0u, (uint32_t)tt, rep, (uint32_t)stream};
         philox4x32_10(ctr, key, o);
     }
     // Gamma(shape) draw for tile b at time tt: Marsaglia & Tsang (2000), counter-driven attempts
-    double gamma_draw(int b, int tt, double shape) const {
+    double gamma_draw(int b, int tt, double shape, int stream_base = STREAM_GAMMA) const {
         const double d = shape - 0.3333333333333333;
         const double c = 1.0 / std::sqrt(9.0 * d);
         for (int a = 0; a < 32; ++a) {
-            const uint32_t c1[4] = {(uint32_t)b, (uint32_t)tt, rep, (uint32_t)(STREAM_GAMMA + 2 * a)};
-            const uint32_t c2[4] = {(uint32_t)b, (uint32_t)tt, rep, (uint32_t)(STREAM_GAMMA + 2 * a + 1)};
+            const uint32_t c1[4] = {(uint32_t)b, (uint32_t)tt, rep, (uint32_t)(stream_base + 2 * a)};
+            const uint32_t c2[4] = {(uint32_t)b, (uint32_t)tt, rep, (uint32_t)(stream_base + 2 * a + 1)};
             uint32_t o1[4], o2[4];
             philox4x32_10(c1, key, o1); philox4x32_10(c2, key, o2);
             const double rad = std::sqrt(-2.0 * o_log(u01_oc(o1[0], o1[1])));
@@ -377,7 +378,8 @@ struct Filter {
     }
 
     // integer targets for the ancestors consumed at time tt (drawn against the cdf of step tt-1)
-    void targets(int tt, std::vector<uint64_t>& tau) const {
+    void targets(int tt, std::vector<uint64_t>& tau, int s_spacing = STREAM_RESAMP, int s_extra = STREAM_RESAMP_EXTRA,
+                 int s_gamma = STREAM_GAMMA) const {
         tau.assign(N, 0);
         const double Sd = (double)Sint;
         if (resamp == RESAMP_MULTINOMIAL) {
@@ -390,11 +392,11 @@ struct Filter {
             double run = 0.0;
             for (int b = 0; b < B; ++b) {
                 const int nb = std::min(TILE, N - b * TILE);
-                gam[b] = gamma_draw(b, tt, (double)nb);
+                gam[b] = gamma_draw(b, tt, (double)nb, s_gamma);
                 pgam[b] = run;
                 run = run + gam[b];
             }
-            uint32_t o[4]; extra_words(tt, o);
+            uint32_t o[4]; extra_words(tt, o, s_extra);
             const double G = run + (-o_log(u01_oc(o[0], o[1])));
             const double scale = Sd / G;
             for (int b = 0; b < B; ++b) {
@@ -402,7 +404,7 @@ struct Filter {
                 std::vector<uint64_t> locE(nb);
                 uint64_t s = 0;
                 for (int j = 0; j < nb; ++j) {
-                    uint32_t wa, wb; resamp_words(b * TILE + j, tt, &wa, &wb);
+                    uint32_t wa, wb; resamp_words(b * TILE + j, tt, &wa, &wb, s_spacing);
                     const double E = -o_log(u01_oc(wa, wb));
                     s += (uint64_t)std::rint(E * 34359738368.0 /* 2^35 */);
                     locE[j] = s;
@@ -440,22 +442,8 @@ struct Filter {
         return std::min(b * TILE + j, N - 1);
     }
 
-    double step(double y, double zcov) {
-        const bool resampled_prev = (t > 0) && (t % rs == 0);
-        std::vector<double> lw_old(N, 0.0);
-        if (t == 0) {
-            for (int i = 0; i < N; ++i) x[i] = m_init(mc, normal(i, 0));
-        } else {
-            xprev.swap(x);
-            if (resampled_prev) {
-                std::vector<uint64_t> tau; targets(t, tau);
-                for (int i = 0; i < N; ++i) anc[i] = (uint32_t)search(tau[i]);
-                for (int i = 0; i < N; ++i) x[i] = m_prop(mc, xprev[anc[i]], normal(i, t), zcov);
-            } else {
-                for (int i = 0; i < N; ++i) { lw_old[i] = logw[i]; x[i] = m_prop(mc, xprev[i], normal(i, t), zcov); }
-            }
-        }
-        for (int i = 0; i < N; ++i) logw[i] = lw_old[i] + m_logg(mc, y, x[i]);
+    // logw[0..N) -> per-tile maxima, tile-local exact cdf, rescaled tile sums, their prefixes; returns S' 2^-rg
+    double build_cdf() {
         // per-tile NaN-propagating max, tile-local exact cdf
         for (int b = 0; b < B; ++b) {
             double mx = NEG_INF; bool nan = false;
@@ -486,7 +474,26 @@ struct Filter {
             run += Ap[b]; Tincl[b] = run;
         }
         Sint = run;
-        const double Sd = Sint ? std::ldexp((double)Sint, -rshift) : std::numeric_limits<double>::quiet_NaN();
+        return Sint ? std::ldexp((double)Sint, -rshift) : std::numeric_limits<double>::quiet_NaN();
+    }
+
+    double step(double y, double zcov) {
+        const bool resampled_prev = (t > 0) && (t % rs == 0);
+        std::vector<double> lw_old(N, 0.0);
+        if (t == 0) {
+            for (int i = 0; i < N; ++i) x[i] = m_init(mc, normal(i, 0));
+        } else {
+            xprev.swap(x);
+            if (resampled_prev) {
+                std::vector<uint64_t> tau; targets(t, tau);
+                for (int i = 0; i < N; ++i) anc[i] = (uint32_t)search(tau[i]);
+                for (int i = 0; i < N; ++i) x[i] = m_prop(mc, xprev[anc[i]], normal(i, t), zcov);
+            } else {
+                for (int i = 0; i < N; ++i) { lw_old[i] = logw[i]; x[i] = m_prop(mc, xprev[i], normal(i, t), zcov); }
+            }
+        }
+        for (int i = 0; i < N; ++i) logw[i] = lw_old[i] + m_logg(mc, y, x[i]);
+        const double Sd = build_cdf();
         const double lse = m + o_log(Sd);
         last_ll = lse - prev;
         loglik += last_ll;
@@ -582,6 +589,327 @@ double ref_run(int model, const double* th, int N, const double* y, const double
     return (double)loglik;
 }
 
+// ---------------------------------------------------------------------------------------
+// Liu-West filter with covariates, auxiliary-particle form: LWFilterWithCovs::filter,
+// include/ssme/liu_west_filter.h:971-1159; proposal components :1184-1198; shrinkage a = (3d-1)/(2d) :960;
+// model svol_lw_1_par, test/test_liu_west.cpp:82-157 (parameters phi, mu, sigma, rho with transforms
+// logit, null, log, twice_fisher :70; uniform priors :150-157); transforms include/ssme/parameters.h:317-457.
+// Resampling every step (the reference's default schedule rs = 1).
+// ---------------------------------------------------------------------------------------
+constexpr int DP = 4;
+enum { TR_NULL = 0, TR_TWICE_FISHER = 1, TR_LOGIT = 2, TR_LOG = 3 };     // enum order of parameters.h:27
+enum { STREAM_LW_PRIOR = 3 /* and 4 */, STREAM_LW_JIT = 5 /* and 6 */, STREAM_LW_K = 7, STREAM_LW_K_EXTRA = 8,
+       STREAM_GAMMA_K = 80 };
+
+// kernel-matched transforms (libm-free)
+inline double tr_inv(int kind, double tp) {                 // parameters.h inv_trans
+    switch (kind) {
+        case TR_NULL: return tp;
+        case TR_TWICE_FISHER: return (tp >= 0.0) ? 2.0 / (1.0 + o_exp(-tp)) - 1.0 : 1.0 - 2.0 / (1.0 + o_exp(tp));
+        case TR_LOGIT: return (tp >= 0.0) ? 1.0 / (1.0 + o_exp(-tp)) : o_exp(tp) / (1.0 + o_exp(tp));
+        default: return o_exp(tp);
+    }
+}
+inline double tr_fwd(int kind, double p) {                  // parameters.h trans
+    switch (kind) {
+        case TR_NULL: return p;
+        case TR_TWICE_FISHER: return o_log(1.0 + p) - o_log(1.0 - p);
+        case TR_LOGIT: return o_log(p) - o_log(1.0 - p);
+        default: return o_log(p);
+    }
+}
+
+// model callbacks of svol_lw_1_par (kernel form of logGEv as in m_logg with beta = 1)
+inline double lw_logg(double y, double x) {
+    const double hl = 0.5 * x;
+    if (hl < -745.1332191019412) return NEG_INF;
+    return (-hl - HALF_LOG_2PI) - 0.5 * ((y * y) * o_exp(-x));
+}
+inline double lw_propmu(double x, double z, const double* tu) {           // test_liu_west.cpp:93-101
+    double xt = tu[1] + tu[0] * (x - tu[1]);
+    xt = xt + ((z * tu[3]) * tu[2]) * o_exp(-0.5 * x);
+    return xt;
+}
+
+// the DPP reduction tree of one wave (64 lanes): returns what lane 63 holds after the inclusive scan
+inline double wave_tree_sum(const double* v64) {
+    double v[64];
+    std::memcpy(v, v64, sizeof(v));
+    for (int d = 1; d <= 8; d <<= 1) {
+        double n[64];
+        for (int l = 0; l < 64; ++l) n[l] = v[l] + (((l & 15) >= d) ? v[l - d] : 0.0);
+        std::memcpy(v, n, sizeof(v));
+    }
+    {   double n[64];
+        for (int l = 0; l < 64; ++l) { const int row = l >> 4; n[l] = v[l] + ((row == 1 || row == 3) ? v[row * 16 - 1] : 0.0); }
+        std::memcpy(v, n, sizeof(v)); }
+    {   double n[64];
+        for (int l = 0; l < 64; ++l) n[l] = v[l] + ((l >= 32) ? v[31] : 0.0);
+        std::memcpy(v, n, sizeof(v)); }
+    return v[63];
+}
+// canonical sum of one tile (2048 values): fold the upper half onto the lower (u_j = v_j + v_{j+1024}), pair sums,
+// wave tree per 128-element segment of u, the 8 segments in order
+inline double tile_tree_sum(const double* v) {
+    double tot = 0.0;
+    for (int sgm = 0; sgm < 8; ++sgm) {
+        double lanes[64];
+        for (int l = 0; l < 64; ++l) {
+            const int j = sgm * 128 + 2 * l;
+            lanes[l] = (v[j] + v[j + 1024]) + (v[j + 1] + v[j + 1025]);
+        }
+        tot = tot + wave_tree_sum(lanes);
+    }
+    return tot;
+}
+// canonical sum over tiles: 64 lanes each add a contiguous chunk of tiles in order, then the wave tree
+inline double tiles_tree_sum(const double* part, int B) {
+    const int c = (B + 63) / 64;
+    double lanes[64];
+    for (int l = 0; l < 64; ++l) { double a = 0.0; for (int j = l * c; j < (l + 1) * c && j < B; ++j) a = a + part[j]; lanes[l] = a; }
+    return wave_tree_sum(lanes);
+}
+
+struct LWFilter {
+    Filter cdfA, cdfB;                 // reuse the exact-cdf machinery: A = first-stage weights, B = second-stage
+    int N, Npad, B, t;
+    uint32_t key[2], rep;
+    int trans[DP];
+    double lo[DP], hi[DP], a_shrink;
+    std::vector<double> x, th[DP], xr, thr[DP], lw1;     // (x, theta) after stage 2; resampled population; first-stage log-weights
+    std::vector<uint32_t> anc, kidx;
+    double thetabar[DP], L[DP][DP];
+    double loglik, last_ll, lse1;
+
+    void init(int N_, uint64_t seed, uint32_t rep_, const int* tr, const double* lo_, const double* hi_, double delta) {
+        N = N_; rep = rep_;
+        key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32);
+        double dummy[3] = {1.0, 0.5, 0.1};
+        cdfA.init(MODEL_SVOL, N, RESAMP_MULTINOMIAL, 1, seed, rep, dummy);
+        cdfB.init(MODEL_SVOL, N, RESAMP_MULTINOMIAL, 1, seed, rep, dummy);
+        B = cdfA.B; Npad = cdfA.Npad;
+        for (int d = 0; d < DP; ++d) { trans[d] = tr[d]; lo[d] = lo_[d]; hi[d] = hi_[d]; th[d].assign(Npad, 0.0); thr[d].assign(Npad, 0.0); }
+        x.assign(Npad, 0.0); xr.assign(Npad, 0.0); lw1.assign(Npad, 0.0); anc.assign(Npad, 0); kidx.assign(Npad, 0);
+        a_shrink = (3.0 * delta - 1.0) / (2.0 * delta);
+        t = 0; loglik = 0.0; last_ll = 0.0; lse1 = 0.0;
+        for (int d = 0; d < DP; ++d) { thetabar[d] = 0.0; for (int e = 0; e < DP; ++e) L[d][e] = 0.0; }
+    }
+    void words(int idx, int tt, int stream, uint32_t o[4]) const {
+        const uint32_t ctr[4] = {(uint32_t)idx, (uint32_t)tt, rep, (uint32_t)stream};
+        philox4x32_10(ctr, key, o);
+    }
+    void normal2(int idx, int tt, int stream, double* z0, double* z1) const {
+        uint32_t o[4]; words(idx, tt, stream, o);
+        const double rad = std::sqrt(-2.0 * o_log(u01_oc(o[0], o[1])));
+        double sn, cs; o_sincos2pi(u01_co(o[2], o[3]), &sn, &cs);
+        *z0 = rad * cs; *z1 = rad * sn;
+    }
+    double state_normal(int i, int tt) const { double z0, z1; normal2(i >> 1, tt, STREAM_PROP, &z0, &z1); return (i & 1) ? z1 : z0; }
+
+    double step(double y, double z) {
+        const double logN = o_log((double)N);
+        if (t == 0) {
+            // :1103-1122  prior draws, q1Samp, weights (logMuEv - logQ1Ev cancel identically)
+            for (int i = 0; i < N; ++i) {
+                uint32_t o1[4], o2[4]; words(i, 0, STREAM_LW_PRIOR, o1); words(i, 0, STREAM_LW_PRIOR + 1, o2);
+                const double u[DP] = {u01_co(o1[0], o1[1]), u01_co(o1[2], o1[3]), u01_co(o2[0], o2[1]), u01_co(o2[2], o2[3])};
+                double tu[DP];
+                for (int d = 0; d < DP; ++d) { tu[d] = lo[d] + u[d] * (hi[d] - lo[d]); th[d][i] = tr_fwd(trans[d], tu[d]); }
+                x[i] = state_normal(i, 0) * (tu[2] / std::sqrt(1.0 - tu[0] * tu[0]));
+                cdfB.logw[i] = lw_logg(y, x[i]);
+            }
+            const double Sd = cdfB.build_cdf();
+            last_ll = (cdfB.m + o_log(Sd)) - logN;
+        } else {
+            // ---- stage 1: resample (x, theta) by the previous second-stage weights (:91-145 via the exact cdf)
+            std::vector<uint64_t> tau;
+            cdfB.targets(t, tau);
+            for (int i = 0; i < N; ++i) anc[i] = (uint32_t)cdfB.search(tau[i]);
+            std::vector<double> mom[14];
+            for (auto& v : mom) v.assign(Npad, 0.0);
+            for (int i = 0; i < N; ++i) {
+                xr[i] = x[anc[i]];
+                double tt[DP], tu[DP];
+                for (int d = 0; d < DP; ++d) { tt[d] = th[d][anc[i]]; thr[d][i] = tt[d]; tu[d] = tr_inv(trans[d], tt[d]); }
+                // first-stage weight :985-991 (logGEv ignores its parameter argument in this model)
+                lw1[i] = lw_logg(y, lw_propmu(xr[i], z, tu));
+                cdfA.logw[i] = lw1[i];
+                int q = 0;
+                for (int d = 0; d < DP; ++d) mom[q++][i] = tt[d];
+                for (int d = 0; d < DP; ++d) for (int e = 0; e <= d; ++e) mom[q++][i] = tt[d] * tt[e];
+            }
+            const double S1 = cdfA.build_cdf();
+            lse1 = cdfA.m + o_log(S1);
+            // ---- proposal components :1184-1198 (theta-bar, V over the resampled population), Cholesky of (1-a^2) V
+            double sums[14];
+            for (int q = 0; q < 14; ++q) {
+                std::vector<double> part(B);
+                for (int b = 0; b < B; ++b) part[b] = tile_tree_sum(&mom[q][(size_t)b * TILE]);
+                sums[q] = tiles_tree_sum(part.data(), B);
+            }
+            const double invN = 1.0 / (double)N;
+            for (int d = 0; d < DP; ++d) thetabar[d] = sums[d] * invN;
+            double Sig[DP][DP];
+            const double h2 = 1.0 - a_shrink * a_shrink;
+            { int q = DP; for (int d = 0; d < DP; ++d) for (int e = 0; e <= d; ++e) { Sig[d][e] = h2 * (sums[q++] * invN - thetabar[d] * thetabar[e]); } }
+            for (int d = 0; d < DP; ++d) for (int e = 0; e < DP; ++e) L[d][e] = 0.0;
+            for (int j = 0; j < DP; ++j) {
+                double sdiag = Sig[j][j];
+                for (int k = 0; k < j; ++k) sdiag = sdiag - L[j][k] * L[j][k];
+                L[j][j] = (sdiag > 0.0) ? std::sqrt(sdiag) : 0.0;
+                for (int i = j + 1; i < DP; ++i) {
+                    double v = Sig[i][j];
+                    for (int k = 0; k < j; ++k) v = v - L[i][k] * L[j][k];
+                    L[i][j] = (L[j][j] > 0.0) ? v / L[j][j] : 0.0;
+                }
+            }
+            // ---- stage 2: k ~ Categorical(first-stage weights) :1006, jitter :1024-1027, fSamp, second-stage weight :1030-1033
+            cdfA.targets(t, tau, STREAM_LW_K, STREAM_LW_K_EXTRA, STREAM_GAMMA_K);
+            for (int i = 0; i < N; ++i) kidx[i] = (uint32_t)cdfA.search(tau[i]);
+            for (int i = 0; i < N; ++i) {
+                const int k = (int)kidx[i];
+                double e[DP];
+                normal2(i, t, STREAM_LW_JIT, &e[0], &e[1]);
+                normal2(i, t, STREAM_LW_JIT + 1, &e[2], &e[3]);
+                double tn[DP], tu[DP];
+                for (int d = 0; d < DP; ++d) {
+                    const double mm = a_shrink * thr[d][k] + (1.0 - a_shrink) * thetabar[d];
+                    double acc = 0.0;
+                    for (int q = 0; q <= d; ++q) acc = acc + L[d][q] * e[q];
+                    tn[d] = mm + acc;
+                    tu[d] = tr_inv(trans[d], tn[d]);
+                }
+                const double xk = xr[k];
+                const double mean = (tu[1] + tu[0] * (xk - tu[1])) + ((z * tu[3]) * tu[2]) * o_exp(-0.5 * xk);     // fSamp :114-121
+                const double xn = mean + state_normal(i, t) * (tu[2] * std::sqrt(1.0 - tu[3] * tu[3]));
+                x[i] = xn;
+                for (int d = 0; d < DP; ++d) th[d][i] = tn[d];
+                cdfB.logw[i] = lw_logg(y, xn) - lw1[k];
+            }
+            const double S2 = cdfB.build_cdf();
+            // :1047  m1 + log(sum1) + m2 + log(sum2) - 2 m3 - 2 log(sum3), with every old weight = 1 after resampling
+            last_ll = ((cdfB.m + o_log(S2)) + lse1) - 2.0 * logN;
+        }
+        loglik += last_ll;
+        ++t;
+        return last_ll;
+    }
+    // weighted mean of the untransformed parameters under the current second-stage weights
+    void param_means(double* out) const {
+        double den = 0.0, num[DP] = {0, 0, 0, 0};
+        for (int i = 0; i < N; ++i) {
+            const double w = o_exp(cdfB.logw[i] - cdfB.m);
+            den += w;
+            for (int d = 0; d < DP; ++d) num[d] += w * tr_inv(trans[d], th[d][i]);
+        }
+        for (int d = 0; d < DP; ++d) out[d] = num[d] / den;
+    }
+};
+
+// Mode A: reference-faithful Liu-West (mt19937, <random>), double.  Follows liu_west_filter.h:971-1159 step by step,
+// including the quirk at :988 (untransformed theta mixed with transformed theta-bar; harmless: logGEv ignores it).
+// MVNSampler is restated with a Cholesky factor (pf uses an eigen-decomposition square root [pf-recollection];
+// any square root gives the same law); k_gen = discrete_distribution on max-subtracted weights [pf-recollection].
+double lw_ref_run(int N, const int* tr, const double* lo, const double* hi, double delta, const double* y, const double* z, int T,
+                  uint32_t seed, double* per_step, double* means_out) {
+    std::mt19937 gen(seed), rgen(seed ^ 0x9E3779B9u), kgen(seed ^ 0x85EBCA6Bu);
+    std::normal_distribution<double> nd(0.0, 1.0);
+    std::uniform_real_distribution<double> ud(0.0, 1.0);
+    const double a = (3.0 * delta - 1.0) / (2.0 * delta);
+    auto inv = [&](int kind, double tp) {
+        switch (kind) {
+            case TR_NULL: return tp;
+            case TR_TWICE_FISHER: return (tp >= 0.0) ? 2.0 / (1.0 + std::exp(-tp)) - 1.0 : 1.0 - 2.0 / (1.0 + std::exp(tp));
+            case TR_LOGIT: return (tp >= 0.0) ? 1.0 / (1.0 + std::exp(-tp)) : std::exp(tp) / (1.0 + std::exp(tp));
+            default: return std::exp(tp);
+        }
+    };
+    auto fwd = [&](int kind, double p) {
+        switch (kind) {
+            case TR_NULL: return p;
+            case TR_TWICE_FISHER: return std::log(1.0 + p) - std::log(1.0 - p);
+            case TR_LOGIT: return std::log(p) - std::log(1.0 - p);
+            default: return std::log(p);
+        }
+    };
+    auto logg = [&](double yy, double xx) { return evalUnivNormLog<double>(yy, 0.0, std::exp(0.5 * xx)); };
+    std::vector<double> x(N), lw(N, 0.0);
+    std::vector<std::array<double, DP>> th(N);
+    double loglik = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double yt = y[t], zt = z ? z[t] : 0.0;
+        double ll;
+        if (t == 0) {
+            for (int i = 0; i < N; ++i) {
+                double tu[DP];
+                for (int d = 0; d < DP; ++d) { tu[d] = lo[d] + ud(gen) * (hi[d] - lo[d]); th[i][d] = fwd(tr[d], tu[d]); }
+                x[i] = nd(gen) * tu[2] / std::sqrt(1.0 - tu[0] * tu[0]);
+                lw[i] = logg(yt, x[i]);
+            }
+            const double mx = *std::max_element(lw.begin(), lw.end());
+            double se = 0; for (int i = 0; i < N; ++i) se += std::exp(lw[i] - mx);
+            ll = -std::log((double)N) + mx + std::log(se);
+        } else {
+            double tb[DP] = {0, 0, 0, 0}, V[DP][DP] = {};
+            for (int i = 0; i < N; ++i) for (int d = 0; d < DP; ++d) { tb[d] += th[i][d] / N; for (int e = 0; e < DP; ++e) V[d][e] += th[i][d] * th[i][e] / N; }
+            double Lc[DP][DP] = {};
+            const double h2 = 1.0 - a * a;
+            for (int d = 0; d < DP; ++d) for (int e = 0; e < DP; ++e) V[d][e] = h2 * (V[d][e] - tb[d] * tb[e]);
+            for (int j = 0; j < DP; ++j) {
+                double sd = V[j][j]; for (int k = 0; k < j; ++k) sd -= Lc[j][k] * Lc[j][k];
+                Lc[j][j] = sd > 0 ? std::sqrt(sd) : 0.0;
+                for (int i = j + 1; i < DP; ++i) { double v = V[i][j]; for (int k = 0; k < j; ++k) v -= Lc[i][k] * Lc[j][k]; Lc[i][j] = Lc[j][j] > 0 ? v / Lc[j][j] : 0.0; }
+            }
+            std::vector<double> lw1(N), w1(N);
+            double m3 = -INFINITY, m2 = -INFINITY;
+            for (int i = 0; i < N; ++i) {
+                if (lw[i] > m3) m3 = lw[i];
+                double tu[DP]; for (int d = 0; d < DP; ++d) tu[d] = inv(tr[d], th[i][d]);
+                const double mu = tu[1] + tu[0] * (x[i] - tu[1]) + zt * tu[3] * tu[2] * std::exp(-0.5 * x[i]);
+                lw1[i] = lw[i] + logg(yt, mu);
+                if (lw1[i] > m2) m2 = lw1[i];
+            }
+            for (int i = 0; i < N; ++i) w1[i] = std::exp(lw1[i] - m2);
+            std::discrete_distribution<int> kd(w1.begin(), w1.end());
+            std::vector<double> xo = x; auto tho = th; std::vector<double> lwo = lw;
+            double m1 = -INFINITY, s1 = 0, s2 = 0, s3 = 0;
+            for (int i = 0; i < N; ++i) {
+                s2 += std::exp(lw1[i] - m2); s3 += std::exp(lwo[i] - m3);
+                const int k = kd(kgen);
+                double tn[DP], tu[DP], tuo[DP], e[DP];
+                for (int d = 0; d < DP; ++d) e[d] = nd(gen);
+                for (int d = 0; d < DP; ++d) { double acc = 0; for (int q = 0; q <= d; ++q) acc += Lc[d][q] * e[q]; tn[d] = a * tho[k][d] + (1.0 - a) * tb[d] + acc; tu[d] = inv(tr[d], tn[d]); tuo[d] = inv(tr[d], tho[k][d]); }
+                const double xk = xo[k];
+                const double xn = tu[1] + tu[0] * (xk - tu[1]) + zt * tu[3] * tu[2] * std::exp(-0.5 * xk) + nd(gen) * tu[2] * std::sqrt(1.0 - tu[3] * tu[3]);
+                const double muk = tuo[1] + tuo[0] * (xk - tuo[1]) + zt * tuo[3] * tuo[2] * std::exp(-0.5 * xk);
+                x[i] = xn; for (int d = 0; d < DP; ++d) th[i][d] = tn[d];
+                lw[i] = logg(yt, xn) - logg(yt, muk);
+                if (lw[i] > m1) m1 = lw[i];
+            }
+            for (int i = 0; i < N; ++i) s1 += std::exp(lw[i] - m1);
+            ll = m1 + std::log(s1) + m2 + std::log(s2) - 2 * m3 - 2 * std::log(s3);
+        }
+        if (per_step) per_step[t] = ll;
+        loglik += ll;
+        if (t == T - 1 && means_out) {
+            const double mx = *std::max_element(lw.begin(), lw.end());
+            double den = 0, num[DP] = {0, 0, 0, 0};
+            for (int i = 0; i < N; ++i) { const double w = std::exp(lw[i] - mx); den += w; for (int d = 0; d < DP; ++d) num[d] += w * inv(tr[d], th[i][d]); }
+            for (int d = 0; d < DP; ++d) means_out[d] = num[d] / den;
+        }
+        // resample states and parameters (:91-145), weights reset
+        {
+            const double mx = *std::max_element(lw.begin(), lw.end());
+            std::vector<double> w(N); for (int i = 0; i < N; ++i) w[i] = std::exp(lw[i] - mx);
+            std::discrete_distribution<int> dd(w.begin(), w.end());
+            std::vector<double> xn(N); auto tn = th;
+            for (int i = 0; i < N; ++i) { const int j = dd(rgen); xn[i] = x[j]; tn[i] = th[j]; }
+            x.swap(xn); th.swap(tn); std::fill(lw.begin(), lw.end(), 0.0);
+        }
+    }
+    return loglik;
+}
+
 }  // namespace
 
 // =======================================================================================
@@ -651,6 +979,30 @@ double orc_ref_run_series(int model, const double* theta, int N, const double* y
                           uint32_t seed, int use_float, int fast_resampler, double* per_step) {
     return use_float ? ref_run<float>(model, theta, N, y, z, T, seed, fast_resampler, per_step)
                      : ref_run<double>(model, theta, N, y, z, T, seed, fast_resampler, per_step);
+}
+
+// ---- Liu-West ----
+void* orc_lw_create(int N, uint64_t seed, uint32_t rep, const int* trans, const double* lo, const double* hi, double delta) {
+    LWFilter* f = new LWFilter(); f->init(N, seed, rep, trans, lo, hi, delta); return f;
+}
+void orc_lw_destroy(void* h) { delete (LWFilter*)h; }
+double orc_lw_step(void* h, double y, double z) { return ((LWFilter*)h)->step(y, z); }
+double orc_lw_loglik(void* h) { return ((LWFilter*)h)->loglik; }
+void orc_lw_param_means(void* h, double* out) { ((LWFilter*)h)->param_means(out); }
+// state after the last step: x, theta (transformed, [4][N]), second-stage log-weights, k indices, ancestors, theta-bar, L
+void orc_lw_state(void* h, double* x, double* theta, double* logw, uint32_t* kidx, uint32_t* anc, double* thetabar, double* L) {
+    LWFilter* f = (LWFilter*)h;
+    if (x) std::memcpy(x, f->x.data(), sizeof(double) * f->N);
+    if (theta) for (int d = 0; d < DP; ++d) std::memcpy(theta + (size_t)d * f->N, f->th[d].data(), sizeof(double) * f->N);
+    if (logw) std::memcpy(logw, f->cdfB.logw.data(), sizeof(double) * f->N);
+    if (kidx) std::memcpy(kidx, f->kidx.data(), sizeof(uint32_t) * f->N);
+    if (anc) std::memcpy(anc, f->anc.data(), sizeof(uint32_t) * f->N);
+    if (thetabar) std::memcpy(thetabar, f->thetabar, sizeof(double) * DP);
+    if (L) std::memcpy(L, f->L, sizeof(double) * DP * DP);
+}
+double orc_lw_ref_run(int N, const int* trans, const double* lo, const double* hi, double delta, const double* y, const double* z,
+                      int T, uint32_t seed, double* per_step, double* means_out) {
+    return lw_ref_run(N, trans, lo, hi, delta, y, z, T, seed, per_step, means_out);
 }
 
 // replicate aggregation, thread_pool.h:263-268

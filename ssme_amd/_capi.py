@@ -27,6 +27,9 @@ EXPORTS = [
     "ssme_pf_test_copy", "ssme_pf_test_gamma",
     "ssme_pf_strerror", "ssme_pf_last_error",
     "ssme_pf_version",
+    "ssme_lw_create", "ssme_lw_destroy", "ssme_lw_reset", "ssme_lw_step", "ssme_lw_run_series", "ssme_lw_get_per_step",
+    "ssme_lw_get_param_means", "ssme_lw_download_state", "ssme_lw_set_debug", "ssme_lw_last_elapsed_ms",
+    "ssme_lw_last_error",
 ]
 
 
@@ -35,6 +38,14 @@ class Config(C.Structure):
         ("model", C.c_int32), ("n_particles", C.c_int32), ("n_filters", C.c_int32), ("dtype", C.c_int32),
         ("resampler", C.c_int32), ("resamp_sched", C.c_int32), ("seed", C.c_uint64), ("device", C.c_int32),
         ("first_filter_id", C.c_uint32),
+    ]
+
+
+class LwConfig(C.Structure):
+    _fields_ = [
+        ("n_particles", C.c_int32), ("n_filters", C.c_int32), ("seed", C.c_uint64), ("device", C.c_int32),
+        ("first_filter_id", C.c_uint32), ("delta", C.c_double), ("transforms", C.c_int32 * 4),
+        ("prior_lo", C.c_double * 4), ("prior_hi", C.c_double * 4),
     ]
 
 
@@ -88,13 +99,25 @@ def lib():
         L.ssme_pf_test_rescale.argtypes = [C.c_int32, u64p, dp, C.c_int32, u64p, C.c_int64]
         L.ssme_pf_test_copy.argtypes = [C.c_int32, C.c_int64, C.c_int32]
         L.ssme_pf_test_gamma.argtypes = [C.c_int32, C.c_uint64, C.c_uint32, C.c_int32, C.c_double, C.c_int32, dp]
+        L.ssme_lw_create.argtypes = [C.POINTER(LwConfig), C.POINTER(H)]
+        L.ssme_lw_destroy.argtypes = [H]
+        L.ssme_lw_reset.argtypes = [H]
+        L.ssme_lw_step.argtypes = [H, dp, dp, dp]
+        L.ssme_lw_run_series.argtypes = [H, dp, dp, C.c_int32, dp]
+        L.ssme_lw_get_per_step.argtypes = [H, dp, C.c_int32]
+        L.ssme_lw_get_param_means.argtypes = [H, dp]
+        L.ssme_lw_download_state.argtypes = [H, C.c_int32, dp, dp, u32p, u32p, dp, dp]
+        L.ssme_lw_set_debug.argtypes = [H, C.c_int32]
+        L.ssme_lw_last_elapsed_ms.argtypes = [H, C.POINTER(C.c_float)]
+        L.ssme_lw_last_error.restype = C.c_char_p
+        L.ssme_lw_last_error.argtypes = [H]
         L.ssme_pf_strerror.restype = C.c_char_p
         L.ssme_pf_strerror.argtypes = [C.c_int]
         L.ssme_pf_last_error.restype = C.c_char_p
         L.ssme_pf_last_error.argtypes = [H]
         L.ssme_pf_version.restype = C.c_int
         for name in EXPORTS:
-            if name not in ("ssme_pf_strerror", "ssme_pf_last_error", "ssme_pf_version"):
+            if name not in ("ssme_pf_strerror", "ssme_pf_last_error", "ssme_pf_version", "ssme_lw_last_error"):
                 getattr(L, name).restype = C.c_int
         _lib = L
     return _lib

@@ -1,0 +1,568 @@
+// lw_kernels.h -- Liu-West filter (auxiliary-particle form with covariates) for gfx950.
+//
+// Replaces LWFilterWithCovs::filter (include/ssme/liu_west_filter.h:971-1159) with the model callbacks of
+// svol_lw_1_par (test/test_liu_west.cpp:82-157), update_parameter_proposal_components (:1184-1198), the
+// multinomial resampler of states and parameters (:91-145) and the inverse parameter transforms
+// (include/ssme/parameters.h:317-457, evaluated per dimension by enum instead of polymorphic objects).
+// Resampling every step (the reference's default schedule).  One time step t >= 1 is three launches:
+//   k_lw_stage1 : resample (x, theta) by the previous second-stage weights (exact integer cdf B, search in LDS,
+//                 gather) -> first-stage weight logG(y, propMu(x, z, theta)) -> cdf A; tile partial sums of the
+//                 14 moments of the transformed parameters
+//   k_lw_mid    : one block per filter: theta-bar, V, Cholesky factor of (1 - a^2) V; log-sum-exp of stage 1
+//   k_lw_stage2 : k ~ Categorical(first-stage weights) (cdf A) -> shrink + jitter theta -> fSamp ->
+//                 second-stage weight -> cdf B
+// Layout: x[R][Npad], theta[R][4][Npad] (transformed space, structure of arrays), fp64.
+#pragma once
+#include "pf_kernels.h"
+
+namespace ssme {
+
+constexpr int kDP = 4;             // phi, mu, sigma, rho
+constexpr int kLwNT = 512;         // threads per 2048-particle tile (2 pairs per thread)
+constexpr int kNMom = 14;          // 4 means + 10 second moments
+enum { TR_NULL = 0, TR_TWICE_FISHER = 1, TR_LOGIT = 2, TR_LOG = 3 };      // enum order of parameters.h:27
+enum { STREAM_LW_PRIOR = 3 /* and 4 */, STREAM_LW_JIT = 5 /* and 6 */, STREAM_LW_K = 7, STREAM_LW_K_EXTRA = 8,
+       STREAM_GAMMA_K = 80 };
+
+struct LwScalars {
+    double mB, SB;       // level-2 of the second-stage weights of the last step
+    double lse1;         // log-sum-exp of the first-stage weights of the last step
+    double loglik, last_ll;
+    double pad[3];
+};
+
+struct LwArgs {
+    double* xB; double* thB;                    // [R][Npad], [R][4][Npad]: population after stage 2 (pre-resampling)
+    double* xr; double* thr; double* lw1;       // resampled population and its first-stage log-weights
+    double *cdfA, *tsumA, *tmaxA;               // exact integer cdf of the first-stage weights
+    double *cdfB, *tsumB, *tmaxB;               // ... of the second-stage weights
+    double* mom;                                // [R][B][16] tile partial sums of the 14 moments
+    double* prop;                               // [R][16]: theta-bar[4], L (lower triangle, row-major)[10]
+    uint32_t *anc, *kidx;                       // debug: resampling ancestors / k indices, or null
+    LwScalars* scal;
+    const double *y, *z;
+    double* per_step;
+    const double *gamB, *pgamB, *gtotB;         // Gamma tables of the resampling draw   (stream base 16)
+    const double *gamA, *pgamA, *gtotA;         // Gamma tables of the k draw            (stream base 80)
+    int32_t N, Npad, B, Bs, Bpow2, rshift, R;
+    int32_t t, yi, gi, Tcap;
+    int32_t finalize_prev;                      // stage 1 accounts log p(y_{t-1} | .) (series mode); 0 in step mode
+    uint32_t key0, key1, first_filter;
+    double logN, a_shrink;
+    int32_t trans[kDP];
+    double lo[kDP], hi[kDP];
+};
+
+// ---- parameter transforms (parameters.h inv_trans / trans), libm-free ------------------------------------
+// `kind` is uniform (a kernel argument), so the switch is a scalar branch; exp(-|tp|) serves both signs.
+__device__ __forceinline__ double tr_inv(int kind, double tp) {
+    if (kind == TR_NULL) return tp;
+    if (kind == TR_LOG) return dexp(tp);
+    const double t = dexp((tp >= 0.0) ? -tp : tp);
+    const double den = 1.0 + t;
+    if (kind == TR_LOGIT) return (tp >= 0.0) ? 1.0 / den : t / den;
+    return (tp >= 0.0) ? 2.0 / den - 1.0 : 1.0 - 2.0 / den;
+}
+__device__ __forceinline__ double tr_fwd(int kind, double p) {
+    switch (kind) {
+        case TR_NULL: return p;
+        case TR_TWICE_FISHER: return dlog(1.0 + p) - dlog(1.0 - p);
+        case TR_LOGIT: return dlog(p) - dlog(1.0 - p);
+        default: return dlog(p);
+    }
+}
+// model callbacks of svol_lw_1_par
+__device__ __forceinline__ double lw_logg(double y, double x) {                // test_liu_west.cpp:132-136, kernel form
+    const double hl = 0.5 * x;
+    double v = (-hl - SSME_HALF_LOG_2PI) - 0.5 * ((y * y) * dexp(-x));
+    if (hl < -745.1332191019412) v = -dinf();
+    return v;
+}
+__device__ __forceinline__ double lw_propmu(double x, double z, const double (&tu)[kDP]) {    // :93-101
+    double xt = tu[1] + tu[0] * (x - tu[1]);
+    xt = xt + ((z * tu[3]) * tu[2]) * dexp(-0.5 * x);
+    return xt;
+}
+
+// ---------------------------------------------------------------------------------------
+// Shared selection: indices idx[k][c] = #{j : C_j < tau} for this tile's sorted-uniform targets against the exact
+// integer cdf (tile sums tsum / maxima tmax / tile-local cdf).  Same arithmetic as k_filter_step.
+// Returns the level-2 results m (global max log-weight) and S (integer weight sum).  Block = 512 threads.
+// ---------------------------------------------------------------------------------------
+struct LwLds {
+    double* lds_T; double* lds_R; double* lds_stage;     // dynamic LDS
+    double* seg_a; double* seg_l2; double* d1; int* cnt;
+};
+
+__device__ __forceinline__ void lw_select(const double* tsum, const double* tmax, const double* cdf, int B, int Bpow2, int rshift,
+                                          int N, int b, double gam, double pgam, double pgam_next, double G, int spacing_stream,
+                                          uint32_t t, uint32_t rep, uint32_t k0, uint32_t k1, const LwLds& L, int (&idx)[2][2],
+                                          double& m_out, double& S_out) {
+    constexpr int NT = kLwNT, NK = 2, NE = 4;
+    const int tid = threadIdx.x;
+    const int i_first = b * kTile;
+    double A2[NE], M2[NE];
+    level2_load<NT>(tsum, tmax, B, A2, M2);
+    if (tid == 0) { L.cnt[0] = 0; L.cnt[1] = 0; }
+    double Ap[NE], Tinc[NE], m, S;
+    level2_scan<NT>(A2, M2, B, rshift, m, Ap, Tinc, S, L.d1, L.seg_l2);
+    m_out = m; S_out = S;
+    const double t_scale = S / G;
+    const double t_lo = __builtin_ceil(pgam * t_scale);
+    const double t_hi = __builtin_ceil(pgam_next * t_scale) + (S * 0x1.0p-40 + 2.0);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        if (e * NT < Bpow2) {
+            const int j = e * NT + tid;
+            if (j < Bpow2) {
+                L.lds_T[j] = (j < B) ? Tinc[e] : dinf();
+                L.lds_R[j] = (j < B) ? A2[e] / Ap[e] : 0.0;
+            }
+            const int w_lo = __popcll(__ballot(j < B && Tinc[e] < t_lo));
+            const int w_hi = __popcll(__ballot(j < B && Tinc[e] < t_hi));
+            if ((tid & 63) == 0) { if (w_lo) atomicAdd(&L.cnt[0], w_lo); if (w_hi) atomicAdd(&L.cnt[1], w_hi); }
+        }
+    }
+    __syncthreads();
+    int lo = L.cnt[0], hi = L.cnt[1];
+    lo = lo < B - 1 ? lo : B - 1;
+    hi = hi < B - 1 ? hi : B - 1;
+    const int bb_min = __builtin_amdgcn_readfirstlane(lo);
+    const int span = __builtin_amdgcn_readfirstlane(hi) - bb_min + 1;
+    double2 stg0[NK], stg1[NK], stg2[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { stg0[k] = make_double2(0.0, 0.0); stg1[k] = stg0[k]; stg2[k] = stg0[k]; }
+    if (span <= kStageTiles) {
+        const double* src = cdf + (size_t)bb_min * kTile + tid * 2;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) stg0[k] = *reinterpret_cast<const double2*>(src + k * NT * 2);
+        if (span >= 2) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) stg1[k] = *reinterpret_cast<const double2*>(src + kTile + k * NT * 2);
+        }
+        if (span >= 3) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) stg2[k] = *reinterpret_cast<const double2*>(src + 2 * kTile + k * NT * 2);
+        }
+    }
+    // exponential spacings (liu_west_filter.h:105-139), exact tile scan; hides the tile loads
+    double qe[NK][2], le[NK][2], se;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int i0 = i_first + (k * NT + tid) * 2;
+        const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), t, rep, (uint32_t)spacing_stream, k0, k1);
+        const double e0 = -dlog_pn(u01_oc(o.v0, o.v1)), e1 = -dlog_pn(u01_oc(o.v2, o.v3));
+        qe[k][0] = (i0 < N) ? __builtin_rint(e0 * 34359738368.0) : 0.0;
+        qe[k][1] = (i0 + 1 < N) ? __builtin_rint(e1 * 34359738368.0) : 0.0;
+    }
+    block_scan_f64<NT>(qe, le, se, L.seg_a);
+    const double ratio = gam / se;
+    double tau[NK][2];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double t1 = ratio * le[k][c];
+            const double t2 = pgam + t1;
+            tau[k][c] = __builtin_ceil(t2 * t_scale);
+        }
+    }
+    if (span <= kStageTiles) {
+        double* dst = L.lds_stage + tid * 2;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) *reinterpret_cast<double2*>(dst + k * NT * 2) = stg0[k];
+        if (span >= 2) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) *reinterpret_cast<double2*>(dst + kTile + k * NT * 2) = stg1[k];
+        }
+        if (span >= 3) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) *reinterpret_cast<double2*>(dst + 2 * kTile + k * NT * 2) = stg2[k];
+        }
+        const int b1 = bb_min + 1 < B ? bb_min + 1 : B - 1, b2 = bb_min + 2 < B ? bb_min + 2 : B - 1;
+        const double T0 = L.lds_T[bb_min];
+        const double T1 = (bb_min + 1 < B) ? L.lds_T[bb_min + 1] : dinf();
+        const double Pm = bb_min ? L.lds_T[bb_min - 1] : 0.0;
+        const double R0 = L.lds_R[bb_min], R1 = L.lds_R[b1], R2 = L.lds_R[b2];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            int sel_prev = -1, j_prev = 0;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const double target = tau[k][c];
+                int sel = (T0 < target ? 1 : 0) + (T1 < target ? 1 : 0);
+                sel = sel < span - 1 ? sel : span - 1;
+                const double Pb = sel == 0 ? Pm : (sel == 1 ? T0 : T1);
+                const double Rb = sel == 0 ? R0 : (sel == 1 ? R1 : R2);
+                const double tloc = __builtin_ceil((target - Pb) * Rb);
+                const double* tile = L.lds_stage + sel * kTile;
+                int j;
+                if (c == 1 && sel == sel_prev) j = count_less_gallop(tile, tloc, j_prev);
+                else j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
+                sel_prev = sel; j_prev = j;
+                int a = (bb_min + sel) * kTile + j;
+                idx[k][c] = a < N - 1 ? a : N - 1;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const double target = tau[k][c];
+                int bb = count_less_pow2(Bpow2, target, [&](int j) { return L.lds_T[j]; });
+                bb = bb < B - 1 ? bb : B - 1;
+                const double Pb = bb ? L.lds_T[bb - 1] : 0.0;
+                const double tloc = __builtin_ceil((target - Pb) * L.lds_R[bb]);
+                const double* tile = cdf + (size_t)bb * kTile;
+                const int j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
+                int a = bb * kTile + j;
+                idx[k][c] = a < N - 1 ? a : N - 1;
+            }
+        }
+    }
+}
+
+// log-weights lg[k][c] of this tile -> tile max, fixed-point weights, exact tile scan; stores cdf / tile sum / tile max
+__device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int N, int i_first, double* cdf_row, double* tsum_row,
+                                             double* tmax_row, int b, double* lds_d, double* lds_seg) {
+    constexpr int NT = kLwNT, NK = 2;
+    const int tid = threadIdx.x;
+    double mx = -dinf();
+    bool nan = false;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int i = i_first + (k * NT + tid) * 2 + c;
+            if (i < N) { const double l = lg[k][c]; nan = nan || (l != l); mx = (l > mx) ? l : mx; }
+        }
+    }
+    const double mb = block_max_nanprop<NT>(mx, nan, lds_d);
+    double q[NK][2], inc[NK][2], total;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int i0 = i_first + (k * NT + tid) * 2;
+        q[k][0] = (i0 < N) ? __builtin_rint(dexp_scaled(lg[k][0] - mb, kTileShift)) : 0.0;
+        q[k][1] = (i0 + 1 < N) ? __builtin_rint(dexp_scaled(lg[k][1] - mb, kTileShift)) : 0.0;
+    }
+    block_scan_f64<NT>(q, inc, total, lds_seg);
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+        *reinterpret_cast<double2*>(cdf_row + i_first + (k * NT + tid) * 2) = make_double2(inc[k][0], inc[k][1]);
+    if (tid == 0) { tsum_row[b] = total; tmax_row[b] = mb; }
+}
+
+#define LW_LDS_SETUP(a)                                                                                   \
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                                  \
+    const int nT2 = (a).Bpow2 < 2 ? 2 : (a).Bpow2;                                                        \
+    __shared__ double lds_seg_a[16];                                                                      \
+    __shared__ double lds_seg_l2[64];                                                                     \
+    __shared__ double lds_seg_c[16];                                                                      \
+    __shared__ double lds_d1[16];                                                                         \
+    __shared__ double lds_d2[16];                                                                         \
+    __shared__ int lds_cnt[2];                                                                            \
+    LwLds L;                                                                                              \
+    L.lds_T = reinterpret_cast<double*>(smem); L.lds_R = L.lds_T + nT2; L.lds_stage = L.lds_T + 2 * nT2;  \
+    L.seg_a = lds_seg_a; L.seg_l2 = lds_seg_l2; L.d1 = lds_d1; L.cnt = lds_cnt;
+
+// ---------------------------------------------------------------------------------------
+// t = 0: prior draws, q1Samp, weights (liu_west_filter.h:1103-1122).  grid = (B, R), block = 512
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kLwNT) void k_lw_init(const LwArgs a) {
+    constexpr int NT = kLwNT, NK = 2;
+    __shared__ double lds_seg_c[16];
+    __shared__ double lds_d2[16];
+    const int tid = threadIdx.x, b = blockIdx.x, r = blockIdx.y;
+    const uint32_t rep = a.first_filter + (uint32_t)r;
+    const size_t rowoff = (size_t)r * a.Npad;
+    const double y = a.y[a.yi];
+    const int i_first = b * kTile;
+    double lg[NK][2];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int i0 = i_first + (k * NT + tid) * 2;
+        double zn[2];
+        normal_pair((uint32_t)(i0 >> 1), 0u, rep, a.key0, a.key1, &zn[0], &zn[1]);
+        double xo[2], tho[kDP][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int i = i0 + c;
+            const u32x4 o1 = philox4x32_10((uint32_t)i, 0u, rep, STREAM_LW_PRIOR, a.key0, a.key1);
+            const u32x4 o2 = philox4x32_10((uint32_t)i, 0u, rep, STREAM_LW_PRIOR + 1, a.key0, a.key1);
+            const double u[kDP] = {u01_co(o1.v0, o1.v1), u01_co(o1.v2, o1.v3), u01_co(o2.v0, o2.v1), u01_co(o2.v2, o2.v3)};
+            double tu[kDP];
+#pragma unroll
+            for (int d = 0; d < kDP; ++d) { tu[d] = a.lo[d] + u[d] * (a.hi[d] - a.lo[d]); tho[d][c] = tr_fwd(a.trans[d], tu[d]); }
+            xo[c] = zn[c] * (tu[2] / dsqrt(1.0 - tu[0] * tu[0]));
+            lg[k][c] = lw_logg(y, xo[c]);
+            if (i >= a.N) { xo[c] = 0.0; lg[k][c] = -dinf(); for (int d = 0; d < kDP; ++d) tho[d][c] = 0.0; }
+        }
+        *reinterpret_cast<double2*>(a.xB + rowoff + i0) = make_double2(xo[0], xo[1]);
+#pragma unroll
+        for (int d = 0; d < kDP; ++d)
+            *reinterpret_cast<double2*>(a.thB + ((size_t)r * kDP + d) * a.Npad + i0) = make_double2(tho[d][0], tho[d][1]);
+    }
+    lw_store_cdf(lg, a.N, i_first, a.cdfB + rowoff, a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, b, lds_d2, lds_seg_c);
+}
+
+// ---------------------------------------------------------------------------------------
+// Stage 1 (t >= 1).  grid = (B, R), block = 512, dynamic LDS as k_filter_step
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
+    constexpr int NT = kLwNT, NK = 2;
+    LW_LDS_SETUP(a)
+    __shared__ double lds_mom[8][kNMom];
+    const int tid = threadIdx.x, b = blockIdx.x, r = blockIdx.y;
+    const uint32_t rep = a.first_filter + (uint32_t)r;
+    const size_t rowoff = (size_t)r * a.Npad;
+    const double y = a.y[a.yi], z = a.z ? a.z[a.yi] : 0.0;
+    const int i_first = b * kTile;
+    const size_t gidx = ((size_t)a.gi * a.R + r) * a.B + b;
+    const double G = a.gtotB[(size_t)a.gi * a.R + r];
+    const double pgam_next = (b + 1 < a.B) ? a.pgamB[gidx + 1] : G;
+
+    // resample (x, theta) by the previous second-stage weights: liu_west_filter.h:91-145 via the exact cdf
+    int anc[NK][2];
+    double mB, SB;
+    lw_select(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.cdfB + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
+              a.gamB[gidx], a.pgamB[gidx], pgam_next, G, STREAM_RESAMP, (uint32_t)a.t, rep, a.key0, a.key1, L, anc, mB, SB);
+    if (b == 0 && tid == 0 && a.finalize_prev) {
+        // log p(y_{t-1} | y_{1:t-2}): :1047 with all old weights equal after resampling; :1136 at t-1 = 0
+        LwScalars* sc = a.scal + r;
+        const double Sd = (SB > 0.0) ? dldexp(SB, -a.rshift) : dnan();
+        const double lseB = mB + dlog(Sd);
+        const double ll = (a.t == 1) ? lseB - a.logN : (lseB + sc->lse1) - 2.0 * a.logN;
+        sc->mB = mB; sc->SB = SB; sc->last_ll = ll; sc->loglik = sc->loglik + ll;
+        if (a.per_step) a.per_step[(size_t)r * a.Tcap + (a.t - 1)] = ll;
+    }
+    double lg[NK][2];
+    const double* xB = a.xB + rowoff;
+    double fold[kNMom][2];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int i0 = i_first + (k * NT + tid) * 2;
+        double xo[2], tt[kDP][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int j = anc[k][c];
+            xo[c] = xB[j];
+#pragma unroll
+            for (int d = 0; d < kDP; ++d) tt[d][c] = a.thB[((size_t)r * kDP + d) * a.Npad + j];
+            if (a.anc && i0 + c < a.N) a.anc[rowoff + i0 + c] = (uint32_t)j;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            double tu[kDP];
+#pragma unroll
+            for (int d = 0; d < kDP; ++d) tu[d] = tr_inv(a.trans[d], tt[d][c]);
+            lg[k][c] = lw_logg(y, lw_propmu(xo[c], z, tu));          // first-stage weight, :985-991
+            const bool valid = (i0 + c) < a.N;
+            if (!valid) { xo[c] = 0.0; lg[k][c] = -dinf(); }
+            // moments of the transformed parameters (:1189-1193); canonical tree: fold the tile halves (k), then the pair (c)
+            int q = 0;
+#pragma unroll
+            for (int d = 0; d < kDP; ++d) { const double v = valid ? tt[d][c] : 0.0; fold[q][c] = (k == 0) ? v : fold[q][c] + v; ++q; }
+#pragma unroll
+            for (int d = 0; d < kDP; ++d) {
+#pragma unroll
+                for (int e = 0; e <= d; ++e) { const double v = valid ? tt[d][c] * tt[e][c] : 0.0; fold[q][c] = (k == 0) ? v : fold[q][c] + v; ++q; }
+            }
+        }
+        *reinterpret_cast<double2*>(a.xr + rowoff + i0) = make_double2(xo[0], xo[1]);
+        *reinterpret_cast<double2*>(a.lw1 + rowoff + i0) = make_double2(lg[k][0], lg[k][1]);
+#pragma unroll
+        for (int d = 0; d < kDP; ++d)
+            *reinterpret_cast<double2*>(a.thr + ((size_t)r * kDP + d) * a.Npad + i0) = make_double2(tt[d][0], tt[d][1]);
+    }
+    // wave tree per 128-element segment of the folded half tile, then the 8 segments in order
+#pragma unroll
+    for (int q = 0; q < kNMom; ++q) {
+        const double s = wave_incl_scan_f64(fold[q][0] + fold[q][1]);
+        if ((tid & 63) == 63) lds_mom[tid >> 6][q] = s;
+    }
+    lw_store_cdf(lg, a.N, i_first, a.cdfA + rowoff, a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, b, lds_d2, lds_seg_c);
+    // (lw_store_cdf contains barriers after the lds_mom writes)
+    if (tid < kNMom) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s = s + lds_mom[w][tid];
+        a.mom[((size_t)r * a.B + b) * 16 + tid] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Mid: proposal components (:1184-1198) + log-sum-exp of the first-stage weights.  grid = (R), block = 256
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_lw_mid(const LwArgs a) {
+    __shared__ double lds_seg[128];
+    __shared__ double lds_d[16];
+    __shared__ double sums[kNMom];
+    const int tid = threadIdx.x, r = blockIdx.x;
+    double A2[8], Ap[8], Tinc[8], M2[8], S, m;
+    level2_load<kThreads>(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.B, A2, M2);
+    level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
+    // moment totals: wave w handles moments w, w+4, ...: 64 lanes add contiguous chunks of tiles in order, then the wave tree
+    const int lane = tid & 63, wave = tid >> 6;
+    const int c = (a.B + 63) / 64;
+    for (int q = wave; q < kNMom; q += 4) {
+        double acc = 0.0;
+        for (int j = lane * c; j < (lane + 1) * c && j < a.B; ++j) acc = acc + a.mom[((size_t)r * a.B + j) * 16 + q];
+        const double s = wave_incl_scan_f64(acc);
+        if (lane == 63) sums[q] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        LwScalars* sc = a.scal + r;
+        const double Sd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
+        sc->lse1 = m + dlog(Sd);
+        const double invN = 1.0 / (double)a.N;
+        double tb[kDP], Sig[kDP][kDP], Lc[kDP][kDP];
+        for (int d = 0; d < kDP; ++d) tb[d] = sums[d] * invN;
+        const double h2 = 1.0 - a.a_shrink * a.a_shrink;
+        int q = kDP;
+        for (int d = 0; d < kDP; ++d) for (int e = 0; e <= d; ++e) { Sig[d][e] = h2 * (sums[q] * invN - tb[d] * tb[e]); ++q; }
+        for (int d = 0; d < kDP; ++d) for (int e = 0; e < kDP; ++e) Lc[d][e] = 0.0;
+        for (int j = 0; j < kDP; ++j) {
+            double sdiag = Sig[j][j];
+            for (int k = 0; k < j; ++k) sdiag = sdiag - Lc[j][k] * Lc[j][k];
+            Lc[j][j] = (sdiag > 0.0) ? dsqrt(sdiag) : 0.0;
+            for (int i = j + 1; i < kDP; ++i) {
+                double v = Sig[i][j];
+                for (int k = 0; k < j; ++k) v = v - Lc[i][k] * Lc[j][k];
+                Lc[i][j] = (Lc[j][j] > 0.0) ? v / Lc[j][j] : 0.0;
+            }
+        }
+        double* p = a.prop + (size_t)r * 16;
+        for (int d = 0; d < kDP; ++d) p[d] = tb[d];
+        q = kDP;
+        for (int d = 0; d < kDP; ++d) for (int e = 0; e <= d; ++e) p[q++] = Lc[d][e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Stage 2 (t >= 1).  grid = (B, R), block = 512
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
+    constexpr int NT = kLwNT, NK = 2;
+    LW_LDS_SETUP(a)
+    const int tid = threadIdx.x, b = blockIdx.x, r = blockIdx.y;
+    const uint32_t rep = a.first_filter + (uint32_t)r;
+    const size_t rowoff = (size_t)r * a.Npad;
+    const double y = a.y[a.yi], z = a.z ? a.z[a.yi] : 0.0;
+    const int i_first = b * kTile;
+    const size_t gidx = ((size_t)a.gi * a.R + r) * a.B + b;
+    const double G = a.gtotA[(size_t)a.gi * a.R + r];
+    const double pgam_next = (b + 1 < a.B) ? a.pgamA[gidx + 1] : G;
+    double prop[16];
+#pragma unroll
+    for (int q = 0; q < 14; ++q) prop[q] = a.prop[(size_t)r * 16 + q];
+
+    // k ~ Categorical(first-stage weights): k_gen.sample, :1006
+    int kk[NK][2];
+    double mA, SA;
+    lw_select(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.cdfA + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
+              a.gamA[gidx], a.pgamA[gidx], pgam_next, G, STREAM_LW_K, (uint32_t)a.t, rep, a.key0, a.key1, L, kk, mA, SA);
+    double lg[NK][2];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int i0 = i_first + (k * NT + tid) * 2;
+        double zs[2];
+        normal_pair((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, a.key0, a.key1, &zs[0], &zs[1]);
+        double xo[2], tho[kDP][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int i = i0 + c;
+            const int j = kk[k][c];
+            const double xk = a.xr[rowoff + j];
+            const double lw1k = a.lw1[rowoff + j];
+            double e[kDP];
+            {
+                const u32x4 o1 = philox4x32_10((uint32_t)i, (uint32_t)a.t, rep, STREAM_LW_JIT, a.key0, a.key1);
+                const double rad1 = dsqrt(-2.0 * dlog_pn(u01_oc(o1.v0, o1.v1)));
+                double sn, cs;
+                dsincos2pi(u01_co(o1.v2, o1.v3), &sn, &cs);
+                e[0] = rad1 * cs; e[1] = rad1 * sn;
+                const u32x4 o2 = philox4x32_10((uint32_t)i, (uint32_t)a.t, rep, STREAM_LW_JIT + 1, a.key0, a.key1);
+                const double rad2 = dsqrt(-2.0 * dlog_pn(u01_oc(o2.v0, o2.v1)));
+                dsincos2pi(u01_co(o2.v2, o2.v3), &sn, &cs);
+                e[2] = rad2 * cs; e[3] = rad2 * sn;
+            }
+            double tu[kDP];
+            int q = kDP;
+#pragma unroll
+            for (int d = 0; d < kDP; ++d) {
+                const double thk = a.thr[((size_t)r * kDP + d) * a.Npad + j];
+                const double mm = a.a_shrink * thk + (1.0 - a.a_shrink) * prop[d];      // :1024
+                double acc = 0.0;
+#pragma unroll
+                for (int w = 0; w <= d; ++w) { acc = acc + prop[q] * e[w]; ++q; }
+                tho[d][c] = mm + acc;                                                    // MVN draw, :1026-1027
+                tu[d] = tr_inv(a.trans[d], tho[d][c]);
+            }
+            const double mean = (tu[1] + tu[0] * (xk - tu[1])) + ((z * tu[3]) * tu[2]) * dexp(-0.5 * xk);       // fSamp :114-121
+            xo[c] = mean + zs[c] * (tu[2] * dsqrt(1.0 - tu[3] * tu[3]));
+            lg[k][c] = lw_logg(y, xo[c]) - lw1k;                                         // :1032-1033
+            if (a.kidx && i < a.N) a.kidx[rowoff + i] = (uint32_t)j;
+            if (i >= a.N) { xo[c] = 0.0; lg[k][c] = -dinf(); }
+        }
+        *reinterpret_cast<double2*>(a.xB + rowoff + i0) = make_double2(xo[0], xo[1]);
+#pragma unroll
+        for (int d = 0; d < kDP; ++d)
+            *reinterpret_cast<double2*>(a.thB + ((size_t)r * kDP + d) * a.Npad + i0) = make_double2(tho[d][0], tho[d][1]);
+    }
+    lw_store_cdf(lg, a.N, i_first, a.cdfB + rowoff, a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, b, lds_d2, lds_seg_c);
+}
+
+// ---------------------------------------------------------------------------------------
+// Accounts the last step's log conditional likelihood.  grid = (R), block = 256
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_lw_finalize(const LwArgs a) {
+    __shared__ double lds_seg[128];
+    __shared__ double lds_d[16];
+    const int tid = threadIdx.x, r = blockIdx.x;
+    double A2[8], Ap[8], Tinc[8], M2[8], S, m;
+    level2_load<kThreads>(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.B, A2, M2);
+    level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
+    if (tid == 0) {
+        LwScalars* sc = a.scal + r;
+        const double Sd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
+        const double lseB = m + dlog(Sd);
+        const double ll = (a.t == 0) ? lseB - a.logN : (lseB + sc->lse1) - 2.0 * a.logN;
+        sc->mB = m; sc->SB = S; sc->last_ll = ll; sc->loglik = sc->loglik + ll;
+        if (a.per_step) a.per_step[(size_t)r * a.Tcap + a.t] = ll;
+    }
+}
+
+// weighted means of the untransformed parameters under the last second-stage weights.  grid = (R), block = 256
+__global__ __launch_bounds__(kThreads) void k_lw_param_means(const LwArgs a, double* out /*[R][4]*/) {
+    __shared__ double lds_n[4][kDP + 1];
+    __shared__ double lds_m[16];
+    const int tid = threadIdx.x, r = blockIdx.x;
+    double mx = -dinf();
+    bool nan = false;
+    for (int j = tid; j < a.B; j += kThreads) { const double v = a.tmaxB[(size_t)r * a.Bs + j]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
+    const double m = block_max_nanprop<kThreads>(mx, nan, lds_m);
+    double acc[kDP + 1] = {0, 0, 0, 0, 0};
+    for (int i = tid; i < a.N; i += kThreads) {
+        const double c1 = a.cdfB[(size_t)r * a.Npad + i];
+        const double c0 = (i & (kTile - 1)) ? a.cdfB[(size_t)r * a.Npad + i - 1] : 0.0;
+        const double w = (c1 - c0) * dexp(a.tmaxB[(size_t)r * a.Bs + i / kTile] - m);
+        acc[kDP] += w;
+        for (int d = 0; d < kDP; ++d) acc[d] += w * tr_inv(a.trans[d], a.thB[((size_t)r * kDP + d) * a.Npad + i]);
+    }
+    for (int q = 0; q <= kDP; ++q) {
+        double v = acc[q];
+        for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, kWave);
+        if ((tid & 63) == 0) lds_n[tid >> 6][q] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t[kDP + 1];
+        for (int q = 0; q <= kDP; ++q) t[q] = ((lds_n[0][q] + lds_n[1][q]) + lds_n[2][q]) + lds_n[3][q];
+        for (int d = 0; d < kDP; ++d) out[(size_t)r * kDP + d] = t[d] / t[kDP];
+    }
+}
+
+}  // namespace ssme

@@ -3,6 +3,7 @@
 // No torch types; no CPU fallback: without a HIP device every call fails with SSME_ERR_HIP.
 #include "../../include/ssme_pf.h"
 #include "pf_kernels.h"
+#include "lw_kernels.h"
 
 #include <cmath>
 #include <cstdio>
@@ -156,9 +157,9 @@ static void launch_gamma(ssme_pf_handle h, int t0, int nT) {
     if (h->cfg.resampler != SSME_RESAMP_MULTINOMIAL) return;
     const uint32_t k0 = (uint32_t)h->cfg.seed, k1 = (uint32_t)(h->cfg.seed >> 32);
     hipLaunchKernelGGL(k_gamma_draw, dim3((h->B + kThreads - 1) / kThreads, nT, h->R), dim3(kThreads), 0, h->stream,
-                       h->gam, h->N, h->B, h->R, t0, k0, k1, h->cfg.first_filter_id);
+                       h->gam, h->N, h->B, h->R, t0, k0, k1, h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA);
     hipLaunchKernelGGL(k_gamma_prefix, dim3((nT * h->R + kThreads - 1) / kThreads), dim3(kThreads), 0, h->stream,
-                       h->gam, h->pgam, h->gtot, h->B, h->R, nT, t0, k0, k1, h->cfg.first_filter_id);
+                       h->gam, h->pgam, h->gtot, h->B, h->R, nT, t0, k0, k1, h->cfg.first_filter_id, (uint32_t)STREAM_RESAMP_EXTRA);
 }
 // accounts the log conditional likelihood of step t from the buffers the step wrote (now `cur`)
 static void launch_kf(ssme_pf_handle h, int t, bool record_per_step) {
@@ -740,5 +741,294 @@ done:
     if (d) hipFree(d);
     return rc;
 }
+
+}  // extern "C"
+
+// =============================================================================================
+// Liu-West filter (LWFilterWithCovs, include/ssme/liu_west_filter.h:971-1159)
+// =============================================================================================
+struct ssme_lw_s {
+    ssme_lw_config cfg;
+    int N, R, Npad, B, Bs, Bpow2, rshift;
+    size_t lds_bytes;
+    int t, debug;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    float last_ms;
+    double *xB, *thB, *xr, *thr, *lw1, *cdfA, *tsumA, *tmaxA, *cdfB, *tsumB, *tmaxB, *mom, *prop;
+    double *ybuf, *zbuf, *per_step, *scratch;
+    double *gamA, *pgamA, *gtotA, *gamB, *pgamB, *gtotB;
+    uint32_t *anc, *kidx;
+    LwScalars* scal;
+    int ycap, tcap, gcap;
+    std::string err;
+};
+
+static int lw_fail(ssme_lw_handle h, const char* what, hipError_t e) {
+    if (h) h->err = std::string(what) + ": " + hipGetErrorString(e);
+    return SSME_ERR_HIP;
+}
+#define LWCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return lw_fail(h, #call, e_); } while (0)
+
+static LwArgs lw_args(ssme_lw_handle h) {
+    LwArgs a{};
+    a.xB = h->xB; a.thB = h->thB; a.xr = h->xr; a.thr = h->thr; a.lw1 = h->lw1;
+    a.cdfA = h->cdfA; a.tsumA = h->tsumA; a.tmaxA = h->tmaxA; a.cdfB = h->cdfB; a.tsumB = h->tsumB; a.tmaxB = h->tmaxB;
+    a.mom = h->mom; a.prop = h->prop;
+    a.anc = (h->debug & 1) ? h->anc : nullptr; a.kidx = (h->debug & 1) ? h->kidx : nullptr;
+    a.scal = h->scal; a.y = h->ybuf; a.z = h->zbuf; a.per_step = nullptr;
+    a.gamA = h->gamA; a.pgamA = h->pgamA; a.gtotA = h->gtotA; a.gamB = h->gamB; a.pgamB = h->pgamB; a.gtotB = h->gtotB;
+    a.N = h->N; a.Npad = h->Npad; a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = h->R;
+    a.Tcap = h->tcap;
+    a.key0 = (uint32_t)h->cfg.seed; a.key1 = (uint32_t)(h->cfg.seed >> 32); a.first_filter = h->cfg.first_filter_id;
+    a.logN = dlog((double)h->N);
+    a.a_shrink = (3.0 * h->cfg.delta - 1.0) / (2.0 * h->cfg.delta);          // liu_west_filter.h:960
+    for (int d = 0; d < kDP; ++d) { a.trans[d] = h->cfg.transforms[d]; a.lo[d] = h->cfg.prior_lo[d]; a.hi[d] = h->cfg.prior_hi[d]; }
+    return a;
+}
+
+static int lw_ensure_capacity(ssme_lw_handle h, int T) {
+    if (T > h->ycap) {
+        if (h->ybuf) hipFree(h->ybuf);
+        if (h->zbuf) hipFree(h->zbuf);
+        LWCHK(hipMalloc(&h->ybuf, sizeof(double) * T));
+        LWCHK(hipMalloc(&h->zbuf, sizeof(double) * T));
+        LWCHK(hipMemset(h->zbuf, 0, sizeof(double) * T));
+        h->ycap = T;
+    }
+    if (T > h->gcap) {
+        double** tabs[] = {&h->gamA, &h->pgamA, &h->gtotA, &h->gamB, &h->pgamB, &h->gtotB};
+        for (auto t : tabs) { if (*t) hipFree(*t); *t = nullptr; }
+        const size_t nb = sizeof(double) * (size_t)T * h->R * h->B, nr = sizeof(double) * (size_t)T * h->R;
+        LWCHK(hipMalloc(&h->gamA, nb)); LWCHK(hipMalloc(&h->pgamA, nb)); LWCHK(hipMalloc(&h->gtotA, nr));
+        LWCHK(hipMalloc(&h->gamB, nb)); LWCHK(hipMalloc(&h->pgamB, nb)); LWCHK(hipMalloc(&h->gtotB, nr));
+        h->gcap = T;
+    }
+    if (T > h->tcap) {
+        if (h->per_step) hipFree(h->per_step);
+        LWCHK(hipMalloc(&h->per_step, sizeof(double) * (size_t)T * h->R));
+        h->tcap = T;
+    }
+    return SSME_OK;
+}
+
+// Gamma tables of both draws for time indices t0 .. t0+nT-1 into rows 0 .. nT-1
+static void lw_launch_gamma(ssme_lw_handle h, int t0, int nT) {
+    const uint32_t k0 = (uint32_t)h->cfg.seed, k1 = (uint32_t)(h->cfg.seed >> 32);
+    const dim3 g1((h->B + kThreads - 1) / kThreads, nT, h->R), g2((nT * h->R + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(k_gamma_draw, g1, dim3(kThreads), 0, h->stream, h->gamB, h->N, h->B, h->R, t0, k0, k1,
+                       h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA);
+    hipLaunchKernelGGL(k_gamma_prefix, g2, dim3(kThreads), 0, h->stream, h->gamB, h->pgamB, h->gtotB, h->B, h->R, nT, t0, k0, k1,
+                       h->cfg.first_filter_id, (uint32_t)STREAM_RESAMP_EXTRA);
+    hipLaunchKernelGGL(k_gamma_draw, g1, dim3(kThreads), 0, h->stream, h->gamA, h->N, h->B, h->R, t0, k0, k1,
+                       h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA_K);
+    hipLaunchKernelGGL(k_gamma_prefix, g2, dim3(kThreads), 0, h->stream, h->gamA, h->pgamA, h->gtotA, h->B, h->R, nT, t0, k0, k1,
+                       h->cfg.first_filter_id, (uint32_t)STREAM_LW_K_EXTRA);
+}
+
+static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record, bool finalize_prev) {
+    LwArgs a = lw_args(h);
+    a.t = t; a.yi = yi; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
+    a.per_step = record ? h->per_step : nullptr;
+    const dim3 grid(h->B, h->R);
+    if (t == 0) {
+        hipLaunchKernelGGL(k_lw_init, grid, dim3(kLwNT), 0, h->stream, a);
+    } else {
+        hipLaunchKernelGGL(k_lw_stage1, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
+        hipLaunchKernelGGL(k_lw_mid, dim3(h->R), dim3(kThreads), 0, h->stream, a);
+        hipLaunchKernelGGL(k_lw_stage2, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
+    }
+}
+static void lw_enqueue_finalize(ssme_lw_handle h, int t, bool record) {
+    LwArgs a = lw_args(h);
+    a.t = t;
+    a.per_step = record ? h->per_step : nullptr;
+    hipLaunchKernelGGL(k_lw_finalize, dim3(h->R), dim3(kThreads), 0, h->stream, a);
+}
+
+static int lw_reset(ssme_lw_handle h) {
+    std::vector<LwScalars> sc(h->R);
+    for (auto& s : sc) std::memset(&s, 0, sizeof(s));
+    LWCHK(hipMemcpyAsync(h->scal, sc.data(), sizeof(LwScalars) * h->R, hipMemcpyHostToDevice, h->stream));
+    LWCHK(hipStreamSynchronize(h->stream));
+    h->t = 0;
+    return SSME_OK;
+}
+
+extern "C" {
+
+int ssme_lw_destroy(ssme_lw_handle h) {
+    if (!h) return SSME_ERR_INVALID_ARG;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->xB, h->thB, h->xr, h->thr, h->lw1, h->cdfA, h->tsumA, h->tmaxA, h->cdfB, h->tsumB, h->tmaxB, h->mom, h->prop,
+                    h->ybuf, h->zbuf, h->per_step, h->scratch, h->gamA, h->pgamA, h->gtotA, h->gamB, h->pgamB, h->gtotB, h->anc,
+                    h->kidx, h->scal};
+    for (void* p : bufs) if (p) hipFree(p);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return SSME_OK;
+}
+
+int ssme_lw_create(const ssme_lw_config* cfg, ssme_lw_handle* out) {
+    if (!cfg || !out) return SSME_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->n_particles < 1 || cfg->n_filters < 1 || cfg->n_filters > 65535) return SSME_ERR_INVALID_ARG;
+    if (!(cfg->delta > 0.0 && cfg->delta <= 1.0)) return SSME_ERR_INVALID_ARG;
+    for (int d = 0; d < kDP; ++d) {
+        if (cfg->transforms[d] < 0 || cfg->transforms[d] > 3) return SSME_ERR_INVALID_ARG;     // parameters.h:283 invalid_argument
+        if (!(cfg->prior_lo[d] <= cfg->prior_hi[d])) return SSME_ERR_INVALID_ARG;
+    }
+    const int B = (cfg->n_particles + kTile - 1) / kTile;
+    if (B > kMaxTilesPerFilter) return SSME_ERR_UNSUPPORTED;
+    ssme_lw_handle h = new (std::nothrow) ssme_lw_s();
+    if (!h) return SSME_ERR_INVALID_ARG;
+    h->cfg = *cfg;
+    h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * kTile;
+    h->Bs = (B + 1) & ~1; h->Bpow2 = next_pow2(B);
+    h->rshift = 52 - ceil_log2(h->Npad);
+    h->lds_bytes = sizeof(double) * (2 * (size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2) + (size_t)kStageTiles * kTile);
+    if (hipSetDevice(cfg->device) != hipSuccess) { delete h; return SSME_ERR_HIP; }
+    int rc = [&]() -> int {
+        LWCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        LWCHK(hipEventCreate(&h->ev0));
+        LWCHK(hipEventCreate(&h->ev1));
+        const size_t np = (size_t)h->R * h->Npad, nb = (size_t)h->R * h->Bs;
+        double** big[] = {&h->xB, &h->xr, &h->lw1, &h->cdfA, &h->cdfB};
+        for (auto p : big) { LWCHK(hipMalloc(p, sizeof(double) * np)); LWCHK(hipMemset(*p, 0, sizeof(double) * np)); }
+        double** big4[] = {&h->thB, &h->thr};
+        for (auto p : big4) { LWCHK(hipMalloc(p, sizeof(double) * np * kDP)); LWCHK(hipMemset(*p, 0, sizeof(double) * np * kDP)); }
+        double** small[] = {&h->tsumA, &h->tmaxA, &h->tsumB, &h->tmaxB};
+        for (auto p : small) { LWCHK(hipMalloc(p, sizeof(double) * nb)); LWCHK(hipMemset(*p, 0, sizeof(double) * nb)); }
+        LWCHK(hipMalloc(&h->mom, sizeof(double) * (size_t)h->R * h->B * 16));
+        LWCHK(hipMalloc(&h->prop, sizeof(double) * (size_t)h->R * 16));
+        LWCHK(hipMemset(h->prop, 0, sizeof(double) * (size_t)h->R * 16));
+        LWCHK(hipMalloc(&h->scal, sizeof(LwScalars) * h->R));
+        LWCHK(hipMalloc(&h->scratch, sizeof(double) * h->R * kDP));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        int rc2 = lw_ensure_capacity(h, 1);
+        if (rc2 != SSME_OK) return rc2;
+        return lw_reset(h);
+    }();
+    if (rc != SSME_OK) { ssme_lw_destroy(h); return rc; }
+    *out = h;
+    return SSME_OK;
+}
+
+int ssme_lw_reset(ssme_lw_handle h) {
+    if (!h) return SSME_ERR_INVALID_ARG;
+    LWCHK(hipSetDevice(h->cfg.device));
+    return lw_reset(h);
+}
+
+int ssme_lw_set_debug(ssme_lw_handle h, int32_t flags) {
+    if (!h) return SSME_ERR_INVALID_ARG;
+    LWCHK(hipSetDevice(h->cfg.device));
+    if ((flags & 1) && !h->anc) {
+        LWCHK(hipMalloc(&h->anc, sizeof(uint32_t) * (size_t)h->R * h->Npad));
+        LWCHK(hipMalloc(&h->kidx, sizeof(uint32_t) * (size_t)h->R * h->Npad));
+        LWCHK(hipMemset(h->anc, 0, sizeof(uint32_t) * (size_t)h->R * h->Npad));
+        LWCHK(hipMemset(h->kidx, 0, sizeof(uint32_t) * (size_t)h->R * h->Npad));
+    }
+    h->debug = flags;
+    return SSME_OK;
+}
+
+int ssme_lw_step(ssme_lw_handle h, const double* y, const double* z, double* out) {
+    if (!h || !y) return SSME_ERR_INVALID_ARG;
+    LWCHK(hipSetDevice(h->cfg.device));
+    const double z0 = z ? *z : 0.0;
+    LWCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    LWCHK(hipMemcpyAsync(h->zbuf, &z0, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h->t > 0) lw_launch_gamma(h, h->t, 1);
+    lw_enqueue_step(h, h->t, 0, 0, false, /*finalize_prev=*/false);
+    lw_enqueue_finalize(h, h->t, false);          // the step API accounts each step right away
+    LWCHK(hipGetLastError());
+    std::vector<LwScalars> sc(h->R);
+    LWCHK(hipMemcpyAsync(sc.data(), h->scal, sizeof(LwScalars) * h->R, hipMemcpyDeviceToHost, h->stream));
+    LWCHK(hipStreamSynchronize(h->stream));
+    if (out) for (int r = 0; r < h->R; ++r) out[r] = sc[r].last_ll;
+    h->t += 1;
+    return SSME_OK;
+}
+
+int ssme_lw_run_series(ssme_lw_handle h, const double* y, const double* z, int32_t T, double* loglik_out) {
+    if (!h || !y) return SSME_ERR_INVALID_ARG;
+    if (T < 1) return SSME_ERR_LENGTH;
+    LWCHK(hipSetDevice(h->cfg.device));
+    int rc = lw_ensure_capacity(h, T);
+    if (rc != SSME_OK) return rc;
+    LWCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    if (z) LWCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    else LWCHK(hipMemsetAsync(h->zbuf, 0, sizeof(double) * T, h->stream));
+    rc = lw_reset(h);
+    if (rc != SSME_OK) return rc;
+    LWCHK(hipEventRecord(h->ev0, h->stream));
+    lw_launch_gamma(h, 0, T);
+    for (int t = 0; t < T; ++t) lw_enqueue_step(h, t, t, t, true, /*finalize_prev=*/t > 0);
+    lw_enqueue_finalize(h, T - 1, true);
+    LWCHK(hipEventRecord(h->ev1, h->stream));
+    LWCHK(hipGetLastError());
+    h->t = T;
+    std::vector<LwScalars> sc(h->R);
+    LWCHK(hipMemcpyAsync(sc.data(), h->scal, sizeof(LwScalars) * h->R, hipMemcpyDeviceToHost, h->stream));
+    LWCHK(hipStreamSynchronize(h->stream));
+    LWCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    if (loglik_out) for (int r = 0; r < h->R; ++r) loglik_out[r] = sc[r].loglik;
+    return SSME_OK;
+}
+
+int ssme_lw_get_per_step(ssme_lw_handle h, double* out, int32_t T) {
+    if (!h || !out || T < 1 || T > h->tcap) return SSME_ERR_INVALID_ARG;
+    LWCHK(hipSetDevice(h->cfg.device));
+    for (int r = 0; r < h->R; ++r)
+        LWCHK(hipMemcpyAsync(out + (size_t)r * T, h->per_step + (size_t)r * h->tcap, sizeof(double) * T, hipMemcpyDeviceToHost, h->stream));
+    LWCHK(hipStreamSynchronize(h->stream));
+    return SSME_OK;
+}
+
+int ssme_lw_get_param_means(ssme_lw_handle h, double* out) {
+    if (!h || !out) return SSME_ERR_INVALID_ARG;
+    if (h->t < 1) return SSME_ERR_STATE;
+    LWCHK(hipSetDevice(h->cfg.device));
+    LwArgs a = lw_args(h);
+    hipLaunchKernelGGL(k_lw_param_means, dim3(h->R), dim3(kThreads), 0, h->stream, a, h->scratch);
+    LWCHK(hipGetLastError());
+    LWCHK(hipMemcpyAsync(out, h->scratch, sizeof(double) * h->R * kDP, hipMemcpyDeviceToHost, h->stream));
+    LWCHK(hipStreamSynchronize(h->stream));
+    return SSME_OK;
+}
+
+int ssme_lw_download_state(ssme_lw_handle h, int32_t f, double* x, double* theta, uint32_t* kidx, uint32_t* anc, double* thetabar,
+                           double* chol) {
+    if (!h || f < 0 || f >= h->R) return SSME_ERR_INVALID_ARG;
+    LWCHK(hipSetDevice(h->cfg.device));
+    const size_t off = (size_t)f * h->Npad;
+    if (x) LWCHK(hipMemcpyAsync(x, h->xB + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (theta) for (int d = 0; d < kDP; ++d)
+        LWCHK(hipMemcpyAsync(theta + (size_t)d * h->N, h->thB + ((size_t)f * kDP + d) * h->Npad, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (kidx || anc) {
+        if (!h->anc) return SSME_ERR_STATE;
+        if (kidx) LWCHK(hipMemcpyAsync(kidx, h->kidx + off, sizeof(uint32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
+        if (anc) LWCHK(hipMemcpyAsync(anc, h->anc + off, sizeof(uint32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
+    }
+    double p[16];
+    LWCHK(hipMemcpyAsync(p, h->prop + (size_t)f * 16, sizeof(p), hipMemcpyDeviceToHost, h->stream));
+    LWCHK(hipStreamSynchronize(h->stream));
+    if (thetabar) for (int d = 0; d < kDP; ++d) thetabar[d] = p[d];
+    if (chol) { int q = kDP; for (int d = 0; d < kDP; ++d) for (int e = 0; e < kDP; ++e) chol[d * kDP + e] = (e <= d) ? p[q++] : 0.0; }
+    return SSME_OK;
+}
+
+int ssme_lw_last_elapsed_ms(ssme_lw_handle h, float* ms) {
+    if (!h || !ms) return SSME_ERR_INVALID_ARG;
+    *ms = h->last_ms;
+    return SSME_OK;
+}
+
+const char* ssme_lw_last_error(ssme_lw_handle h) { return h ? h->err.c_str() : ""; }
 
 }  // extern "C"

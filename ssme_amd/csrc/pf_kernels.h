@@ -311,12 +311,13 @@ __device__ __forceinline__ void normal_pair_angle(double rad, double u2, double*
 }
 
 // Gamma(shape) draw, Marsaglia & Tsang (2000), attempts driven by the Philox counter
-__device__ __forceinline__ double gamma_draw(uint32_t b, uint32_t t, uint32_t rep, uint32_t k0, uint32_t k1, double shape) {
+__device__ __forceinline__ double gamma_draw(uint32_t b, uint32_t t, uint32_t rep, uint32_t k0, uint32_t k1, double shape,
+                                             uint32_t stream_base = STREAM_GAMMA) {
     const double d = shape - 0.3333333333333333;
     const double c = 1.0 / dsqrt(9.0 * d);
     for (int a = 0; a < 32; ++a) {
-        const u32x4 o1 = philox4x32_10(b, t, rep, (uint32_t)(STREAM_GAMMA + 2 * a), k0, k1);
-        const u32x4 o2 = philox4x32_10(b, t, rep, (uint32_t)(STREAM_GAMMA + 2 * a + 1), k0, k1);
+        const u32x4 o1 = philox4x32_10(b, t, rep, stream_base + 2 * a, k0, k1);
+        const u32x4 o2 = philox4x32_10(b, t, rep, stream_base + 2 * a + 1, k0, k1);
         const double rad = dsqrt(-2.0 * dlog_pn(u01_oc(o1.v0, o1.v1)));
         double sn, cs;
         dsincos2pi(u01_co(o1.v2, o1.v3), &sn, &cs);
@@ -797,16 +798,18 @@ __global__ __launch_bounds__(kThreads) void kf_finalize(const StepArgs a) {
 // k_gamma_draw: grid = (ceil(B/256), nT, R).  k_gamma_prefix: one thread per (ti, r).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_gamma_draw(double* gam, int N, int B, int R, int t0, uint32_t key0,
-                                                         uint32_t key1, uint32_t first_filter) {
+                                                         uint32_t key1, uint32_t first_filter, uint32_t gamma_stream) {
     const int b = blockIdx.x * kThreads + threadIdx.x;
     const int ti = blockIdx.y, r = blockIdx.z;
     if (b >= B) return;
     const int nb = (N - b * kTile) < kTile ? (N - b * kTile) : kTile;
-    gam[((size_t)ti * R + r) * B + b] = gamma_draw((uint32_t)b, (uint32_t)(t0 + ti), first_filter + (uint32_t)r, key0, key1, (double)nb);
+    gam[((size_t)ti * R + r) * B + b] = gamma_draw((uint32_t)b, (uint32_t)(t0 + ti), first_filter + (uint32_t)r, key0, key1, (double)nb,
+                                                   gamma_stream);
 }
 
 __global__ __launch_bounds__(kThreads) void k_gamma_prefix(const double* gam, double* pgam, double* gtot, int B, int R,
-                                                           int nT, int t0, uint32_t key0, uint32_t key1, uint32_t first_filter) {
+                                                           int nT, int t0, uint32_t key0, uint32_t key1, uint32_t first_filter,
+                                                           uint32_t extra_stream) {
     const int id = blockIdx.x * kThreads + threadIdx.x;
     if (id >= nT * R) return;
     const int ti = id / R, r = id % R;
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(kThreads) void k_gamma_prefix(const double* gam, do
     double* p = pgam + (size_t)id * B;
     double run = 0.0;
     for (int b = 0; b < B; ++b) { p[b] = run; run = run + g[b]; }
-    const u32x4 ox = philox4x32_10(0u, (uint32_t)(t0 + ti), first_filter + (uint32_t)r, STREAM_RESAMP_EXTRA, key0, key1);
+    const u32x4 ox = philox4x32_10(0u, (uint32_t)(t0 + ti), first_filter + (uint32_t)r, extra_stream, key0, key1);
     gtot[id] = run + (-dlog_pn(u01_oc(ox.v0, ox.v1)));
 }
 

@@ -16,7 +16,8 @@ from . import _capi as capi
 from ._capi import (MODEL_LIN_GAUSS, MODEL_SVOL, MODEL_SVOL_LEVERAGE, RESAMP_MULTINOMIAL, RESAMP_MULTINOMIAL_IID,
                     RESAMP_STRATIFIED, RESAMP_SYSTEMATIC, SsmeError)
 
-__all__ = ["ParticleFilterBank", "svol_bs", "svol_leverage", "lin_gauss_bs", "log_like_eval",
+__all__ = ["ParticleFilterBank", "svol_bs", "svol_leverage", "lin_gauss_bs", "log_like_eval", "svol_lw_1_par",
+           "TR_NULL", "TR_TWICE_FISHER", "TR_LOGIT", "TR_LOG",
            "MODEL_SVOL", "MODEL_SVOL_LEVERAGE", "MODEL_LIN_GAUSS", "RESAMP_MULTINOMIAL", "RESAMP_SYSTEMATIC",
            "RESAMP_STRATIFIED", "RESAMP_MULTINOMIAL_IID", "SsmeError"]
 
@@ -211,3 +212,95 @@ def log_like_eval(untrans_theta, data, nparts=500, num_pfilters=1, seed=0, resam
     finally:
         if own:
             bank.close()
+
+
+# ---- Liu-West -------------------------------------------------------------------------------------------------
+TR_NULL, TR_TWICE_FISHER, TR_LOGIT, TR_LOG = 0, 1, 2, 3        # include/ssme/parameters.h:27
+
+
+class svol_lw_1_par:
+    """test/test_liu_west.cpp:22-157: Liu-West filter (auxiliary form, with covariates) for the SVOL-leverage model.
+
+    Ctor arguments as the reference's: delta, then the uniform prior bounds of phi, mu, sigma, rho.  Methods:
+    filter(y, z), getLogCondLike(), getParamSamples() (transformed parameters, as param::pack::get_trans_params),
+    plus run_series / param_means for whole-series use.  n_filters independent filters share one handle.
+    """
+
+    def __init__(self, delta, phi_l, phi_u, mu_l, mu_u, sig_l, sig_u, rho_l, rho_u, dte=0, nparts=10, n_filters=1, seed=0,
+                 device=0, first_filter_id=0, transforms=(TR_LOGIT, TR_NULL, TR_LOG, TR_TWICE_FISHER)):
+        self._h = C.c_void_p()
+        self.n, self.r = int(nparts), int(n_filters)
+        cfg = capi.LwConfig(n_particles=nparts, n_filters=n_filters, seed=seed, device=device, first_filter_id=first_filter_id,
+                            delta=delta)
+        cfg.transforms[:] = list(transforms)
+        cfg.prior_lo[:] = [phi_l, mu_l, sig_l, rho_l]
+        cfg.prior_hi[:] = [phi_u, mu_u, sig_u, rho_u]
+        capi.check(capi.lib().ssme_lw_create(C.byref(cfg), C.byref(self._h)))
+        self._last = np.zeros(self.r)
+        self._T = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            capi.lib().ssme_lw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _chk(self, status):
+        if status != capi.OK:
+            msg = capi.lib().ssme_pf_strerror(status).decode()
+            if status == capi.ERR_HIP:
+                msg += " (" + capi.lib().ssme_lw_last_error(self._h).decode() + ")"
+            raise SsmeError(status, msg)
+
+    def set_debug(self, on=True):
+        self._chk(capi.lib().ssme_lw_set_debug(self._h, 1 if on else 0))
+
+    def reset(self):
+        self._chk(capi.lib().ssme_lw_reset(self._h))
+
+    def filter(self, y, z=0.0):
+        yv = np.array([float(np.ravel(y)[0])])
+        zv = np.array([float(np.ravel(z)[0])])
+        out = np.empty(self.r)
+        self._chk(capi.lib().ssme_lw_step(self._h, capi.dptr(yv), capi.dptr(zv), capi.dptr(out)))
+        self._last = out
+
+    def getLogCondLike(self):
+        return float(self._last[0]) if self.r == 1 else self._last.copy()
+
+    def run_series(self, y, z=None):
+        yv = capi.as_f64(y)
+        zv = None if z is None else capi.as_f64(z)
+        out = np.empty(self.r)
+        self._chk(capi.lib().ssme_lw_run_series(self._h, capi.dptr(yv), capi.dptr(zv), yv.size, capi.dptr(out)))
+        self._T = yv.size
+        return out
+
+    def per_step(self):
+        out = np.empty((self.r, self._T))
+        self._chk(capi.lib().ssme_lw_get_per_step(self._h, capi.dptr(out), self._T))
+        return out
+
+    def param_means(self):
+        out = np.empty((self.r, 4))
+        self._chk(capi.lib().ssme_lw_get_param_means(self._h, capi.dptr(out)))
+        return out
+
+    def state(self, f=0, indices=False):
+        n = self.n
+        x, th = np.empty(n), np.empty((4, n))
+        k = np.empty(n, dtype=np.uint32) if indices else None
+        a = np.empty(n, dtype=np.uint32) if indices else None
+        tb, L = np.empty(4), np.empty((4, 4))
+        self._chk(capi.lib().ssme_lw_download_state(self._h, f, capi.dptr(x), capi.dptr(th), capi.u32ptr(k), capi.u32ptr(a),
+                                                    capi.dptr(tb), capi.dptr(L)))
+        return dict(x=x, theta=th, kidx=k, anc=a, thetabar=tb, L=L)
+
+    def getParamSamples(self, f=0):
+        return self.state(f)["theta"]
+
+    def last_elapsed_ms(self):
+        ms = C.c_float()
+        self._chk(capi.lib().ssme_lw_last_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value

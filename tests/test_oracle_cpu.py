@@ -248,3 +248,66 @@ def test_oracle_full_series_golden(oracle, golden, spy):
         assert ll == golden[f"svol_{tname}_n500_full_ll"][0]
         np.testing.assert_array_equal(per, golden[f"svol_{tname}_n500_full_per"])
     assert len(spy) == 3084
+
+
+# ---- Liu-West oracle (liu_west_filter.h:971-1159 restated; test_liu_west.cpp model) --------------------------------
+def _sim_leverage(T, phi, mu, sig, rho, seed):
+    rng = np.random.default_rng(seed)
+    x, y = np.zeros(T), np.zeros(T)
+    x[0] = mu + sig / np.sqrt(1 - phi * phi) * rng.normal()
+    y[0] = np.exp(x[0] / 2) * rng.normal()
+    for t in range(1, T):
+        x[t] = (mu + phi * (x[t - 1] - mu) + rho * sig * y[t - 1] * np.exp(-x[t - 1] / 2)
+                + sig * np.sqrt(1 - rho * rho) * rng.normal())
+        y[t] = np.exp(x[t] / 2) * rng.normal()
+    return y, np.concatenate([[0.0], y[:-1]])
+
+
+def test_liu_west_mode_a_vs_mode_b(oracle):
+    """The kernel-matched Liu-West oracle (Philox, exact cdf) and the reference-faithful restatement (mt19937,
+    discrete_distribution) estimate the same log-likelihood and posterior means within Monte-Carlo error."""
+    y, z = _sim_leverage(120, 0.95, 0.0, 0.05, -0.3, 4)
+    n, reps = 4000, 6
+    la, ma = [], []
+    for s in range(reps):
+        ll, per, means = oracle.lw_ref_run(n, y, z, seed=100 + s)
+        assert np.isfinite(ll) and abs(per.sum() - ll) < 1e-9
+        la.append(ll); ma.append(means)
+    lb, mb = [], []
+    for s in range(reps):
+        f = oracle.LWFilter(n, 7, rep=s)
+        lb.append(sum(f.step(y[t], z[t]) for t in range(y.size)))
+        mb.append(f.param_means())
+    la, lb, ma, mb = np.array(la), np.array(lb), np.array(ma), np.array(mb)
+    se = np.sqrt(la.var(ddof=1) / reps + lb.var(ddof=1) / reps)
+    assert abs(la.mean() - lb.mean()) < 4 * se + 0.3
+    sem = np.sqrt(ma.var(0, ddof=1) / reps + mb.var(0, ddof=1) / reps)
+    assert np.all(np.abs(ma.mean(0) - mb.mean(0)) < 4 * sem + [0.01, 0.01, 0.005, 0.03])
+    # parameters stay inside the support the transforms impose (test_liu_west.cpp:165 priors)
+    assert np.all((mb[:, 0] > 0) & (mb[:, 0] < 1) & (mb[:, 2] > 0) & (np.abs(mb[:, 3]) < 1))
+
+
+def test_liu_west_oracle_deterministic_and_replicates_differ(oracle):
+    y, z = _sim_leverage(10, 0.95, 0.0, 0.05, -0.3, 5)
+    def run(rep):
+        f = oracle.LWFilter(700, 3, rep=rep)
+        return [f.step(y[t], z[t]) for t in range(y.size)], f.state()
+    a, sa_ = run(0); b, sb = run(0); c, _ = run(1)
+    assert a == b and a != c
+    assert np.array_equal(sa_["kidx"], sb["kidx"]) and np.array_equal(sa_["anc"], sb["anc"])
+    assert sa_["kidx"].max() < 700 and sa_["anc"].max() < 700
+    assert np.all(np.diff(sa_["anc"].astype(np.int64)) >= 0)        # sorted-uniform multinomial draws come out ordered
+    L = sa_["L"]
+    assert np.all(np.diag(L) > 0) and np.allclose(np.triu(L, 1), 0)
+
+
+def test_liu_west_delta_one_freezes_parameters(oracle):
+    """delta = 1 => a = 1, h^2 = 0: no shrinkage and no jitter, parameters are only resampled (liu_west_filter.h:960,1195)."""
+    y, z = _sim_leverage(5, 0.95, 0.0, 0.05, -0.3, 6)
+    f = oracle.LWFilter(500, 9, delta=1.0)
+    f.step(y[0], z[0])
+    th0 = f.state()["theta"].copy()
+    f.step(y[1], z[1])
+    s = f.state()
+    for d in range(4):
+        assert set(np.unique(s["theta"][d]).tolist()) <= set(np.unique(th0[d]).tolist())

@@ -411,3 +411,91 @@ def test_max_tiles_per_filter(sa, spy):
     st = bank.state(0, ancestors=True)
     assert st["anc"].max() < n and (np.diff(st["anc"].astype(np.int64)) >= 0).all()   # systematic: sorted
     bank.close()
+
+
+# ---- Liu-West filter --------------------------------------------------
+def _lw_series(T, seed=3):
+    rng = np.random.default_rng(seed)
+    y = rng.normal(0.0, 0.02, T)
+    z = np.concatenate([[0.0], y[:-1]])            # lagged return as the covariate (test_liu_west.cpp usage)
+    return y, z
+
+
+@pytest.mark.parametrize("n", [100, 2048, 5000, 40000])
+def test_liu_west_bit_exact_vs_oracle(sa, oracle, n):
+    """Every step: particles, transformed parameters, the k-draw and resampling indices, theta-bar, the Cholesky
+    factor and the log conditional likelihood are bit-identical to the oracle's kernel-matched Liu-West filter."""
+    T = 6
+    y, z = _lw_series(T)
+    g = sa.svol_lw_1_par(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, seed=77)
+    g.set_debug(True)
+    o = oracle.LWFilter(n, 77, rep=0, delta=0.99)
+    for t in range(T):
+        g.filter(y[t], z[t])
+        lo = o.step(y[t], z[t])
+        sg, so = g.state(0, indices=True), o.state()
+        assert_bits_equal(sg["x"], so["x"], f"LW x t={t}")
+        assert_bits_equal(sg["theta"], so["theta"], f"LW theta t={t}")
+        if t > 0:
+            np.testing.assert_array_equal(sg["anc"], so["anc"], err_msg=f"LW ancestors t={t}")
+            np.testing.assert_array_equal(sg["kidx"], so["kidx"], err_msg=f"LW k t={t}")
+            assert_bits_equal(sg["thetabar"], so["thetabar"], f"LW thetabar t={t}")
+            assert_bits_equal(np.tril(sg["L"]), np.tril(so["L"]), f"LW chol t={t}")
+        assert_bits_equal([g.getLogCondLike()], [lo], f"LW logcondlike t={t}")
+    # convenience reduction outside filter(): summation order differs (strided block sum vs sequential), fp64 tolerance
+    np.testing.assert_allclose(g.param_means()[0], o.param_means(), rtol=1e-12, atol=0)
+    g.close()
+
+
+def test_liu_west_series_equals_steps_and_replicates(sa, oracle):
+    n, T, R = 3000, 12, 3
+    y, z = _lw_series(T, seed=5)
+    g = sa.svol_lw_1_par(0.95, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, n_filters=R, seed=5)
+    ll = g.run_series(y, z)
+    per = g.per_step()
+    np.testing.assert_allclose(per.sum(axis=1), ll, rtol=0, atol=1e-9)
+    pm = g.param_means()
+    assert len(set(ll.tolist())) == R                       # replicates are independent streams
+    for r in range(R):
+        o = oracle.LWFilter(n, 5, rep=r, delta=0.95)
+        po = np.array([o.step(y[t], z[t]) for t in range(T)])
+        assert_bits_equal(per[r], po, f"LW per-step filter {r}")
+        np.testing.assert_allclose(pm[r], o.param_means(), rtol=1e-12, atol=0)
+    g.reset()
+    steps = []
+    for t in range(T):
+        g.filter(y[t], z[t])
+        steps.append(g.getLogCondLike().copy())
+    assert_bits_equal(np.array(steps).T, per, "LW step API == series API")
+    g.close()
+
+
+def test_liu_west_recovers_parameters_like_reference_restatement(sa, oracle):
+    """Statistical: posterior means from the device filter agree with the mode-A (mt19937, reference-faithful)
+    restatement within Monte-Carlo error on a simulated leverage-SVOL series."""
+    rng = np.random.default_rng(9)
+    T, phi, mu, sig, rho = 200, 0.95, 0.0, 0.05, -0.3
+    x = np.zeros(T); y = np.zeros(T)
+    x[0] = mu + sig / np.sqrt(1 - phi * phi) * rng.normal()
+    y[0] = np.exp(x[0] / 2) * rng.normal()
+    for t in range(1, T):
+        x[t] = mu + phi * (x[t - 1] - mu) + rho * sig * y[t - 1] * np.exp(-x[t - 1] / 2) + sig * np.sqrt(1 - rho * rho) * rng.normal()
+        y[t] = np.exp(x[t] / 2) * rng.normal()
+    z = np.concatenate([[0.0], y[:-1]])
+    g = sa.svol_lw_1_par(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=20000, n_filters=4, seed=1)
+    ll = g.run_series(y, z)
+    pm = g.param_means()
+    ref = [oracle.lw_ref_run(20000, y, z, seed=s) for s in (1, 2, 3, 4)]
+    ll_ref = np.array([r[0] for r in ref]); pm_ref = np.array([r[2] for r in ref])
+    assert np.all(np.isfinite(ll))
+    assert abs(ll.mean() - ll_ref.mean()) < 4 * np.sqrt(ll.var() / 4 + ll_ref.var() / 4) + 0.5
+    assert np.all(np.abs(pm.mean(0) - pm_ref.mean(0)) < 4 * np.sqrt(pm.var(0) / 4 + pm_ref.var(0) / 4) + [0.01, 0.01, 0.005, 0.03])
+    g.close()
+
+
+def test_liu_west_rejects_bad_config(sa):
+    from ssme_amd import SsmeError
+    with pytest.raises(SsmeError):
+        sa.svol_lw_1_par(1.5, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=100)      # delta outside (0,1]
+    with pytest.raises(SsmeError):
+        sa.svol_lw_1_par(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=0)
