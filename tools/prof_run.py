@@ -20,10 +20,21 @@ ap.add_argument("--model", type=int, default=0)
 ap.add_argument("--eager", action="store_true")
 ap.add_argument("--nt", type=int, default=0)
 ap.add_argument("--sweep", action="store_true")
+ap.add_argument("--lw", action="store_true", help="Liu-West filter instead of the bootstrap filter")
 a = ap.parse_args()
 y = np.loadtxt(os.path.join(ROOT, "tests", "golden", "spy_returns.csv"))[:a.T]
 z = np.concatenate([[0.0], y[:-1]]) if a.model == 1 else None
 th = {0: [1.0, 0.95, 0.25], 1: [0.9, 0.0, 1.0, -0.1], 2: [0.9, 0.5, 0.7]}[a.model]
+if a.lw:
+    zz = np.concatenate([[0.0], y[:-1]])
+    g = ssme_amd.svol_lw_1_par(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=a.n, n_filters=a.filters, seed=20260101)
+    best = 1e9
+    for _ in range(a.passes):
+        ll = g.run_series(y, zz)
+        best = min(best, g.last_elapsed_ms())
+    print(f"liu-west N={a.n} R={a.filters} loglik {ll[:2]} best ms {best:.3f} us/step {best*1e3/a.T:.2f} "
+          f"p-s/s {a.n * a.filters * a.T / (best * 1e-3):.4g} means {g.param_means()[0]}")
+    sys.exit(0)
 bank = ssme_amd.ParticleFilterBank(a.model, a.n, a.filters, 20260101, a.resampler)
 if a.eager:
     bank.set_graph_mode(False)
