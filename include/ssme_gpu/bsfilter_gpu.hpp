@@ -19,6 +19,8 @@
 
 #include <cmath>
 #include <cstddef>
+#include <fstream>
+#include <sstream>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -145,6 +147,105 @@ double log_like_eval_gpu(const Pack& theta, const Data& data, int nparts, int nu
     double out = 0.0;
     check(ssme_pf_log_mean_exp(h.get(), &out), h.get());
     return out;
+}
+
+// ---- persistent evaluator: one handle, one captured graph, a fresh random stream per call --------------------------
+// The PMMH caller evaluates log_like_eval once per MCMC iteration (ada_pmmh_mvn.h:344,363 through thread_pool::work).
+// Constructing a model per evaluation (estimate_univ_svol.h:119) costs device allocations and a graph capture; this
+// object keeps the handle, so an evaluation is: upload theta, new seed, replay the graph, log-mean-exp.
+class svol_log_like_evaluator {
+public:
+    template <typename Data>
+    svol_log_like_evaluator(const Data& data, int nparts, int num_pfilters, gpu_options o = gpu_options())
+        : h_(SSME_MODEL_SVOL, nparts, num_pfilters, o.seed, o.resampler, o.resamp_sched, o.device, 0), ll_((std::size_t)num_pfilters) {
+        if (data.empty()) throw std::length_error("can't read in data\n");
+        y_.resize(data.size());
+        for (std::size_t i = 0; i < data.size(); ++i) y_[i] = (double)data[i](0);
+    }
+    // theta in the reference's pack order: beta, phi, ss (sigma = sqrt(ss))
+    template <typename Pack>
+    double operator()(const Pack& theta, std::uint64_t seed) {
+        const double th[3] = {(double)theta.get_untrans_params(0, 0)(0), (double)theta.get_untrans_params(1, 1)(0),
+                              std::sqrt((double)theta.get_untrans_params(2, 2)(0))};
+        check(ssme_pf_set_seed(h_.get(), seed), h_.get());
+        check(ssme_pf_set_params(h_.get(), th, 3, 1), h_.get());
+        check(ssme_pf_run_series(h_.get(), y_.data(), nullptr, (int)y_.size(), ll_.data()), h_.get());
+        double out = 0.0;
+        check(ssme_pf_log_mean_exp(h_.get(), &out), h_.get());
+        return out;
+    }
+    float device_ms() const { float ms = 0; ssme_pf_last_elapsed_ms(h_.get(), &ms); return ms; }
+    ssme_pf_handle native() const { return h_.get(); }
+
+private:
+    handle h_;
+    std::vector<double> y_, ll_;
+};
+
+// ---- svol_lw_1_par (LWFilterWithCovs) ---------------------------------------------------------------------------
+// test/test_liu_west.cpp:22-157: ctor (delta, phi_l, phi_u, mu_l, mu_u, sig_l, sig_u, rho_l, rho_u[, dte]);
+// filter(y, z), getLogCondLike() (liu_west_filter.h:971-1159).  Transforms as svol_lw_1_par passes them to its base:
+// logit, null, log, twice_fisher (test_liu_west.cpp:70).
+template <std::size_t nparts, typename float_t = double>
+class svol_lw_1_par_gpu {
+public:
+    svol_lw_1_par_gpu(const float_t& delta, const float_t& phi_l, const float_t& phi_u, const float_t& mu_l, const float_t& mu_u,
+                      const float_t& sig_l, const float_t& sig_u, const float_t& rho_l, const float_t& rho_u, unsigned /*dte*/ = 0,
+                      gpu_options o = gpu_options()) {
+        ssme_lw_config c{};
+        c.n_particles = (int)nparts; c.n_filters = 1; c.seed = o.seed; c.device = o.device; c.first_filter_id = 0;
+        c.delta = (double)delta;
+        const int tr[4] = {2, 0, 3, 1};
+        const double lo[4] = {(double)phi_l, (double)mu_l, (double)sig_l, (double)rho_l};
+        const double hi[4] = {(double)phi_u, (double)mu_u, (double)sig_u, (double)rho_u};
+        for (int d = 0; d < 4; ++d) { c.transforms[d] = tr[d]; c.prior_lo[d] = lo[d]; c.prior_hi[d] = hi[d]; }
+        ssme_lw_handle raw = nullptr;
+        check(ssme_lw_create(&c, &raw));
+        h_ = std::shared_ptr<ssme_lw_s>(raw, [](ssme_lw_handle p) { if (p) ssme_lw_destroy(p); });
+    }
+    template <typename Osv, typename Cvsv>
+    void filter(const Osv& yt, const Cvsv& zt) {
+        const double y = (double)yt(0), z = (double)zt(0);
+        double out = 0.0;
+        const int rc = ssme_lw_step(h_.get(), &y, &z, &out);
+        if (rc != SSME_OK) throw std::runtime_error(std::string(ssme_pf_strerror(rc)) + " (" + ssme_lw_last_error(h_.get()) + ")");
+        last_ = (float_t)out;
+    }
+    float_t getLogCondLike() const { return last_; }
+    // weighted posterior means of (phi, mu, sigma, rho) under the last step's weights
+    std::vector<double> getParamMeans() const {
+        std::vector<double> m(4);
+        check(ssme_lw_get_param_means(h_.get(), m.data()));
+        return m;
+    }
+    ssme_lw_handle native() const { return h_.get(); }
+
+private:
+    std::shared_ptr<ssme_lw_s> h_;
+    float_t last_ = 0;
+};
+
+// ---- headerless CSV -> rows of doubles (utils::read_data, include/ssme/utils.h:25-64) -------------------------------
+// Same tolerance as the reference: rows that fail to parse are skipped; an unreadable file yields an empty vector
+// (callers then throw length_error, estimate_univ_svol.h:112-113).
+struct csv_row {
+    std::vector<double> v;
+    double operator()(std::size_t i) const { return v[i]; }
+};
+inline std::vector<csv_row> read_data(const std::string& file_loc, std::size_t ncols = 1) {
+    std::vector<csv_row> rows;
+    std::ifstream in(file_loc);
+    std::string line, cell;
+    while (std::getline(in, line)) {
+        csv_row r;
+        std::istringstream ls(line);
+        bool ok = true;
+        while (ok && std::getline(ls, cell, ',')) {
+            try { r.v.push_back(std::stod(cell)); } catch (const std::exception&) { ok = false; }
+        }
+        if (ok && r.v.size() >= ncols) { r.v.resize(ncols); rows.push_back(r); }
+    }
+    return rows;
 }
 
 }  // namespace ssme_gpu

@@ -89,6 +89,9 @@ int ssme_pf_destroy(ssme_pf_handle h);
 int ssme_pf_set_params(ssme_pf_handle h, const double* theta, int32_t n_theta, int32_t n_rows);
 
 /* Back to t = 0 with the current parameters (a fresh model object in the reference). */
+/* New random stream for the next evaluation; resets the filters.  The reference seeds every model object from the clock
+ * (a fresh likelihood estimate per PMMH proposal, estimate_univ_svol.h:119); here the caller supplies the seed. */
+int ssme_pf_set_seed(ssme_pf_handle h, uint64_t seed);
 int ssme_pf_reset(ssme_pf_handle h);
 
 /* One filter() call on every filter of the handle: BSFilter::filter(y_t) /
@@ -132,6 +135,9 @@ int ssme_pf_set_debug(ssme_pf_handle h, int32_t flags);
  * not depend on it (the weight cdf is exact integer arithmetic). */
 int ssme_pf_set_tuning(ssme_pf_handle h, int32_t threads_per_tile);
 
+/* Filters of one tile (N <= 2048) run ssme_pf_run_series as ONE launch that loops over the series with the state in
+ * LDS (default 1); 0 forces the tiled per-step kernel.  Results are bit-identical either way (parity tests). */
+int ssme_pf_set_small_series(ssme_pf_handle h, int32_t enable);
 /* Execution policy of run_series: 0 = eager launches, 1 = one hipGraph per series (default). */
 int ssme_pf_set_graph_mode(ssme_pf_handle h, int32_t mode);
 

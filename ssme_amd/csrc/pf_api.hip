@@ -4,6 +4,7 @@
 #include "../../include/ssme_pf.h"
 #include "pf_kernels.h"
 #include "lw_kernels.h"
+#include "pf_small.h"
 
 #include <cmath>
 #include <cstdio>
@@ -23,6 +24,7 @@ struct ssme_pf_s {
     bool params_set;
     int debug_anc, keep_logw;
     int graph_mode;
+    int small_series;        // 1: one-tile filters run the whole series in one launch (k_filter_series_small)
     int nt;                  // threads per 2048-particle tile of k_filter_step (256, 512, 1024)
     hipStream_t stream;
     hipEvent_t ev0, ev1;
@@ -35,6 +37,7 @@ struct ssme_pf_s {
     double *logw, *ybuf, *zbuf, *per_step, *scratchR;
     double *gam, *pgam, *gtot;   // Gamma tables of the multinomial resampler, gcap time rows
     uint32_t* anc;
+    uint32_t* keybuf;        // [2] Philox key = seed (lo, hi)
     FilterScalars* scal;
     ModelConst* mc;
     int cur;                 // buffer index holding the latest step's output
@@ -101,7 +104,7 @@ static StepArgs step_args(ssme_pf_handle h) {
     a.N = h->N; a.Npad = h->Npad; a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = h->R;
     a.Tcap = h->tcap;
     a.resampler = h->cfg.resampler; a.resamp_sched = h->cfg.resamp_sched;
-    a.key0 = (uint32_t)h->cfg.seed; a.key1 = (uint32_t)(h->cfg.seed >> 32); a.first_filter = h->cfg.first_filter_id;
+    a.keyp = h->keybuf; a.first_filter = h->cfg.first_filter_id;
     a.logN = dlog((double)h->N);
 #ifdef SSME_ABLATE
     { const char* e = getenv("SSME_ABLATE_MASK"); a.ablate = e ? atoi(e) : 0; }
@@ -155,11 +158,11 @@ static void launch_step(ssme_pf_handle h, const StepArgs& a) {
 // Gamma tables for time indices t0 .. t0+nT-1 into table rows 0 .. nT-1
 static void launch_gamma(ssme_pf_handle h, int t0, int nT) {
     if (h->cfg.resampler != SSME_RESAMP_MULTINOMIAL) return;
-    const uint32_t k0 = (uint32_t)h->cfg.seed, k1 = (uint32_t)(h->cfg.seed >> 32);
     hipLaunchKernelGGL(k_gamma_draw, dim3((h->B + kThreads - 1) / kThreads, nT, h->R), dim3(kThreads), 0, h->stream,
-                       h->gam, h->N, h->B, h->R, t0, k0, k1, h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA);
+                       h->gam, h->N, h->B, h->R, t0, (const uint32_t*)h->keybuf, h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA);
     hipLaunchKernelGGL(k_gamma_prefix, dim3((nT * h->R + kThreads - 1) / kThreads), dim3(kThreads), 0, h->stream,
-                       h->gam, h->pgam, h->gtot, h->B, h->R, nT, t0, k0, k1, h->cfg.first_filter_id, (uint32_t)STREAM_RESAMP_EXTRA);
+                       h->gam, h->pgam, h->gtot, h->B, h->R, nT, t0, (const uint32_t*)h->keybuf, h->cfg.first_filter_id,
+                       (uint32_t)STREAM_RESAMP_EXTRA);
 }
 // accounts the log conditional likelihood of step t from the buffers the step wrote (now `cur`)
 static void launch_kf(ssme_pf_handle h, int t, bool record_per_step) {
@@ -177,6 +180,29 @@ static void enqueue_step(ssme_pf_handle h, int t, int yi, int gi, bool has_z, bo
     a.t = t; a.yi = yi; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
     launch_step(h, a);
     h->cur ^= 1;
+}
+
+// whole series in one launch for one-tile filters (pf_small.h); reads buffers `cur`-independent, writes x[1] etc.
+template <int MODEL>
+static void launch_small_m(ssme_pf_handle h, const StepArgs& a, int T) {
+    const dim3 grid(h->R);
+    if (h->N <= 256) hipLaunchKernelGGL((k_filter_series_small<MODEL, 128, 1>), grid, dim3(128), 0, h->stream, a, T);
+    else if (h->N <= 512) hipLaunchKernelGGL((k_filter_series_small<MODEL, 256, 1>), grid, dim3(256), 0, h->stream, a, T);
+    else if (h->N <= 1024) hipLaunchKernelGGL((k_filter_series_small<MODEL, 512, 1>), grid, dim3(512), 0, h->stream, a, T);
+    else hipLaunchKernelGGL((k_filter_series_small<MODEL, 512, 2>), grid, dim3(512), 0, h->stream, a, T);
+}
+static void enqueue_series_small(ssme_pf_handle h, int T, bool has_z) {
+    launch_gamma(h, 0, T);
+    h->cur = 0;
+    StepArgs a = step_args(h);
+    a.z = has_z ? h->zbuf : nullptr;
+    a.per_step = h->per_step;
+    switch (h->cfg.model) {
+        case SSME_MODEL_SVOL: launch_small_m<MODEL_SVOL>(h, a, T); break;
+        case SSME_MODEL_SVOL_LEVERAGE: launch_small_m<MODEL_SVOL_LEVERAGE>(h, a, T); break;
+        default: launch_small_m<MODEL_LIN_GAUSS>(h, a, T); break;
+    }
+    h->cur = 1;
 }
 
 static int ensure_series_capacity(ssme_pf_handle h, int T) {
@@ -216,6 +242,13 @@ static int ensure_logw(ssme_pf_handle h) {
         HIPCHK(hipMalloc(&h->logw, sizeof(double) * np));
         HIPCHK(hipMemset(h->logw, 0, sizeof(double) * np));
     }
+    return SSME_OK;
+}
+
+static int upload_key(ssme_pf_handle h) {
+    const uint32_t k[2] = {(uint32_t)h->cfg.seed, (uint32_t)(h->cfg.seed >> 32)};
+    HIPCHK(hipMemcpyAsync(h->keybuf, k, sizeof(k), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));   // k is a temporary
     return SSME_OK;
 }
 
@@ -264,6 +297,7 @@ int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) {
     h->rshift = 52 - ceil_log2(h->Npad);
     h->lds_bytes = sizeof(double) * (2 * (size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2) + (size_t)kStageTiles * kTile);
     h->graph_mode = 1;
+    h->small_series = 1;
     h->nt = 512;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) { delete h; return SSME_ERR_HIP; }
@@ -288,7 +322,10 @@ int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) {
         HIPCHK(hipMalloc(&h->scal, sizeof(FilterScalars) * h->R));
         HIPCHK(hipMalloc(&h->mc, sizeof(ModelConst) * h->R));
         HIPCHK(hipMalloc(&h->scratchR, sizeof(double) * h->R));
-        int rc2 = ensure_logw(h);
+        HIPCHK(hipMalloc(&h->keybuf, sizeof(uint32_t) * 2));
+        int rc2 = upload_key(h);
+        if (rc2 != SSME_OK) return rc2;
+        rc2 = ensure_logw(h);
         if (rc2 != SSME_OK) return rc2;
         return ensure_series_capacity(h, 1);
     }();
@@ -303,7 +340,7 @@ int ssme_pf_destroy(ssme_pf_handle h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     void* bufs[] = {h->x[0], h->x[1], h->cdf[0], h->cdf[1], h->tsum[0], h->tsum[1], h->tmax[0], h->tmax[1], h->logw,
-                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot};
+                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -323,6 +360,17 @@ int ssme_pf_set_params(ssme_pf_handle h, const double* theta, int32_t n_theta, i
     HIPCHK(hipStreamSynchronize(h->stream));
     h->params_set = true;
     return do_reset(h);
+}
+
+// New random stream for the next evaluation (PMMH draws a fresh likelihood estimate per proposal; the reference
+// seeds every model object from the clock).  The key lives in device memory: a captured graph stays valid.
+int ssme_pf_set_seed(ssme_pf_handle h, uint64_t seed) {
+    if (!h) return SSME_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    h->cfg.seed = seed;
+    int rc = upload_key(h);
+    if (rc != SSME_OK) return rc;
+    return h->params_set ? do_reset(h) : SSME_OK;
 }
 
 int ssme_pf_reset(ssme_pf_handle h) {
@@ -349,6 +397,12 @@ int ssme_pf_set_tuning(ssme_pf_handle h, int32_t threads_per_tile) {
     if (!h) return SSME_ERR_INVALID_ARG;
     if (threads_per_tile != 256 && threads_per_tile != 512 && threads_per_tile != 1024) return SSME_ERR_INVALID_ARG;
     h->nt = threads_per_tile;
+    return SSME_OK;
+}
+
+int ssme_pf_set_small_series(ssme_pf_handle h, int32_t enable) {
+    if (!h || enable < 0 || enable > 1) return SSME_ERR_INVALID_ARG;
+    h->small_series = enable;
     return SSME_OK;
 }
 
@@ -399,7 +453,11 @@ int ssme_pf_run_series(ssme_pf_handle h, const double* y, const double* z, int32
     if (rc != SSME_OK) return rc;
     const bool has_z = z != nullptr;
     const int lw = logw_needed(h) ? 1 : 0;
-    if (h->graph_mode) {
+    if (h->B == 1 && h->small_series) {
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        enqueue_series_small(h, T, has_z);
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+    } else if (h->graph_mode) {
         if (!h->gexec || h->g_T != T || h->g_has_z != (int)has_z || h->g_debug != h->debug_anc || h->g_logw != lw ||
             h->g_nt != h->nt) {
             if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
@@ -758,7 +816,7 @@ struct ssme_lw_s {
     double *xB, *thB, *xr, *thr, *lw1, *cdfA, *tsumA, *tmaxA, *cdfB, *tsumB, *tmaxB, *mom, *prop;
     double *ybuf, *zbuf, *per_step, *scratch;
     double *gamA, *pgamA, *gtotA, *gamB, *pgamB, *gtotB;
-    uint32_t *anc, *kidx;
+    uint32_t *anc, *kidx, *keybuf;
     LwScalars* scal;
     int ycap, tcap, gcap;
     std::string err;
@@ -814,15 +872,15 @@ static int lw_ensure_capacity(ssme_lw_handle h, int T) {
 
 // Gamma tables of both draws for time indices t0 .. t0+nT-1 into rows 0 .. nT-1
 static void lw_launch_gamma(ssme_lw_handle h, int t0, int nT) {
-    const uint32_t k0 = (uint32_t)h->cfg.seed, k1 = (uint32_t)(h->cfg.seed >> 32);
+    const uint32_t* kp = h->keybuf;
     const dim3 g1((h->B + kThreads - 1) / kThreads, nT, h->R), g2((nT * h->R + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(k_gamma_draw, g1, dim3(kThreads), 0, h->stream, h->gamB, h->N, h->B, h->R, t0, k0, k1,
+    hipLaunchKernelGGL(k_gamma_draw, g1, dim3(kThreads), 0, h->stream, h->gamB, h->N, h->B, h->R, t0, kp,
                        h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA);
-    hipLaunchKernelGGL(k_gamma_prefix, g2, dim3(kThreads), 0, h->stream, h->gamB, h->pgamB, h->gtotB, h->B, h->R, nT, t0, k0, k1,
+    hipLaunchKernelGGL(k_gamma_prefix, g2, dim3(kThreads), 0, h->stream, h->gamB, h->pgamB, h->gtotB, h->B, h->R, nT, t0, kp,
                        h->cfg.first_filter_id, (uint32_t)STREAM_RESAMP_EXTRA);
-    hipLaunchKernelGGL(k_gamma_draw, g1, dim3(kThreads), 0, h->stream, h->gamA, h->N, h->B, h->R, t0, k0, k1,
+    hipLaunchKernelGGL(k_gamma_draw, g1, dim3(kThreads), 0, h->stream, h->gamA, h->N, h->B, h->R, t0, kp,
                        h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA_K);
-    hipLaunchKernelGGL(k_gamma_prefix, g2, dim3(kThreads), 0, h->stream, h->gamA, h->pgamA, h->gtotA, h->B, h->R, nT, t0, k0, k1,
+    hipLaunchKernelGGL(k_gamma_prefix, g2, dim3(kThreads), 0, h->stream, h->gamA, h->pgamA, h->gtotA, h->B, h->R, nT, t0, kp,
                        h->cfg.first_filter_id, (uint32_t)STREAM_LW_K_EXTRA);
 }
 
@@ -863,7 +921,7 @@ int ssme_lw_destroy(ssme_lw_handle h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     void* bufs[] = {h->xB, h->thB, h->xr, h->thr, h->lw1, h->cdfA, h->tsumA, h->tmaxA, h->cdfB, h->tsumB, h->tmaxB, h->mom, h->prop,
                     h->ybuf, h->zbuf, h->per_step, h->scratch, h->gamA, h->pgamA, h->gtotA, h->gamB, h->pgamB, h->gtotB, h->anc,
-                    h->kidx, h->scal};
+                    h->kidx, h->scal, h->keybuf};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -907,6 +965,11 @@ int ssme_lw_create(const ssme_lw_config* cfg, ssme_lw_handle* out) {
         LWCHK(hipMemset(h->prop, 0, sizeof(double) * (size_t)h->R * 16));
         LWCHK(hipMalloc(&h->scal, sizeof(LwScalars) * h->R));
         LWCHK(hipMalloc(&h->scratch, sizeof(double) * h->R * kDP));
+        LWCHK(hipMalloc(&h->keybuf, sizeof(uint32_t) * 2));
+        {
+            const uint32_t k[2] = {(uint32_t)h->cfg.seed, (uint32_t)(h->cfg.seed >> 32)};
+            LWCHK(hipMemcpy(h->keybuf, k, sizeof(k), hipMemcpyHostToDevice));
+        }
         LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         int rc2 = lw_ensure_capacity(h, 1);

@@ -89,7 +89,8 @@ struct StepArgs {
     int32_t t, yi, gi, Tcap;   // t: time index (RNG counter, schedule); yi / gi: rows of y / gamma tables
     int32_t resampler, resamp_sched;
     int32_t finalize_prev;     // account log p(y_{t-1}|.) of the previous step
-    uint32_t key0, key1, first_filter;
+    const uint32_t* keyp;      // [2] Philox key (the seed), device resident so that a captured graph survives ssme_pf_set_seed
+    uint32_t first_filter;
     double logN;
     int32_t ablate;            // measurement builds only (-DSSME_ABLATE): skip sections, results invalid
     unsigned long long* stamps;  // measurement builds only: phase time stamps
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x, r = blockIdx.y;
     const uint32_t rep = a.first_filter + (uint32_t)r;
+    const uint32_t key0 = a.keyp[0], key1 = a.keyp[1];
     const size_t rowoff = (size_t)r * a.Npad;
     const ModelConst mc = a.mc[r];
     const double y = a.y[a.yi];
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             t_lo = __builtin_ceil(pgam * t_scale);
             t_hi = __builtin_ceil(pgam_next * t_scale) + (S * 0x1.0p-40 + 2.0);   // slack covers the rounding of ratio*E_tile vs Gamma_b
         } else if (a.resampler == RESAMP_SYSTEMATIC) {
-            const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, a.key0, a.key1);
+            const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, key0, key1);
             u0 = u01_co(ox.v0, ox.v1);
             t_scale = Sd / (double)a.N;
             t_lo = __builtin_ceil(((double)i_first + u0) * t_scale);
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             double e0, e1;
             if (ABL(a, 1)) { e0 = 1.0 + 1e-6 * (double)(i0 & 1023); e1 = 1.0; }
             else {
-                const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, a.key0, a.key1);
+                const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, key0, key1);
                 e0 = -dlog_pn(u01_oc(o.v0, o.v1)); e1 = -dlog_pn(u01_oc(o.v2, o.v3));
             }
             qe[k][0] = (i0 < a.N) ? __builtin_rint(e0 * 34359738368.0 /* 2^35 */) : 0.0;
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                 tau[k][0] = __builtin_ceil(((double)i0 + u0) * t_scale);
                 tau[k][1] = __builtin_ceil(((double)(i0 + 1) + u0) * t_scale);
             } else {
-                const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, a.key0, a.key1);
+                const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, key0, key1);
                 const double v0 = u01_co(o.v0, o.v1), v1 = u01_co(o.v2, o.v3);
                 if (a.resampler == RESAMP_STRATIFIED) {
                     tau[k][0] = __builtin_ceil(((double)i0 + v0) * t_scale);
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     for (int k = 0; k < NK; ++k) {
         const uint32_t pair = (uint32_t)(b * (kTile / 2) + k * NT + tid);
         if (ABL(a, 0)) { zn[k][0] = 0.25 + 1e-9 * (double)pair; zn[k][1] = -0.25; }
-        else normal_pair(pair, (uint32_t)a.t, rep, a.key0, a.key1, &zn[k][0], &zn[k][1]);
+        else normal_pair(pair, (uint32_t)a.t, rep, key0, key1, &zn[k][0], &zn[k][1]);
     }
     STAMP(a, 7);
 
@@ -797,8 +799,9 @@ __global__ __launch_bounds__(kThreads) void kf_finalize(const StepArgs a) {
 // Gamma tables for the multinomial resampler (data independent: seed, t, filter, tile only).
 // k_gamma_draw: grid = (ceil(B/256), nT, R).  k_gamma_prefix: one thread per (ti, r).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_gamma_draw(double* gam, int N, int B, int R, int t0, uint32_t key0,
-                                                         uint32_t key1, uint32_t first_filter, uint32_t gamma_stream) {
+__global__ __launch_bounds__(kThreads) void k_gamma_draw(double* gam, int N, int B, int R, int t0, const uint32_t* keyp,
+                                                         uint32_t first_filter, uint32_t gamma_stream) {
+    const uint32_t key0 = keyp[0], key1 = keyp[1];
     const int b = blockIdx.x * kThreads + threadIdx.x;
     const int ti = blockIdx.y, r = blockIdx.z;
     if (b >= B) return;
@@ -808,8 +811,9 @@ __global__ __launch_bounds__(kThreads) void k_gamma_draw(double* gam, int N, int
 }
 
 __global__ __launch_bounds__(kThreads) void k_gamma_prefix(const double* gam, double* pgam, double* gtot, int B, int R,
-                                                           int nT, int t0, uint32_t key0, uint32_t key1, uint32_t first_filter,
+                                                           int nT, int t0, const uint32_t* keyp, uint32_t first_filter,
                                                            uint32_t extra_stream) {
+    const uint32_t key0 = keyp[0], key1 = keyp[1];
     const int id = blockIdx.x * kThreads + threadIdx.x;
     if (id >= nT * R) return;
     const int ti = id / R, r = id % R;

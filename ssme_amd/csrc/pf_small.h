@@ -1,0 +1,290 @@
+// pf_small.h -- whole-series kernel for filters that fit one tile (N <= 2048): the T steps of
+// BSFilter::filter (call site example/estimate_univ_svol.h:121-127) run inside ONE launch, one workgroup
+// per filter.  Particles and the integer weight cdf stay in LDS, log-weights in registers; there is no
+// kernel boundary and no HBM round trip per step, which is what bounds small filters (a step of the
+// tiled kernel costs ~10 us of launch + dependent-latency chain however small N is).
+//
+// The arithmetic is the tiled kernel's (k_filter_step with B = 1) operation for operation: same Philox
+// counters, same spacings / targets / count-search, same tile max and exact fp64-integer scan.  The two
+// paths are bit-identical (tests/test_parity_gpu.py::test_small_series_kernel_*); the oracle does not
+// distinguish them.  Used by ssme_pf_run_series when the filter has one tile (the shipped example's
+// N = 500, example/main.cpp:9) -- the step API and multi-tile filters use k_filter_step.
+#pragma once
+#include "pf_kernels.h"
+
+namespace ssme {
+
+// Exact inclusive scan of P = 2*NT*NK integer-valued doubles (pairs q[k][c] at position (k*NT + tid)*2 + c).
+template <int NT, int NK>
+__device__ __forceinline__ void block_scan_f64_g(const double (&q)[NK][2], double (&incl)[NK][2], double& total, double* lds_seg) {
+    constexpr int WPR = NT / 64, NSEG = NK * WPR;
+    static_assert(NSEG <= 16, "segment totals are scanned inside one 16-lane row");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double s0[NK], s1[NK], exc[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        s0[k] = q[k][0];
+        s1[k] = s0[k] + q[k][1];
+        const double inc = wave_incl_scan_f64(s1[k]);
+        exc[k] = wave_shr1_f64(inc);
+        if (lane == 63) lds_seg[k * WPR + wave] = inc;
+    }
+    __syncthreads();
+    double sv = (lane & 15) < NSEG ? lds_seg[lane & 15] : 0.0;
+    sv = sv + dpp_f64_zero<0x111, 0xF>(sv);
+    sv = sv + dpp_f64_zero<0x112, 0xF>(sv);
+    sv = sv + dpp_f64_zero<0x114, 0xF>(sv);
+    sv = sv + dpp_f64_zero<0x118, 0xF>(sv);
+    total = readlane_f64(sv, 15);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int seg = k * WPR + wave;
+        const double pre = seg ? readlane_f64(sv, seg - 1) : 0.0;
+        const double base = pre + exc[k];
+        incl[k][0] = base + s0[k];
+        incl[k][1] = base + s1[k];
+    }
+}
+
+// min(#{ j < P : tile[j] < target }, P-1) for two targets at once by a radix-8 descent: the probes of one level are
+// independent loads, so a search costs log8(P) dependent LDS round trips instead of log2(P) -- this kernel runs one
+// wave per SIMD and is bound by dependent latency, not by issue slots.  Same count as count_less_pow2 (monotone tile).
+template <int P>
+__device__ __forceinline__ void count_less_radix8_x2(const double* tile, double t0, double t1, int& j0, int& j1) {
+    int p0 = 0, p1 = 0;
+#pragma unroll
+    for (int w = P; w > 1;) {
+        const int radix = (w >= 8) ? 8 : w;          // P is a power of two: the last level may be radix 2 or 4
+        const int s = w / radix;
+        int c0 = 0, c1 = 0;
+#pragma unroll
+        for (int k = 1; k < radix; ++k) {
+            c0 += (tile[p0 + k * s - 1] < t0) ? 1 : 0;
+            c1 += (tile[p1 + k * s - 1] < t1) ? 1 : 0;
+        }
+        p0 += c0 * s; p1 += c1 * s;
+        w = s;
+    }
+    j0 = p0; j1 = p1;
+}
+
+// grid = (R filters), block = NT, covers P = 2*NT*NK >= N particle slots (P a power of two, 256 .. 2048).
+// a.x_out / cdf_out / tsum_out / tmax_out / logw receive the state after the last step (as k_filter_step
+// leaves it), a.scal the accumulated log-likelihood; a.t / yi / gi are ignored (t = yi = gi = 0 .. T-1).
+template <int MODEL, int NT, int NK>
+__global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, const int T) {
+    constexpr int P = 2 * NT * NK;
+    __shared__ __attribute__((aligned(16))) double lds_x[P];
+    __shared__ __attribute__((aligned(16))) double lds_cdf[P];
+    __shared__ double lds_seg_a[16];
+    __shared__ double lds_seg_c[16];
+    __shared__ double lds_d2[16];
+
+    const int tid = threadIdx.x;
+    const int r = blockIdx.x;
+    const uint32_t rep = a.first_filter + (uint32_t)r;
+    const uint32_t key0 = a.keyp[0], key1 = a.keyp[1];
+    const size_t rowoff = (size_t)r * a.Npad;
+    const ModelConst mc = a.mc[r];
+    const bool multinomial_kind = a.resampler == RESAMP_MULTINOMIAL;
+
+    FilterScalars sc;                                // every thread carries the (uniform) scalars
+    sc.m = 0.0; sc.S = 0.0; sc.last_ll = 0.0;
+    sc.prev = a.scal[r].prev; sc.loglik = a.scal[r].loglik;
+    double xcur[NK][2], lwcur[NK][2];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { xcur[k][0] = 0.0; xcur[k][1] = 0.0; lwcur[k][0] = 0.0; lwcur[k][1] = 0.0; }
+    double A_prev = 0.0, mb_prev = 0.0;
+
+    // next step's inputs are requested one step ahead (uniform scalar loads)
+    double y_n = a.y[0], z_n = a.z ? a.z[0] : 0.0;
+    double gam_n = 0.0, pgam_n = 0.0, G_n = 1.0;
+
+    for (int t = 0; t < T; ++t) {
+        const double y = y_n, zcov = z_n;
+        const double gam = gam_n, pgam = pgam_n, G = G_n;
+        if (t + 1 < T) {
+            y_n = a.y[t + 1];
+            if (a.z) z_n = a.z[t + 1];
+            if (multinomial_kind && ((t + 1) % a.resamp_sched == 0)) {
+                const size_t gidx = ((size_t)(t + 1) * a.R + r) * a.B;          // B = 1, tile 0
+                gam_n = a.gam[gidx]; pgam_n = a.pgam[gidx]; G_n = a.gtot[(size_t)(t + 1) * a.R + r];
+            }
+        }
+        const bool resampled = (t > 0) && (t % a.resamp_sched == 0);
+        const bool multinomial = resampled && multinomial_kind;
+
+        // --- level-2 with one tile (level2_scan for B = 1) and the log conditional likelihood of step t-1 ---
+        double S = 0.0, R0 = 0.0;
+        if (t > 0) {
+            const double m = (mb_prev != mb_prev) ? dnan() : mb_prev;
+            // one tile: m_b - m is +0 unless the max is NaN or infinite, and the shift is 0 (Npad = 2048); exp(0) 2^0 = 1 exactly
+            const double dm = mb_prev - m;
+            const int sh = a.rshift - kTileShift;
+            const double Ap = (dm == 0.0 && sh == 0) ? __builtin_rint(A_prev) : __builtin_rint(A_prev * dexp_scaled(dm, sh));
+            S = Ap;
+            R0 = A_prev / Ap;
+            const double Sdd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
+            const double lse = m + dlog(Sdd);
+            const double ll = lse - sc.prev;
+            sc.m = m; sc.S = S; sc.last_ll = ll;
+            sc.loglik = sc.loglik + ll;
+            sc.prev = resampled ? a.logN : lse;
+            if (tid == 0 && a.per_step) a.per_step[(size_t)r * a.Tcap + (t - 1)] = ll;
+        }
+
+        // --- standard normals of this step: independent of the resampling chain, issued next to the spacings so that the
+        //     two instruction streams interleave ---
+        double zn[NK][2];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) normal_pair((uint32_t)(k * NT + tid), (uint32_t)t, rep, key0, key1, &zn[k][0], &zn[k][1]);
+
+        // --- exponential spacings (multinomial), exact scan ---
+        double le[NK][2], se = 1.0;
+        if (multinomial) {
+            double qe[NK][2];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int i0 = (k * NT + tid) * 2;
+                const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)t, rep, STREAM_RESAMP, key0, key1);
+                const double e0 = -dlog_pn(u01_oc(o.v0, o.v1)), e1 = -dlog_pn(u01_oc(o.v2, o.v3));
+                qe[k][0] = (i0 < a.N) ? __builtin_rint(e0 * 34359738368.0 /* 2^35 */) : 0.0;
+                qe[k][1] = (i0 + 1 < a.N) ? __builtin_rint(e1 * 34359738368.0) : 0.0;
+            }
+            block_scan_f64_g<NT, NK>(qe, le, se, lds_seg_a);
+        }
+
+        double xin[NK][2], lw_old[NK][2];
+        if (t == 0) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { xin[k][0] = 0.0; xin[k][1] = 0.0; lw_old[k][0] = 0.0; lw_old[k][1] = 0.0; }
+        } else if (!resampled) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { xin[k][0] = xcur[k][0]; xin[k][1] = xcur[k][1]; lw_old[k][0] = lwcur[k][0]; lw_old[k][1] = lwcur[k][1]; }
+        } else {
+            double t_scale, u0 = 0.0;
+            if (a.resampler == RESAMP_MULTINOMIAL) t_scale = S / G;
+            else {
+                t_scale = S / (double)a.N;
+                if (a.resampler == RESAMP_SYSTEMATIC) {
+                    const u32x4 ox = philox4x32_10(0u, (uint32_t)t, rep, STREAM_RESAMP_EXTRA, key0, key1);
+                    u0 = u01_co(ox.v0, ox.v1);
+                }
+            }
+            const double ratio = gam / se;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int i0 = (k * NT + tid) * 2;
+                double tau[2];
+                if (a.resampler == RESAMP_MULTINOMIAL) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const double t1 = ratio * le[k][c];
+                        const double t2 = pgam + t1;
+                        tau[c] = __builtin_ceil(t2 * t_scale);
+                    }
+                } else if (a.resampler == RESAMP_SYSTEMATIC) {
+                    tau[0] = __builtin_ceil(((double)i0 + u0) * t_scale);
+                    tau[1] = __builtin_ceil(((double)(i0 + 1) + u0) * t_scale);
+                } else {
+                    const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)t, rep, STREAM_RESAMP, key0, key1);
+                    const double v0 = u01_co(o.v0, o.v1), v1 = u01_co(o.v2, o.v3);
+                    if (a.resampler == RESAMP_STRATIFIED) {
+                        tau[0] = __builtin_ceil(((double)i0 + v0) * t_scale);
+                        tau[1] = __builtin_ceil(((double)(i0 + 1) + v1) * t_scale);
+                    } else {
+                        tau[0] = __builtin_ceil(v0 * S);
+                        tau[1] = __builtin_ceil(v1 * S);
+                    }
+                }
+                const double tl0 = __builtin_ceil((tau[0] - 0.0) * R0), tl1 = __builtin_ceil((tau[1] - 0.0) * R0);
+                int jj[2];
+                count_less_radix8_x2<P>(lds_cdf, tl0, tl1, jj[0], jj[1]);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int anc = jj[c] < a.N - 1 ? jj[c] : a.N - 1;
+                    if (a.anc && (i0 + c) < a.N) a.anc[rowoff + i0 + c] = (uint32_t)anc;
+                    xin[k][c] = lds_x[anc];
+                    lw_old[k][c] = 0.0;
+                }
+            }
+        }
+
+        // --- standard normals, fSamp / q1Samp, logGEv, tile max ---
+        double lg[NK][2];
+        double mx = -dinf();
+        bool nan = false;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int i0 = (k * NT + tid) * 2;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const double xn = (t == 0) ? zn[k][c] * mc.a2 : model_prop<MODEL>(mc, xin[k][c], zn[k][c], zcov);
+                const double l = lw_old[k][c] + model_logg<MODEL>(mc, y, xn);
+                const bool valid = (i0 + c) < a.N;
+                xcur[k][c] = valid ? xn : 0.0;
+                lg[k][c] = valid ? l : -dinf();
+                if (valid) { nan = nan || (l != l); mx = (l > mx) ? l : mx; }
+            }
+            lwcur[k][0] = lg[k][0]; lwcur[k][1] = lg[k][1];
+        }
+        const double mb = block_max_nanprop<NT>(mx, nan, lds_d2);    // barrier: every search / gather of this step is done
+
+        // --- tile-local fixed-point weights, exact scan -> the next step's cdf (LDS) ---
+        double q[NK][2], inc[NK][2], total;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int i0 = (k * NT + tid) * 2;
+            q[k][0] = (i0 < a.N) ? __builtin_rint(dexp_scaled(lg[k][0] - mb, kTileShift)) : 0.0;
+            q[k][1] = (i0 + 1 < a.N) ? __builtin_rint(dexp_scaled(lg[k][1] - mb, kTileShift)) : 0.0;
+        }
+        block_scan_f64_g<NT, NK>(q, inc, total, lds_seg_c);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int i0 = (k * NT + tid) * 2;
+            *reinterpret_cast<double2*>(lds_cdf + i0) = make_double2(inc[k][0], inc[k][1]);
+            *reinterpret_cast<double2*>(lds_x + i0) = make_double2(xcur[k][0], xcur[k][1]);
+        }
+        A_prev = total;
+        mb_prev = mb;
+        __syncthreads();                                              // cdf / x of step t visible to step t+1
+    }
+
+    // --- log conditional likelihood of the last step (kf_finalize) and the state hand-over ---
+    {
+        const double m = (mb_prev != mb_prev) ? dnan() : mb_prev;
+        const double S = __builtin_rint(A_prev * dexp_scaled(mb_prev - m, a.rshift - kTileShift));
+        const bool resample_now = (T % a.resamp_sched == 0);
+        const double Sd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
+        const double lse = m + dlog(Sd);
+        const double ll = lse - sc.prev;
+        sc.m = m; sc.S = S; sc.last_ll = ll;
+        sc.loglik = sc.loglik + ll;
+        sc.prev = resample_now ? a.logN : lse;
+        if (tid == 0) {
+            if (a.per_step) a.per_step[(size_t)r * a.Tcap + (T - 1)] = ll;
+            FilterScalars* o = a.scal + r;
+            o->m = sc.m; o->S = sc.S; o->prev = sc.prev; o->loglik = sc.loglik; o->last_ll = sc.last_ll;
+            a.tsum_out[(size_t)r * a.Bs] = A_prev;
+            a.tmax_out[(size_t)r * a.Bs] = mb_prev;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int i0 = (k * NT + tid) * 2;
+        *reinterpret_cast<double2*>(a.x_out + rowoff + i0) = make_double2(xcur[k][0], xcur[k][1]);
+        *reinterpret_cast<double2*>(a.cdf_out + rowoff + i0) = *reinterpret_cast<const double2*>(lds_cdf + i0);
+        if (a.logw) *reinterpret_cast<double2*>(a.logw + rowoff + i0) = make_double2(lwcur[k][0], lwcur[k][1]);
+    }
+    if (P < kTile) {
+        // slots beyond P: x = 0, cdf flat at the tile sum, log-weight -inf -- what k_filter_step writes there
+        for (int i = P + tid * 2; i < kTile; i += NT * 2) {
+            *reinterpret_cast<double2*>(a.x_out + rowoff + i) = make_double2(0.0, 0.0);
+            *reinterpret_cast<double2*>(a.cdf_out + rowoff + i) = make_double2(A_prev, A_prev);
+            if (a.logw) *reinterpret_cast<double2*>(a.logw + rowoff + i) = make_double2(-dinf(), -dinf());
+        }
+    }
+}
+
+}  // namespace ssme

@@ -58,6 +58,14 @@ class ParticleFilterBank:
     def reset(self):
         self._chk(capi.lib().ssme_pf_reset(self._h))
 
+    def set_small_series(self, enable=True):
+        """One-tile filters (N <= 2048): whole series in one launch (default) or the tiled per-step kernel."""
+        self._chk(capi.lib().ssme_pf_set_small_series(self._h, 1 if enable else 0))
+
+    def set_seed(self, seed):
+        """New random stream for the next evaluation (a fresh likelihood estimate per PMMH proposal); resets the filters."""
+        self._chk(capi.lib().ssme_pf_set_seed(self._h, int(seed)))
+
     def set_debug(self, record_ancestors=True, keep_logw=True):
         """Parity/debug: record ancestor indices and/or keep the log-weights in device memory."""
         self._chk(capi.lib().ssme_pf_set_debug(self._h, (1 if record_ancestors else 0) | (2 if keep_logw else 0)))

@@ -46,6 +46,21 @@ int main(int argc, char** argv) {
     }
     std::printf("svol_leverage %.17g\n", ll);
     std::printf("expect42 %.17g\n", lev2.getExpectations()[0]);
+    // (5) persistent evaluator (one handle, fresh stream per call) == a fresh model with that seed
+    ssme_gpu::svol_log_like_evaluator ev(data, 500, 4, o);
+    ev(theta, 5);                                        // some other stream first
+    std::printf("evaluator %.17g\n", ev(theta, 77));
+    // (6) Liu-West model as test/test_liu_west.cpp:160-200 drives it
+    ssme_gpu::svol_lw_1_par_gpu<800> lwmod(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, 0, o);
+    double lwll = 0.0;
+    for (size_t row = 0; row < 6; ++row) {
+        lwmod.filter(data[row], vec1{row ? data[row - 1].v : 0.0});
+        lwll += lwmod.getLogCondLike();
+    }
+    std::printf("liu_west %.17g\n", lwll);
+    // (7) utils::read_data stand-in
+    const auto rows = ssme_gpu::read_data(argv[1], 1);
+    std::printf("read_data %zu %.17g\n", rows.size(), rows.empty() ? 0.0 : rows[0](0));
     // (4) error mapping
     try { std::vector<vec1> empty; ssme_gpu::log_like_eval_gpu(theta, empty, 100, 1, o); std::printf("no-throw\n"); }
     catch (const std::length_error&) { std::printf("length_error ok\n"); }

@@ -38,3 +38,39 @@ def test_adaptor_matches_oracle(oracle, spy):
     assert float(vals["svol_leverage"]) == sum(ol.step(y[t], z[t]) for t in range(8))
     assert abs(float(vals["expect42"]) - 42.0) < 1e-4
     assert vals["length_error"].strip() == "ok"
+    assert abs(float(vals["evaluator"]) - oracle.log_mean_exp(np.array(lls))) < 1e-12
+    lw = oracle.LWFilter(800, 77)
+    assert float(vals["liu_west"]) == sum(lw.step(y[t], z[t]) for t in range(6))
+    n, first = vals["read_data"].split()
+    assert int(n) == spy.size and float(first) == spy[0]
+
+
+def test_pmmh_harness_compiles():
+    from ssme_amd import build
+    so = build.build()
+    exe = os.path.join(ROOT, "examples", "estimate_univ_svol_gpu")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "estimate_univ_svol_gpu.cpp"), "-o", exe, so,
+                           "-Wl,-rpath," + os.path.dirname(so)])
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+def test_pmmh_harness_runs(tmp_path):
+    """The shipped example's CLI on the device: 30 iterations, 4 replicate filters of 2000 particles."""
+    exe = os.path.join(ROOT, "examples", "estimate_univ_svol_gpu")
+    if not os.path.exists(exe):
+        test_pmmh_harness_compiles()
+    import json
+    p = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "spy_returns.csv"), str(tmp_path / "samples"),
+                        str(tmp_path / "messages"), "30", "4", "2000", "7"], capture_output=True, text=True, check=True)
+    info = json.loads(p.stderr.strip().splitlines()[-1])
+    assert info["iters"] == 30 and info["T"] == 3084
+    samples = [f for f in os.listdir(tmp_path) if f.startswith("samples_")]
+    messages = [f for f in os.listdir(tmp_path) if f.startswith("messages_")]
+    assert len(samples) == 1 and len(messages) == 1
+    rows = np.loadtxt(tmp_path / samples[0], delimiter=",")
+    assert rows.shape == (30, 3) and np.all(np.isfinite(rows)) and np.all((rows[:, 1] > -1) & (rows[:, 1] < 1)) and np.all(rows[:, 2] > 0)
+    lines = open(tmp_path / messages[0]).read().splitlines()
+    assert lines[0].startswith("iter number, accept rate, old_ll") and len(lines) == 31
+    assert np.isfinite(float(lines[1].split(",")[2]))

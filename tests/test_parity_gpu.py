@@ -499,3 +499,91 @@ def test_liu_west_rejects_bad_config(sa):
         sa.svol_lw_1_par(1.5, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=100)      # delta outside (0,1]
     with pytest.raises(SsmeError):
         sa.svol_lw_1_par(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=0)
+
+
+def test_set_seed_reuses_graph_and_matches_fresh_handle(sa, oracle, spy):
+    """ssme_pf_set_seed: same handle (and captured graph), new stream == a fresh handle created with that seed."""
+    y = spy[:40]
+    a = sa.ParticleFilterBank(sa.MODEL_SVOL, 5000, 2, 11, sa.RESAMP_MULTINOMIAL)
+    a.set_params([1.0, 0.95, 0.25])
+    l11 = a.run_series(y)
+    a.set_seed(12)
+    l12 = a.run_series(y)
+    b = sa.ParticleFilterBank(sa.MODEL_SVOL, 5000, 2, 12, sa.RESAMP_MULTINOMIAL)
+    b.set_params([1.0, 0.95, 0.25])
+    assert_bits_equal(l12, b.run_series(y), "set_seed vs fresh handle")
+    assert not np.array_equal(l11, l12)
+    a.set_seed(11)
+    assert_bits_equal(a.run_series(y), l11, "seed restored")
+    o = oracle.Filter(oracle.MODEL_SVOL, 5000, [1.0, 0.95, 0.25], 12, rep=1)
+    assert_bits_equal([l12[1]], [o.run_series(y)[0]], "set_seed vs oracle")
+    a.close(); b.close()
+
+
+# ---- one-tile filters: whole series in one launch (pf_small.h) ---------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 100, 256, 257, 500, 1000, 1024, 1025, 2048])
+@pytest.mark.parametrize("rs", [0, 1, 2, 3])
+def test_small_series_kernel_matches_tiled_kernel_and_oracle(sa, oracle, spy, n, rs):
+    """N <= 2048: the single-launch series kernel, the tiled per-step kernel and the oracle agree bit for bit
+    (log-likelihoods, per-step values, final particles, integer cdf, log-weights, last ancestors)."""
+    y = spy[:25]
+    th = [1.0, 0.95, 0.25]
+    outs = []
+    for small in (True, False):
+        b = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 3, 1234, rs)
+        b.set_small_series(small)
+        b.set_debug(True, True)
+        b.set_params(th)
+        ll = b.run_series(y)
+        outs.append((ll, b.per_step(), [b.state(f, ancestors=True) for f in range(3)]))
+        b.close()
+    (l0, p0, s0), (l1, p1, s1) = outs
+    assert_bits_equal(l0, l1, "series log-lik small vs tiled")
+    assert_bits_equal(p0, p1, "per-step small vs tiled")
+    for f in range(3):
+        for key in ("x", "logw"):
+            assert_bits_equal(s0[f][key][:n], s1[f][key][:n], f"{key} filter {f}")
+        np.testing.assert_array_equal(s0[f]["cdf"], s1[f]["cdf"])
+        np.testing.assert_array_equal(s0[f]["A"], s1[f]["A"])
+        assert_bits_equal(s0[f]["mb"], s1[f]["mb"], "tile max")
+        assert s0[f]["S"] == s1[f]["S"] and (s0[f]["m"] == s1[f]["m"] or (np.isnan(s0[f]["m"]) and np.isnan(s1[f]["m"])))
+        np.testing.assert_array_equal(s0[f]["anc"][:n], s1[f]["anc"][:n])
+    o = oracle.Filter(oracle.MODEL_SVOL, n, th, 1234, rep=2, resampler=rs)
+    lo, po = o.run_series(y)
+    assert_bits_equal([l0[2]], [lo], "small vs oracle")
+    assert_bits_equal(p0[2], po, "per-step small vs oracle")
+
+
+@pytest.mark.parametrize("model,th", [(1, [0.9, 0.0, 1.0, -0.1]), (2, [0.9, 0.5, 0.7])])
+def test_small_series_kernel_other_models_and_schedules(sa, oracle, spy, model, th):
+    y = spy[:30]
+    z = np.concatenate([[0.0], y[:-1]]) if model == 1 else None
+    for sched in (1, 3):
+        b = sa.ParticleFilterBank(model, 700, 2, 99, sa.RESAMP_MULTINOMIAL, sched)
+        b.set_params(th)
+        ll = b.run_series(y, z)
+        o = oracle.Filter(model, 700, th, 99, rep=1, resampler=0, resamp_sched=sched)
+        lo, po = o.run_series(y, z)
+        assert_bits_equal([ll[1]], [lo], f"model {model} sched {sched}")
+        assert_bits_equal(b.per_step()[1], po, "per-step")
+        # the step API continues from the state the series kernel handed over
+        l_next = b.step(y[5], None if z is None else z[5])
+        lo_next = o.step(y[5], 0.0 if z is None else z[5])
+        assert_bits_equal([l_next[1]], [lo_next], "step after small series")
+        b.close()
+
+
+def test_small_series_kernel_degenerate_weights(sa, oracle):
+    """NaN observation => NaN log-likelihood from that step on, no hang; huge |y| => finite or -inf handled as the oracle does."""
+    y = np.array([0.1, -0.2, np.nan, 0.3, 0.1])
+    b = sa.ParticleFilterBank(sa.MODEL_SVOL, 300, 1, 5)
+    b.set_params([1.0, 0.95, 0.25])
+    b.run_series(y)
+    o = oracle.Filter(oracle.MODEL_SVOL, 300, [1.0, 0.95, 0.25], 5)
+    _, po = o.run_series(y)
+    assert_bits_equal(b.per_step()[0], po, "NaN propagation")
+    y2 = np.array([0.1, 1e200, 0.2, -1e160, 0.0])
+    b.run_series(y2)
+    _, po2 = oracle.Filter(oracle.MODEL_SVOL, 300, [1.0, 0.95, 0.25], 5).run_series(y2)
+    assert_bits_equal(b.per_step()[0], po2, "extreme observations")
+    b.close()
