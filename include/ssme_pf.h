@@ -169,6 +169,34 @@ int ssme_pf_test_copy(int32_t device, int64_t n_doubles, int32_t repeats);
 int ssme_pf_test_gamma(int32_t device, uint64_t seed, uint32_t rep, int32_t t, double shape, int32_t n, double* out);
 
 /* ============================================================================================
+ * Particle-sharded filter: ONE filter of cfg->n_particles particles over `world` GPUs,
+ * one process per GPU.  Rank g owns tiles [g B/world, (g+1) B/world) (a tile = 2048 particles; n_particles must be a
+ * multiple of 2048 world; n_filters = 1, resamp_sched = 1).  Per time step the host side (ssme_amd/sharded.py over
+ * torch.distributed) does:   all_gather of the tile sums / maxima  ->  ssme_pf_shard_plan (which source tiles each
+ * rank's resampling touches)  ->  exchange of those tiles (cdf + particles)  ->  ssme_pf_shard_step.
+ * The level-2 arithmetic, the RNG counters (global particle index) and the Gamma tables (global tile id) are those of
+ * the unsharded filter, so a sharded run is bit-identical to ssme_pf_run_series with the same N and seed.
+ * Buffers are the caller's device pointers; all launches go to the stream given to ssme_pf_set_stream.
+ * ============================================================================================ */
+int ssme_pf_shard_create(const ssme_pf_config* cfg, int32_t rank, int32_t world, ssme_pf_handle* out);
+/* Launch on the caller's HIP stream (hipStream_t as void*; NULL = the handle's own stream). */
+int ssme_pf_set_stream(ssme_pf_handle h, void* hip_stream);
+/* Uploads the series, draws the Gamma tables of all T steps (every rank holds all tiles' draws), resets the scalars. */
+int ssme_pf_shard_prepare(ssme_pf_handle h, const double* y, const double* z, int32_t T);
+/* Step t >= 1: from the gathered tile sums / maxima of step t-1 (device, B doubles each) the inclusive source-tile range
+ * [lo, hi] of every rank: lo_hi_host[2*g], lo_hi_host[2*g+1].  Synchronises the stream. */
+int ssme_pf_shard_plan(ssme_pf_handle h, const double* tsum_all, const double* tmax_all, int32_t t, int32_t* lo_hi_host);
+/* One filter step on this rank's tiles.  x_win / cdf_win hold source tiles win_tile0 .. (at least) this rank's hi,
+ * 2048 doubles per tile (ignored at t = 0); outputs: this rank's particles, integer cdf, tile sums and maxima.
+ * anc_out (optional): global ancestor index of every output particle.  Accounts log p(y_{t-1} | .) on every rank. */
+int ssme_pf_shard_step(ssme_pf_handle h, int32_t t, const double* x_win, const double* cdf_win, int32_t win_tile0,
+                       const double* tsum_all, const double* tmax_all, double* x_out, double* cdf_out, double* tsum_out,
+                       double* tmax_out, uint32_t* anc_out);
+/* Accounts the log conditional likelihood of the last step t from its gathered tile arrays; then
+ * ssme_pf_get_loglik / ssme_pf_get_per_step return the same values on every rank. */
+int ssme_pf_shard_finalize(ssme_pf_handle h, int32_t t, const double* tsum_all, const double* tmax_all);
+
+/* ============================================================================================
  * Liu-West filter: LWFilterWithCovs<nparts,1,1,1,4,float_t>::filter (include/ssme/liu_west_filter.h:971-1159)
  * with the model of svol_lw_1_par (test/test_liu_west.cpp:22-157): parameters (phi, mu, sigma, rho), one
  * transform per parameter (parameters.h:27 enum order: 0 null, 1 twice_fisher, 2 logit, 3 log), uniform priors,

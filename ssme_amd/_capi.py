@@ -19,7 +19,8 @@ F64, F32 = 0, 1
 H_X, H_X2, H_VOL, H_CONST42 = 0, 1, 2, 3
 
 EXPORTS = [
-    "ssme_pf_create", "ssme_pf_destroy", "ssme_pf_set_params", "ssme_pf_reset", "ssme_pf_set_seed", "ssme_pf_set_small_series", "ssme_pf_step",
+    "ssme_pf_create", "ssme_pf_destroy", "ssme_pf_set_params", "ssme_pf_reset", "ssme_pf_set_seed", "ssme_pf_set_small_series", "ssme_pf_shard_create", "ssme_pf_set_stream",
+    "ssme_pf_shard_prepare", "ssme_pf_shard_plan", "ssme_pf_shard_step", "ssme_pf_shard_finalize", "ssme_pf_step",
     "ssme_pf_run_series", "ssme_pf_get_per_step", "ssme_pf_get_loglik", "ssme_pf_get_expectations",
     "ssme_pf_log_mean_exp", "ssme_pf_download_state", "ssme_pf_download_scalars", "ssme_pf_set_debug",
     "ssme_pf_set_graph_mode", "ssme_pf_set_tuning", "ssme_pf_last_elapsed_ms", "ssme_pf_profile_series", "ssme_pf_test_math",
@@ -99,6 +100,13 @@ def lib():
         L.ssme_pf_test_rescale.argtypes = [C.c_int32, u64p, dp, C.c_int32, u64p, C.c_int64]
         L.ssme_pf_test_copy.argtypes = [C.c_int32, C.c_int64, C.c_int32]
         L.ssme_pf_test_gamma.argtypes = [C.c_int32, C.c_uint64, C.c_uint32, C.c_int32, C.c_double, C.c_int32, dp]
+        L.ssme_pf_shard_create.argtypes = [C.POINTER(Config), C.c_int32, C.c_int32, C.POINTER(H)]
+        L.ssme_pf_set_stream.argtypes = [H, C.c_void_p]
+        L.ssme_pf_shard_prepare.argtypes = [H, dp, dp, C.c_int32]
+        L.ssme_pf_shard_plan.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        L.ssme_pf_shard_step.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ssme_pf_shard_finalize.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p]
         L.ssme_pf_set_seed.argtypes = [H, C.c_uint64]
         L.ssme_pf_set_small_series.argtypes = [H, C.c_int32]
         L.ssme_lw_create.argtypes = [C.POINTER(LwConfig), C.POINTER(H)]

@@ -24,6 +24,9 @@ struct ssme_pf_s {
     bool params_set;
     int debug_anc, keep_logw;
     int graph_mode;
+    int shard_rank, shard_world;   // particle-sharded filter: this handle computes tiles [rank*B/world, (rank+1)*B/world); world = 0: unsharded
+    hipStream_t own_stream;  // the stream created with the handle (stream may be replaced by ssme_pf_set_stream)
+    int32_t* plan_dev;       // [world][2] source-tile ranges (k_shard_plan)
     int small_series;        // 1: one-tile filters run the whole series in one launch (k_filter_series_small)
     int nt;                  // threads per 2048-particle tile of k_filter_step (256, 512, 1024)
     hipStream_t stream;
@@ -279,7 +282,7 @@ const char* ssme_pf_strerror(int s) {
 }
 const char* ssme_pf_last_error(ssme_pf_handle h) { return h ? h->err.c_str() : ""; }
 
-int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) {
+static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_world, ssme_pf_handle* out) {
     if (!cfg || !out) return SSME_ERR_INVALID_ARG;
     *out = nullptr;
     if (cfg->n_particles < 1 || cfg->n_filters < 1 || cfg->n_filters > 65535) return SSME_ERR_INVALID_ARG;
@@ -292,6 +295,7 @@ int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) {
     ssme_pf_handle h = new (std::nothrow) ssme_pf_s();
     if (!h) return SSME_ERR_INVALID_ARG;
     h->cfg = *cfg;
+    h->shard_rank = shard_rank; h->shard_world = shard_world;
     h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * kTile;
     h->Bs = (B + 1) & ~1; h->Bpow2 = next_pow2(B);
     h->rshift = 52 - ceil_log2(h->Npad);
@@ -303,10 +307,12 @@ int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) {
     if (e != hipSuccess) { delete h; return SSME_ERR_HIP; }
     int rc = [&]() -> int {
         HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = h->stream;
         HIPCHK(hipEventCreate(&h->ev0));
         HIPCHK(hipEventCreate(&h->ev1));
         const size_t np = (size_t)h->R * h->Npad, nb = (size_t)h->R * h->Bs;
-        for (int i = 0; i < 2; ++i) {
+        if (h->shard_world > 0) HIPCHK(hipMalloc(&h->plan_dev, sizeof(int32_t) * 2 * h->shard_world));
+        for (int i = 0; i < 2 && h->shard_world == 0; ++i) {   // a sharded handle works on the caller's buffers
             HIPCHK(hipMalloc(&h->x[i], sizeof(double) * np));
             HIPCHK(hipMalloc(&h->cdf[i], sizeof(double) * np));
             HIPCHK(hipMalloc(&h->tsum[i], sizeof(double) * nb));
@@ -325,6 +331,7 @@ int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) {
         HIPCHK(hipMalloc(&h->keybuf, sizeof(uint32_t) * 2));
         int rc2 = upload_key(h);
         if (rc2 != SSME_OK) return rc2;
+        if (h->shard_world > 0) return ensure_series_capacity(h, 1);
         rc2 = ensure_logw(h);
         if (rc2 != SSME_OK) return rc2;
         return ensure_series_capacity(h, 1);
@@ -338,14 +345,114 @@ int ssme_pf_destroy(ssme_pf_handle h) {
     if (!h) return SSME_ERR_INVALID_ARG;
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    h->stream = h->own_stream;
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     void* bufs[] = {h->x[0], h->x[1], h->cdf[0], h->cdf[1], h->tsum[0], h->tsum[1], h->tmax[0], h->tmax[1], h->logw,
-                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf};
+                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
+    return SSME_OK;
+}
+
+int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) { return create_impl(cfg, 0, 0, out); }
+
+// ---- particle-sharded filter: one filter of cfg->n_particles particles over `world` GPUs ------------------------------
+//   This handle owns rank `rank`'s share: B/world consecutive tiles.  Particle buffers
+// are the caller's (device pointers), so that the host side can hand the same memory to its collective library.
+int ssme_pf_shard_create(const ssme_pf_config* cfg, int32_t rank, int32_t world, ssme_pf_handle* out) {
+    if (!cfg || !out) return SSME_ERR_INVALID_ARG;
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) return SSME_ERR_INVALID_ARG;
+    if (cfg->n_filters != 1 || cfg->resamp_sched != 1) return SSME_ERR_UNSUPPORTED;
+    if (cfg->n_particles < 1 || cfg->n_particles % (kTile * world) != 0) return SSME_ERR_UNSUPPORTED;   // equal whole tiles per rank
+    return create_impl(cfg, rank, world, out);
+}
+
+int ssme_pf_set_stream(ssme_pf_handle h, void* hip_stream) {
+    if (!h) return SSME_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+    return SSME_OK;
+}
+
+int ssme_pf_shard_prepare(ssme_pf_handle h, const double* y, const double* z, int32_t T) {
+    if (!h || !y) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1 || !h->params_set) return SSME_ERR_STATE;
+    if (T < 1) return SSME_ERR_LENGTH;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = ensure_series_capacity(h, T);
+    if (rc != SSME_OK) return rc;
+    HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    if (z) HIPCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    h->g_has_z = z != nullptr;
+    rc = do_reset(h);
+    if (rc != SSME_OK) return rc;
+    launch_gamma(h, 0, T);                       // global tables: every rank holds all B tiles' draws
+    HIPCHK(hipGetLastError());
+    return SSME_OK;
+}
+
+static StepArgs shard_args(ssme_pf_handle h, int t, const double* tsum_all, const double* tmax_all) {
+    StepArgs a = step_args(h);
+    a.tsum_in = tsum_all; a.tmax_in = tmax_all;
+    a.z = h->g_has_z ? h->zbuf : nullptr;
+    a.per_step = h->per_step;
+    a.t = t; a.yi = t; a.gi = t;
+    a.logw = nullptr; a.anc = nullptr;
+    return a;
+}
+
+int ssme_pf_shard_plan(ssme_pf_handle h, const double* tsum_all, const double* tmax_all, int32_t t, int32_t* lo_hi) {
+    if (!h || !tsum_all || !tmax_all || !lo_hi || t < 1) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1) return SSME_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    StepArgs a = shard_args(h, t, tsum_all, tmax_all);
+    hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(512), sizeof(double) * (h->Bpow2 < 2 ? 2 : h->Bpow2), h->stream, a,
+                       h->shard_world, h->plan_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(lo_hi, h->plan_dev, sizeof(int32_t) * 2 * h->shard_world, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SSME_OK;
+}
+
+int ssme_pf_shard_step(ssme_pf_handle h, int32_t t, const double* x_win, const double* cdf_win, int32_t win_tile0,
+                       const double* tsum_all, const double* tmax_all, double* x_out, double* cdf_out, double* tsum_out,
+                       double* tmax_out, uint32_t* anc_out) {
+    if (!h || !x_out || !cdf_out || !tsum_out || !tmax_out || t < 0) return SSME_ERR_INVALID_ARG;
+    if (t > 0 && (!x_win || !cdf_win || !tsum_all || !tmax_all || win_tile0 < 0)) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1 || !h->params_set) return SSME_ERR_STATE;
+    if (t >= h->tcap) return SSME_ERR_STATE;            // ssme_pf_shard_prepare sizes the series
+    HIPCHK(hipSetDevice(h->cfg.device));
+    StepArgs a = shard_args(h, t, tsum_all, tmax_all);
+    a.x_in = x_win; a.cdf_in = cdf_win; a.win_tile0 = win_tile0;
+    a.x_out = x_out; a.cdf_out = cdf_out; a.tsum_out = tsum_out; a.tmax_out = tmax_out;
+    a.anc = anc_out;
+    a.finalize_prev = t > 0 ? 1 : 0;
+    const int Bl = h->B / h->shard_world;
+    a.tile0 = h->shard_rank * Bl;
+    const dim3 grid(Bl, 1);
+    switch (h->cfg.model) {
+        case SSME_MODEL_SVOL: hipLaunchKernelGGL((k_filter_step<MODEL_SVOL, 512>), grid, dim3(512), h->lds_bytes, h->stream, a); break;
+        case SSME_MODEL_SVOL_LEVERAGE: hipLaunchKernelGGL((k_filter_step<MODEL_SVOL_LEVERAGE, 512>), grid, dim3(512), h->lds_bytes, h->stream, a); break;
+        default: hipLaunchKernelGGL((k_filter_step<MODEL_LIN_GAUSS, 512>), grid, dim3(512), h->lds_bytes, h->stream, a); break;
+    }
+    HIPCHK(hipGetLastError());
+    h->t = t + 1;
+    return SSME_OK;
+}
+
+int ssme_pf_shard_finalize(ssme_pf_handle h, int32_t t, const double* tsum_all, const double* tmax_all) {
+    if (!h || !tsum_all || !tmax_all || t < 0) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1) return SSME_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    StepArgs a = shard_args(h, t, tsum_all, tmax_all);
+    hipLaunchKernelGGL(kf_finalize, dim3(1), dim3(kThreads), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
     return SSME_OK;
 }
 
@@ -383,6 +490,7 @@ int ssme_pf_reset(ssme_pf_handle h) {
 // flags: bit 0 = record ancestor indices, bit 1 = keep the log-weights in memory
 int ssme_pf_set_debug(ssme_pf_handle h, int32_t flags) {
     if (!h) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
     if ((flags & 1) && !h->anc) {
         HIPCHK(hipMalloc(&h->anc, sizeof(uint32_t) * (size_t)h->R * h->Npad));
@@ -414,6 +522,7 @@ int ssme_pf_set_graph_mode(ssme_pf_handle h, int32_t mode) {
 
 int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out) {
     if (!h || !y) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;     // sharded handles are driven by ssme_pf_shard_*
     if (!h->params_set) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -442,6 +551,7 @@ static void enqueue_series(ssme_pf_handle h, int T, bool has_z) {
 
 int ssme_pf_run_series(ssme_pf_handle h, const double* y, const double* z, int32_t T, double* loglik_out) {
     if (!h || !y) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;     // sharded handles are driven by ssme_pf_shard_*
     if (T < 1) return SSME_ERR_LENGTH;
     if (!h->params_set) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -527,6 +637,7 @@ int ssme_pf_log_mean_exp(ssme_pf_handle h, double* out) {
 
 int ssme_pf_get_expectations(ssme_pf_handle h, int32_t functional, double* out) {
     if (!h || !out || functional < 0 || functional > SSME_H_CONST42) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;
     if (h->t < 1) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(k_expectation, dim3(h->R), dim3(kThreads), 0, h->stream, h->x[h->cur], h->cdf[h->cur],
@@ -539,6 +650,7 @@ int ssme_pf_get_expectations(ssme_pf_handle h, int32_t functional, double* out) 
 
 int ssme_pf_download_state(ssme_pf_handle h, int32_t f, double* x, double* logw, uint64_t* cdf, uint32_t* anc) {
     if (!h || f < 0 || f >= h->R) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
     const size_t off = (size_t)f * h->Npad;
     if (x) HIPCHK(hipMemcpyAsync(x, h->x[h->cur] + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
@@ -562,6 +674,7 @@ int ssme_pf_download_state(ssme_pf_handle h, int32_t f, double* x, double* logw,
 int ssme_pf_download_scalars(ssme_pf_handle h, int32_t f, double* max_logw, uint64_t* sum_q, uint64_t* tile_sums,
                              double* tile_max, int32_t* rshift) {
     if (!h || f < 0 || f >= h->R) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
     FilterScalars sc;
     HIPCHK(hipMemcpyAsync(&sc, h->scal + f, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
@@ -586,6 +699,7 @@ int ssme_pf_last_elapsed_ms(ssme_pf_handle h, float* ms) {
 int ssme_pf_profile_series(ssme_pf_handle h, const double* y, const double* z, int32_t T, double* mean_us,
                            int32_t* launches) {
     if (!h || !y || !mean_us || !launches) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;
     if (T < 1) return SSME_ERR_LENGTH;
     if (!h->params_set) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));

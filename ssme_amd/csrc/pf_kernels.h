@@ -89,6 +89,9 @@ struct StepArgs {
     int32_t t, yi, gi, Tcap;   // t: time index (RNG counter, schedule); yi / gi: rows of y / gamma tables
     int32_t resampler, resamp_sched;
     int32_t finalize_prev;     // account log p(y_{t-1}|.) of the previous step
+    int32_t tile0;             // particle-sharded filter: global id of this launch's first OUTPUT tile (0 otherwise); outputs
+                               // are stored at local offsets (tile - tile0)
+    int32_t win_tile0;         // global id of the first SOURCE tile held in x_in / cdf_in (0 otherwise)
     const uint32_t* keyp;      // [2] Philox key (the seed), device resident so that a captured graph survives ssme_pf_set_seed
     uint32_t first_filter;
     double logN;
@@ -418,6 +421,27 @@ __device__ __forceinline__ void level2_scan(const double (&A)[2048 / NT], const 
     S = carry;
 }
 
+// Bounds [t_lo, t_hi] of the integer resampling targets of output tile b (first particle i_first, nvalid valid
+// outputs), known without the random spacings.  Shared by k_filter_step and the shard planner (k_shard_plan),
+// which must agree to the bit on which source tiles a tile touches.
+__device__ __forceinline__ void tile_target_bounds(int resampler, double S, int N, int i_first, int nvalid, double pgam,
+                                                   double pgam_next, double G, double u0, double& t_scale, double& t_lo,
+                                                   double& t_hi) {
+    if (resampler == RESAMP_MULTINOMIAL) {
+        t_scale = S / G;                          // targets: (pgam + Gamma_b E_cum/E_tile) * S'/G  
+        t_lo = __builtin_ceil(pgam * t_scale);
+        t_hi = __builtin_ceil(pgam_next * t_scale) + (S * 0x1.0p-40 + 2.0);   // slack covers the rounding of ratio*E_tile vs Gamma_b
+    } else if (resampler == RESAMP_SYSTEMATIC) {
+        t_scale = S / (double)N;
+        t_lo = __builtin_ceil(((double)i_first + u0) * t_scale);
+        t_hi = __builtin_ceil(((double)(i_first + nvalid - 1) + u0) * t_scale);
+    } else {
+        t_scale = S / (double)N;
+        t_lo = __builtin_ceil((double)i_first * t_scale);
+        t_hi = __builtin_ceil((double)(i_first + nvalid) * t_scale);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // k_filter_step: one bootstrap-filter step for every tile of every filter.
 // grid = (B tiles, R filters), block = NT (256/512/1024: NK = 1024/NT particle pairs per thread),
@@ -442,7 +466,8 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     __shared__ double lds_d2[16];
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.x, r = blockIdx.y;
+    const int b = blockIdx.x + a.tile0, r = blockIdx.y;   // global tile id (tile0 = 0 unless the filter is sharded over GPUs)
+    const int out0 = a.tile0 * kTile, win0 = a.win_tile0 * kTile;
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const uint32_t key0 = a.keyp[0], key1 = a.keyp[1];
     const size_t rowoff = (size_t)r * a.Npad;
@@ -450,7 +475,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     const double y = a.y[a.yi];
     const double zcov = a.z ? a.z[a.yi] : 0.0;
     const bool resampled = (a.t > 0) && (a.t % a.resamp_sched == 0);
-    const bool need_l2 = (a.t > 0) && (resampled || (b == 0 && a.finalize_prev));
+    const bool need_l2 = (a.t > 0) && (resampled || (blockIdx.x == 0 && a.finalize_prev));
     const bool sorted = a.resampler != RESAMP_MULTINOMIAL_IID;
     const int i_first = b * kTile;
     const int nvalid = (a.N - i_first) < kTile ? (a.N - i_first) : kTile;    // valid outputs in this tile (>= 1)
@@ -483,23 +508,12 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         level2_scan<NT>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d1, lds_seg_l2);
         STAMP(a, 14);
         // bounds [t_lo, t_hi] of this tile's targets, known to every thread without the spacings
-        const double Sd = S;
         double t_lo = 0.0, t_hi = dinf();
-        if (a.resampler == RESAMP_MULTINOMIAL) {
-            t_scale = Sd / G;                          // targets: (pgam + Gamma_b E_cum/E_tile) * S'/G  
-            t_lo = __builtin_ceil(pgam * t_scale);
-            t_hi = __builtin_ceil(pgam_next * t_scale) + (S * 0x1.0p-40 + 2.0);   // slack covers the rounding of ratio*E_tile vs Gamma_b
-        } else if (a.resampler == RESAMP_SYSTEMATIC) {
+        if (a.resampler == RESAMP_SYSTEMATIC) {
             const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, key0, key1);
             u0 = u01_co(ox.v0, ox.v1);
-            t_scale = Sd / (double)a.N;
-            t_lo = __builtin_ceil(((double)i_first + u0) * t_scale);
-            t_hi = __builtin_ceil(((double)(i_first + nvalid - 1) + u0) * t_scale);
-        } else {
-            t_scale = Sd / (double)a.N;
-            t_lo = __builtin_ceil((double)i_first * t_scale);
-            t_hi = __builtin_ceil((double)(i_first + nvalid) * t_scale);
         }
+        tile_target_bounds(a.resampler, S, a.N, i_first, nvalid, pgam, pgam_next, G, u0, t_scale, t_lo, t_hi);
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             if (e * NT < a.Bpow2) {
@@ -517,7 +531,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             }
         }
         STAMP(a, 15);
-        if (b == 0 && tid == 0 && a.finalize_prev) {
+        if (blockIdx.x == 0 && tid == 0 && a.finalize_prev) {
             FilterScalars* sc = a.scal + r;
             const double Sdd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
             const double lse = m + dlog(Sdd);
@@ -550,7 +564,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             span = __builtin_amdgcn_readfirstlane(hi) - bb_min + 1;
         }
         if (span <= kStageTiles) {
-            const double* src = cdf_r + (size_t)bb_min * kTile + tid * 2;
+            const double* src = cdf_r + (size_t)(bb_min - a.win_tile0) * kTile + tid * 2;
 #pragma unroll
             for (int k = 0; k < NK; ++k) stg0[k] = *reinterpret_cast<const double2*>(src + k * NT * 2);
             if (span >= 2) {
@@ -593,7 +607,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     } else if (!resampled) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            const size_t idx = rowoff + (size_t)i_first + (k * NT + tid) * 2;
+            const size_t idx = rowoff + (size_t)(i_first - out0) + (k * NT + tid) * 2;
             const double2 xv = *reinterpret_cast<const double2*>(a.x_in + idx);
             const double2 lv = *reinterpret_cast<const double2*>(a.logw + idx);
             xin[k][0] = xv.x; xin[k][1] = xv.y; lw_old[k][0] = lv.x; lw_old[k][1] = lv.y;
@@ -670,8 +684,8 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                     int anc = (bb_min + sel) * kTile + j;
                     anc = anc < a.N - 1 ? anc : a.N - 1;
                     const int i = i_first + (k * NT + tid) * 2 + c;
-                    if (a.anc && i < a.N) a.anc[rowoff + i] = (uint32_t)anc;
-                    xin[k][c] = xin_r[anc];
+                    if (a.anc && i < a.N) a.anc[rowoff + i - out0] = (uint32_t)anc;
+                    xin[k][c] = xin_r[anc - win0];
                     lw_old[k][c] = 0.0;
                 }
             }
@@ -686,13 +700,13 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                     bb = bb < a.B - 1 ? bb : a.B - 1;
                     const double Pb = bb ? lds_T[bb - 1] : 0.0;
                     const double tloc = __builtin_ceil((target - Pb) * lds_R[bb]);
-                    const double* tile = cdf_r + (size_t)bb * kTile;
+                    const double* tile = cdf_r + (size_t)(bb - a.win_tile0) * kTile;
                     const int j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
                     int anc = bb * kTile + j;
                     anc = anc < a.N - 1 ? anc : a.N - 1;
                     const int i = i_first + (k * NT + tid) * 2 + c;
-                    if (a.anc && i < a.N) a.anc[rowoff + i] = (uint32_t)anc;
-                    xin[k][c] = xin_r[anc];
+                    if (a.anc && i < a.N) a.anc[rowoff + i - out0] = (uint32_t)anc;
+                    xin[k][c] = xin_r[anc - win0];
                     lw_old[k][c] = 0.0;
                 }
             }
@@ -727,7 +741,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             lg[k][c] = valid ? l : -dinf();
             if (valid) { nan = nan || (l != l); mx = (l > mx) ? l : mx; }
         }
-        const size_t idx = rowoff + (size_t)i0;
+        const size_t idx = rowoff + (size_t)(i0 - out0);
         *reinterpret_cast<double2*>(a.x_out + idx) = make_double2(xo[0], xo[1]);
         if (a.logw) *reinterpret_cast<double2*>(a.logw + idx) = make_double2(lg[k][0], lg[k][1]);
     }
@@ -755,12 +769,12 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int i0 = i_first + (k * NT + tid) * 2;
-        *reinterpret_cast<double2*>(a.cdf_out + rowoff + i0) = make_double2(inc[k][0], inc[k][1]);
+        *reinterpret_cast<double2*>(a.cdf_out + rowoff + (i0 - out0)) = make_double2(inc[k][0], inc[k][1]);
     }
     STAMP(a, 10);
     if (tid == 0) {
-        a.tsum_out[(size_t)r * a.Bs + b] = total;
-        a.tmax_out[(size_t)r * a.Bs + b] = mb;
+        a.tsum_out[(size_t)r * a.Bs + (b - a.tile0)] = total;
+        a.tmax_out[(size_t)r * a.Bs + (b - a.tile0)] = mb;
     }
 #ifdef SSME_ABLATE
     __syncthreads();
@@ -792,6 +806,58 @@ __global__ __launch_bounds__(kThreads) void kf_finalize(const StepArgs a) {
         sc->loglik = sc->loglik + ll;
         sc->prev = resample_now ? a.logN : lse;
         if (a.per_step) a.per_step[(size_t)r * a.Tcap + a.t] = ll;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Particle-sharded filter (one filter over `world` GPUs, B/world tiles each): the range of SOURCE tiles
+// [lo, hi] that the output tiles of every rank touch at step a.t, from the gathered tile sums / maxima.
+// Runs the same level-2 and the same target bounds as k_filter_step, so the ranges are exact.
+// grid = 1, block = 512, dynamic LDS = max(Bpow2, 2) doubles.  lo_hi: [world][2] ints.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_shard_plan(const StepArgs a, int world, int32_t* lo_hi) {
+    constexpr int NT = 512, NE = 2048 / NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_plan[];
+    double* lds_T = reinterpret_cast<double*>(smem_plan);
+    __shared__ double lds_seg[64];
+    __shared__ double lds_d[16];
+    const int tid = threadIdx.x;
+    double A2[NE], M2[NE], Ap[NE], Tinc[NE], S, m;
+    level2_load<NT>(a.tsum_in, a.tmax_in, a.B, A2, M2);
+    level2_scan<NT>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int j = e * NT + tid;
+        if (j < a.Bpow2) lds_T[j] = (j < a.B) ? Tinc[e] : dinf();
+    }
+    __syncthreads();
+    if (tid < world) {
+        const int Bl = a.B / world, bF = tid * Bl, bL = bF + Bl - 1;
+        int lo = 0, hi = a.B - 1;
+        if (a.resampler != RESAMP_MULTINOMIAL_IID) {
+            const uint32_t key0 = a.keyp[0], key1 = a.keyp[1];
+            double G = 1.0, pgF = 0.0, pgFn = 0.0, pgL = 0.0, pgLn = 0.0, u0 = 0.0;
+            if (a.resampler == RESAMP_MULTINOMIAL) {
+                const size_t g0 = (size_t)a.gi * a.B;                       // R = 1
+                G = a.gtot[a.gi];
+                pgF = a.pgam[g0 + bF]; pgFn = (bF + 1 < a.B) ? a.pgam[g0 + bF + 1] : G;
+                pgL = a.pgam[g0 + bL]; pgLn = (bL + 1 < a.B) ? a.pgam[g0 + bL + 1] : G;
+            } else if (a.resampler == RESAMP_SYSTEMATIC) {
+                const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, a.first_filter, STREAM_RESAMP_EXTRA, key0, key1);
+                u0 = u01_co(ox.v0, ox.v1);
+            }
+            const int iF = bF * kTile, iL = bL * kTile;
+            const int nvF = (a.N - iF) < kTile ? (a.N - iF) : kTile, nvL = (a.N - iL) < kTile ? (a.N - iL) : kTile;
+            double ts, t_lo, t_hi, unused;
+            tile_target_bounds(a.resampler, S, a.N, iF, nvF, pgF, pgFn, G, u0, ts, t_lo, unused);
+            tile_target_bounds(a.resampler, S, a.N, iL, nvL, pgL, pgLn, G, u0, ts, unused, t_hi);
+            lo = count_less_pow2(a.Bpow2, t_lo, [&](int j) { return lds_T[j]; });
+            hi = count_less_pow2(a.Bpow2, t_hi, [&](int j) { return lds_T[j]; });
+            lo = lo < a.B - 1 ? lo : a.B - 1;
+            hi = hi < a.B - 1 ? hi : a.B - 1;
+        }
+        lo_hi[2 * tid] = lo;
+        lo_hi[2 * tid + 1] = hi;
     }
 }
 

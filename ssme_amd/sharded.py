@@ -1,0 +1,215 @@
+"""One particle filter sharded over the GPUs of a node.
+
+One process per GPU; rank g owns N/G consecutive particles = B/G tiles of 2048.  A time step is
+
+    1. all_gather of the per-tile weight sums and maxima of step t-1 (B x 16 bytes in total).  Every rank then runs
+       the SAME exact level-2 (global max, rescaled integer tile sums, exact scan): the global log-sum-exp, hence
+       log p(y_{t-1} | y_{1:t-2}), and the global weight cdf over tiles.  This is the north star's "allreduce of the
+       global log-weight sum", done as gather + deterministic integer scan so that the result does not depend on G.
+    2. ssme_pf_shard_plan: which source tiles each rank's resampling targets fall into (sorted targets => one
+       contiguous range per rank, mostly its own tiles when the weights are balanced).
+    3. exchange of those tiles (integer cdf + particles, 32 KiB per tile) with grouped point-to-point sends: the
+       "all-to-all for post-resample particle redistribution", done BEFORE the search so that every rank resamples
+       exactly its own N/G offspring and no rebalancing step is needed afterwards.
+    4. ssme_pf_shard_step: the unsharded filter's fused step kernel on this rank's tiles.
+
+RNG counters use global particle indices and the Gamma tables global tile ids, so a sharded run is bit-identical to
+`ParticleFilterBank.run_series` with the same N and seed, for every G (tests/test_sharded_gpu.py).
+
+The reference has no distributed filter; the single-process semantics reproduced are BSFilter::filter's
+(example/estimate_univ_svol.h:121-127).  Collectives go through torch.distributed: backend "nccl" (= RCCL over xGMI)
+exchanges device tensors; backend "gloo" (CPU rehearsal, several ranks on one GPU) stages them through host memory.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import SsmeError
+
+TILE = 2048
+
+__all__ = ["ShardedParticleFilter", "exchange_plan", "TILE"]
+
+
+def exchange_plan(lo_hi, tiles_per_rank, rank):
+    """Who sends which tiles to whom, from the planner's inclusive source ranges.
+
+    lo_hi: sequence of (lo, hi) per destination rank (global tile ids).  Returns (sends, recvs):
+      sends[d] = (first, count) of MY tiles (global ids) that rank d needs (count may be 0);
+      recvs[s] = (first, count) of rank s's tiles that I need.
+    The received pieces, concatenated in rank order, are the contiguous window lo_hi[rank][0] .. lo_hi[rank][1].
+    """
+    world = len(lo_hi)
+    my_first, my_last = rank * tiles_per_rank, (rank + 1) * tiles_per_rank - 1
+    sends, recvs = [], []
+    for d in range(world):
+        lo, hi = int(lo_hi[d][0]), int(lo_hi[d][1])
+        a, b = max(lo, my_first), min(hi, my_last)
+        sends.append((a, b - a + 1) if b >= a else (my_first, 0))
+    lo, hi = int(lo_hi[rank][0]), int(lo_hi[rank][1])
+    for s in range(world):
+        s_first, s_last = s * tiles_per_rank, (s + 1) * tiles_per_rank - 1
+        a, b = max(lo, s_first), min(hi, s_last)
+        recvs.append((a, b - a + 1) if b >= a else (s_first, 0))
+    assert sum(c for _, c in recvs) == hi - lo + 1
+    return sends, recvs
+
+
+def exchange_tiles(local, my_first_tile, sends, recvs, rank, group=None, stage_through_host=False):
+    """Grouped point-to-point exchange of whole tiles.  local: [tiles_per_rank, W] tensor (this rank's tiles);
+    returns the window [sum(recv counts), W] in global tile order.  Works for any backend with send/recv."""
+    import torch
+    import torch.distributed as dist
+    world = len(sends)
+    total = sum(c for _, c in recvs)
+    comm_dev = torch.device("cpu") if stage_through_host else local.device
+    window = torch.empty((total, local.shape[1]), dtype=local.dtype, device=comm_dev)
+    src = local.to(comm_dev) if stage_through_host else local
+    ops, off = [], 0
+    for s in range(world):
+        first, cnt = recvs[s]
+        if cnt:
+            piece = window[off:off + cnt]
+            if s == rank:
+                piece.copy_(src[first - my_first_tile:first - my_first_tile + cnt])
+            else:
+                ops.append(dist.P2POp(dist.irecv, piece, s if group is None else dist.get_global_rank(group, s), group))
+            off += cnt
+    for d in range(world):
+        first, cnt = sends[d]
+        if cnt and d != rank:
+            piece = src[first - my_first_tile:first - my_first_tile + cnt].contiguous()
+            ops.append(dist.P2POp(dist.isend, piece, d if group is None else dist.get_global_rank(group, d), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return window.to(local.device) if stage_through_host else window
+
+
+class ShardedParticleFilter:
+    """Bootstrap filter with its N particles sharded over the ranks of a torch.distributed group."""
+
+    def __init__(self, model, n_particles, seed=0, resampler=capi.RESAMP_MULTINOMIAL, device=None, group=None, filter_id=0):
+        import torch
+        import torch.distributed as dist
+        assert dist.is_initialized(), "init_process_group first (one process per GPU)"
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.stage = self.backend != "nccl"                     # gloo rehearsal: collectives on host copies
+        if n_particles % (TILE * self.world) != 0:
+            raise SsmeError(capi.ERR_UNSUPPORTED, f"n_particles must be a multiple of {TILE} x world ({self.world})")
+        self.n, self.B = int(n_particles), n_particles // TILE
+        self.Bl = self.B // self.world
+        self.tile0 = self.rank * self.Bl
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        cfg = capi.Config(model=model, n_particles=n_particles, n_filters=1, dtype=capi.F64, resampler=resampler, resamp_sched=1,
+                          seed=seed, device=self.device.index or 0, first_filter_id=filter_id)
+        self._h = C.c_void_p()
+        capi.check(capi.lib().ssme_pf_shard_create(C.byref(cfg), self.rank, self.world, C.byref(self._h)))
+        # one side stream for kernels, staging copies and (nccl) collectives: torch's default stream has handle 0,
+        # which ssme_pf_set_stream reads as "use the handle's own stream"
+        self._stream = torch.cuda.Stream(self.device)
+        self._chk(capi.lib().ssme_pf_set_stream(self._h, C.c_void_p(self._stream.cuda_stream)))
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.x = torch.zeros((self.Bl, TILE), **f64)            # this rank's particles after the last step
+        self.cdf = torch.zeros((self.Bl, TILE), **f64)          # tile-local integer cdf (integers < 2^53 in fp64)
+        self.tiles_loc = torch.zeros((2, self.Bl), **f64)       # row 0: tile sums, row 1: tile maxima
+        self.tiles_all = torch.zeros((2, self.B), **f64)
+        self.anc = None
+        self.exchanged_tiles = 0                                # tiles received from other ranks (statistics)
+        self._T = 0
+        torch.cuda.synchronize(self.device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            capi.lib().ssme_pf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _chk(self, status):
+        if status != capi.OK:
+            msg = capi.lib().ssme_pf_strerror(status).decode()
+            if status == capi.ERR_HIP:
+                msg += " (" + capi.lib().ssme_pf_last_error(self._h).decode() + ")"
+            raise SsmeError(status, msg)
+
+    def set_params(self, theta):
+        th = np.ascontiguousarray(theta, dtype=np.float64).reshape(1, -1)
+        self._chk(capi.lib().ssme_pf_set_params(self._h, capi.dptr(th), th.shape[1], 1))
+
+    def record_ancestors(self, on=True):
+        import torch
+        self.anc = torch.zeros((self.Bl, TILE), dtype=torch.int32, device=self.device) if on else None
+
+    # ---- collectives --------------------------------------------------------------------------------------------
+    def _gather_tiles(self):
+        """tiles_all[:, g*Bl:(g+1)*Bl] = rank g's tiles_loc."""
+        import torch
+        import torch.distributed as dist
+        loc = self.tiles_loc.cpu() if self.stage else self.tiles_loc
+        parts = [torch.empty((2, self.Bl), dtype=loc.dtype, device=loc.device) for _ in range(self.world)]
+        dist.all_gather(parts, loc.contiguous(), group=self.group)
+        self.tiles_all.copy_(torch.cat(parts, dim=1), non_blocking=False)
+
+    def _ptr(self, t):
+        return C.c_void_p(t.data_ptr())
+
+    # ---- the series loop ------------------------------------------------------------------------------------------
+    def run_series(self, y, z=None):
+        """log p(y_{1:T}) of the sharded filter; identical on every rank."""
+        import torch
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._stream):
+            return self._run_series(y, z)
+
+    def _run_series(self, y, z):
+        import torch
+        yv = capi.as_f64(y)
+        zv = None if z is None else capi.as_f64(z)
+        T = yv.size
+        L = capi.lib()
+        self._chk(L.ssme_pf_shard_prepare(self._h, capi.dptr(yv), capi.dptr(zv), T))
+        ts, tm = self.tiles_all[0], self.tiles_all[1]
+        x_new, cdf_new = torch.empty_like(self.x), torch.empty_like(self.cdf)
+        lo_hi = (C.c_int32 * (2 * self.world))()
+        self.exchanged_tiles = 0
+        for t in range(T):
+            if t == 0:
+                xw = cw = None
+                win0 = 0
+            else:
+                self._gather_tiles()
+                self._chk(L.ssme_pf_shard_plan(self._h, self._ptr(ts), self._ptr(tm), t, lo_hi))
+                plan = [(lo_hi[2 * g], lo_hi[2 * g + 1]) for g in range(self.world)]
+                sends, recvs = exchange_plan(plan, self.Bl, self.rank)
+                self.exchanged_tiles += sum(c for s, (_, c) in enumerate(recvs) if s != self.rank)
+                cw = exchange_tiles(self.cdf, self.tile0, sends, recvs, self.rank, self.group, self.stage)
+                xw = exchange_tiles(self.x, self.tile0, sends, recvs, self.rank, self.group, self.stage)
+                win0 = plan[self.rank][0]
+            self._chk(L.ssme_pf_shard_step(
+                self._h, t, None if xw is None else self._ptr(xw), None if cw is None else self._ptr(cw), win0,
+                self._ptr(ts), self._ptr(tm), self._ptr(x_new), self._ptr(cdf_new), self._ptr(self.tiles_loc[0]),
+                self._ptr(self.tiles_loc[1]), None if self.anc is None else self._ptr(self.anc)))
+            # the windows must outlive the kernel that reads them: same stream, freed by the caching allocator in order
+            self.x, x_new = x_new, self.x
+            self.cdf, cdf_new = cdf_new, self.cdf
+        self._gather_tiles()
+        self._chk(L.ssme_pf_shard_finalize(self._h, T - 1, self._ptr(ts), self._ptr(tm)))
+        self._T = T
+        out = np.empty(1)
+        self._chk(L.ssme_pf_get_loglik(self._h, capi.dptr(out)))
+        return float(out[0])
+
+    def per_step(self):
+        out = np.empty((1, self._T))
+        self._chk(capi.lib().ssme_pf_get_per_step(self._h, capi.dptr(out), self._T))
+        return out[0]
+
+    def local_particles(self):
+        return self.x.reshape(-1).cpu().numpy()
+
+    def local_cdf(self):
+        return self.cdf.reshape(-1).cpu().numpy()

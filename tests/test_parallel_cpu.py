@@ -70,3 +70,58 @@ def test_gather_logliks_gloo_world2(n_filters):
         assert allv == expect                       # every rank sees all filters, in filter-id order
         assert lme == log_mean_exp(expect)
         assert tmax == 2.0                          # MAX over ranks, as bench.py does for the timing
+
+
+# ---- particle-sharded filter: host-side exchange logic (ssme_amd/sharded.py) ---------------------------------------
+def test_exchange_plan_covers_exactly_the_planned_windows():
+    from ssme_amd.sharded import exchange_plan
+    rng = np.random.default_rng(0)
+    for world, Bl in ((2, 4), (4, 8), (8, 2), (3, 5)):
+        B = world * Bl
+        for _ in range(50):
+            lo = np.sort(rng.integers(0, B, world))
+            hi = np.maximum(lo, np.sort(rng.integers(0, B, world)))
+            plan = list(zip(lo.tolist(), hi.tolist()))
+            all_sends = [exchange_plan(plan, Bl, r)[0] for r in range(world)]
+            for r in range(world):
+                sends, recvs = exchange_plan(plan, Bl, r)
+                tiles = [t for first, cnt in recvs for t in range(first, first + cnt)]
+                assert tiles == list(range(plan[r][0], plan[r][1] + 1))          # contiguous window in global order
+                for s in range(world):
+                    assert recvs[s] == all_sends[s][r] or (recvs[s][1] == 0 and all_sends[s][r][1] == 0)
+                    first, cnt = recvs[s]
+                    assert cnt == 0 or (s * Bl <= first and first + cnt <= (s + 1) * Bl)
+
+
+def _exchange_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssme_amd.sharded import exchange_plan, exchange_tiles
+    Bl, W = 3, 8
+    local = (torch.arange(Bl * W, dtype=torch.float64).reshape(Bl, W) + 1000.0 * rank)
+    plan = [(0, 4), (2, 5)]                                   # rank 0 needs tiles 0..4, rank 1 needs 2..5
+    sends, recvs = exchange_plan(plan, Bl, rank)
+    win = exchange_tiles(local, rank * Bl, sends, recvs, rank)
+    q.put((rank, win.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_tiles_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Bl, W = 3, 8
+    full = np.concatenate([np.arange(Bl * W, dtype=np.float64).reshape(Bl, W) + 1000.0 * r for r in range(2)])
+    np.testing.assert_array_equal(got[0], full[0:5])
+    np.testing.assert_array_equal(got[1], full[2:6])
