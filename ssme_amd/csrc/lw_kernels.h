@@ -407,8 +407,16 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid(const LwArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int c = (a.B + 63) / 64;
     for (int q = wave; q < kNMom; q += 4) {
+        // same order of additions as a plain loop; the loads are issued eight at a time so that their latencies overlap
         double acc = 0.0;
-        for (int j = lane * c; j < (lane + 1) * c && j < a.B; ++j) acc = acc + a.mom[((size_t)r * a.B + j) * 16 + q];
+        const int j0 = lane * c, j1 = ((lane + 1) * c < a.B) ? (lane + 1) * c : a.B;
+        for (int j = j0; j < j1; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (j + u < j1) ? a.mom[((size_t)r * a.B + j + u) * 16 + q] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (j + u < j1) acc = acc + v[u];
+        }
         const double s = wave_incl_scan_f64(acc);
         if (lane == 63) sums[q] = s;
     }
