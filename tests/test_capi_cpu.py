@@ -71,7 +71,50 @@ def test_product_never_imports_oracle():
     import sys
     code = "import sys, ssme_amd, ssme_amd._capi; assert not any(m.startswith('oracle') for m in sys.modules), sys.modules.keys()"
     subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
-    for fn in ("_capi.py", "filters.py", "__init__.py", "build.py", "csrc/pf_api.hip", "csrc/pf_kernels.h",
-               "csrc/ssme_math.h"):
+    for fn in ("_capi.py", "filters.py", "__init__.py", "build.py", "parallel.py", "sharded.py", "csrc/pf_api.hip",
+               "csrc/pf_kernels.h", "csrc/pf_small.h", "csrc/lw_kernels.h", "csrc/ssme_math.h"):
         text = open(os.path.join(ROOT, "ssme_amd", fn)).read()
         assert "import oracle" not in text and "from oracle" not in text and "libssme_oracle" not in text
+
+
+def test_shard_and_liu_west_entry_points_validate_arguments():
+    """Argument checks happen before any HIP call, so they are testable without a device."""
+    from ssme_amd import _capi
+    L = _capi.lib()
+    h = C.c_void_p()
+    cfg = _capi.Config(model=0, n_particles=4 * 2048, n_filters=1, dtype=0, resampler=0, resamp_sched=1, seed=1, device=0,
+                       first_filter_id=0)
+    assert L.ssme_pf_shard_create(C.byref(cfg), 0, 0, C.byref(h)) == _capi.ERR_INVALID_ARG        # world < 1
+    assert L.ssme_pf_shard_create(C.byref(cfg), 2, 2, C.byref(h)) == _capi.ERR_INVALID_ARG        # rank >= world
+    assert L.ssme_pf_shard_create(C.byref(cfg), 0, 3, C.byref(h)) == _capi.ERR_UNSUPPORTED        # 4 tiles over 3 ranks
+    cfg.n_filters = 2
+    assert L.ssme_pf_shard_create(C.byref(cfg), 0, 2, C.byref(h)) == _capi.ERR_UNSUPPORTED        # one filter only
+    cfg.n_filters, cfg.resamp_sched = 1, 2
+    assert L.ssme_pf_shard_create(C.byref(cfg), 0, 2, C.byref(h)) == _capi.ERR_UNSUPPORTED
+    assert not h.value
+    for fn in (L.ssme_pf_set_stream, ):
+        assert fn(None, None) == _capi.ERR_INVALID_ARG
+    assert L.ssme_pf_set_seed(None, 1) == _capi.ERR_INVALID_ARG
+    assert L.ssme_pf_set_small_series(None, 1) == _capi.ERR_INVALID_ARG
+    lw = _capi.LwConfig(n_particles=100, n_filters=1, seed=1, device=0, first_filter_id=0, delta=0.99)
+    lw.transforms[:] = [2, 0, 3, 1]
+    lw.prior_lo[:] = [0.8, -0.1, 0.01, -0.5]
+    lw.prior_hi[:] = [0.99, 0.1, 0.1, -0.01]
+    for field, value in (("delta", 0.0), ("delta", 1.5), ("n_particles", 0), ("n_filters", 0)):
+        bad = _capi.LwConfig.from_buffer_copy(lw)
+        setattr(bad, field, value)
+        assert L.ssme_lw_create(C.byref(bad), C.byref(h)) == _capi.ERR_INVALID_ARG
+    bad = _capi.LwConfig.from_buffer_copy(lw)
+    bad.transforms[1] = 9
+    assert L.ssme_lw_create(C.byref(bad), C.byref(h)) == _capi.ERR_INVALID_ARG
+    bad = _capi.LwConfig.from_buffer_copy(lw)
+    bad.prior_lo[0], bad.prior_hi[0] = 0.9, 0.8                                                  # empty prior interval
+    assert L.ssme_lw_create(C.byref(bad), C.byref(h)) == _capi.ERR_INVALID_ARG
+    assert L.ssme_lw_destroy(None) == _capi.ERR_INVALID_ARG
+    assert not h.value
+
+
+def test_sharded_python_class_requires_process_group():
+    from ssme_amd.sharded import ShardedParticleFilter
+    with pytest.raises(AssertionError):
+        ShardedParticleFilter(0, 4096)
