@@ -225,6 +225,61 @@ private:
     float_t last_ = 0;
 };
 
+// ---- SwarmWithCovs over SVOL-leverage members (include/ssme/pswarm_filter.h:325-560; test/test_pswarm.cpp:146-208) ----
+// All nparamparts member filters live in ONE handle (n_filters = nparamparts, one theta row each): update(y, z) is one
+// launch; the swarm's log conditional likelihood and expectations are the plain averages over the members, as the
+// reference's intra/inter_agg_func compute them (:392-460).  samp_untrans_params() is the reference's pure virtual.
+template <std::size_t n_state_parts, std::size_t n_param_parts, typename float_t = double>
+class swarm_with_covs_gpu {
+public:
+    using float_type = float_t;
+    using func = int;                                            // SSME_H_* functional id
+    explicit swarm_with_covs_gpu(const std::vector<func>& fs, gpu_options o = gpu_options()) : fs_(fs), opt_(o) {}
+    virtual ~swarm_with_covs_gpu() = default;
+    virtual std::vector<float_t> samp_untrans_params() = 0;      // order phi, mu, sigma, rho
+
+    template <typename Osv, typename Csv>
+    void update(const Osv& yt, const Csv& zt) {
+        if (!h_) finish_construction();
+        const double y = (double)yt(0), z = (double)zt(0);
+        std::vector<double> ll(n_param_parts), e(n_param_parts);
+        check(ssme_pf_step(h_.get(), &y, &z, ll.data()), h_.get());
+        double s = 0.0;
+        for (double v : ll) s += v;
+        log_cond_like_ = (float_t)(s / (double)n_param_parts);
+        expectations_.assign(fs_.size(), 0.0);
+        for (std::size_t i = 0; i < fs_.size(); ++i) {
+            check(ssme_pf_get_expectations(h_.get(), fs_[i], e.data()), h_.get());
+            double se = 0.0;
+            for (double v : e) se += v;
+            expectations_[i] = se / (double)n_param_parts;
+        }
+        ++num_obs_;
+    }
+    float_t getLogCondLike() const { return log_cond_like_; }
+    std::vector<double> getExpectations() const { return expectations_; }
+    const std::vector<double>& params() const { return theta_; }         // [n_param_parts][4]
+
+private:
+    void finish_construction() {                                  // pswarm_filter.h:280-304
+        theta_.resize(n_param_parts * 4);
+        for (std::size_t i = 0; i < n_param_parts; ++i) {
+            const std::vector<float_t> p = samp_untrans_params();
+            if (p.size() != 4) throw std::invalid_argument("samp_untrans_params must return phi, mu, sigma, rho");
+            for (int d = 0; d < 4; ++d) theta_[i * 4 + d] = (double)p[d];
+        }
+        h_ = handle(SSME_MODEL_SVOL_LEVERAGE, (int)n_state_parts, (int)n_param_parts, opt_.seed, opt_.resampler, opt_.resamp_sched,
+                    opt_.device, 0);
+        check(ssme_pf_set_params(h_.get(), theta_.data(), 4, (int)n_param_parts), h_.get());
+    }
+    std::vector<func> fs_;
+    gpu_options opt_;
+    handle h_;
+    std::vector<double> theta_, expectations_;
+    float_t log_cond_like_ = 0;
+    unsigned num_obs_ = 0;
+};
+
 // ---- headerless CSV -> rows of doubles (utils::read_data, include/ssme/utils.h:25-64) -------------------------------
 // Same tolerance as the reference: rows that fail to parse are skipped; an unreadable file yields an empty vector
 // (callers then throw length_error, estimate_univ_svol.h:112-113).

@@ -16,7 +16,7 @@ from . import _capi as capi
 from ._capi import (MODEL_LIN_GAUSS, MODEL_SVOL, MODEL_SVOL_LEVERAGE, RESAMP_MULTINOMIAL, RESAMP_MULTINOMIAL_IID,
                     RESAMP_STRATIFIED, RESAMP_SYSTEMATIC, SsmeError)
 
-__all__ = ["ParticleFilterBank", "svol_bs", "svol_leverage", "lin_gauss_bs", "log_like_eval", "svol_lw_1_par",
+__all__ = ["ParticleFilterBank", "svol_bs", "svol_leverage", "lin_gauss_bs", "log_like_eval", "svol_lw_1_par", "SwarmWithCovs", "svol_swarm_1",
            "TR_NULL", "TR_TWICE_FISHER", "TR_LOGIT", "TR_LOG",
            "MODEL_SVOL", "MODEL_SVOL_LEVERAGE", "MODEL_LIN_GAUSS", "RESAMP_MULTINOMIAL", "RESAMP_SYSTEMATIC",
            "RESAMP_STRATIFIED", "RESAMP_MULTINOMIAL_IID", "SsmeError"]
@@ -220,6 +220,71 @@ def log_like_eval(untrans_theta, data, nparts=500, num_pfilters=1, seed=0, resam
     finally:
         if own:
             bank.close()
+
+
+# ---- particle swarm ---------------------------------------------------------------------------------------------
+class SwarmWithCovs:
+    """include/ssme/pswarm_filter.h:325-560: nparamparts bootstrap filters, one parameter draw each, advanced together.
+
+    update(y, z) = filter(y, z, fs) on every member (comp_func :380-388), then the swarm's log conditional likelihood and
+    expectations are the plain averages over members (intra/inter_agg_func :392-460: uniform weights, parameters come
+    from the prior).  All members live in ONE handle (n_filters = nparamparts, one theta row each), so an update is one
+    kernel launch.  Subclasses give samp_untrans_params() (the reference's pure virtual); fs are SSME_H_* ids.
+    """
+    _model = MODEL_SVOL_LEVERAGE
+
+    def __init__(self, fs, nstateparts, nparamparts, seed=0, resampler=RESAMP_MULTINOMIAL, device=0, first_filter_id=0):
+        self._fs = tuple(int(f) for f in fs)
+        self._args = (int(nstateparts), int(nparamparts), seed, resampler, 1, device)
+        self._first = first_filter_id
+        self._bank = None
+        self._lcl = 0.0
+        self._exp = [0.0] * len(self._fs)
+        self.num_obs = 0
+        self.params = None
+
+    def samp_untrans_params(self):
+        raise NotImplementedError("subclasses sample one untransformed parameter vector, as the reference's pure virtual")
+
+    def _finish_construction(self):                         # pswarm_filter.h:280-304
+        n, r = self._args[0], self._args[1]
+        self.params = np.array([self.samp_untrans_params() for _ in range(r)], dtype=np.float64)
+        self._bank = ParticleFilterBank(self._model, n, r, *self._args[2:], first_filter_id=self._first)
+        self._bank.set_params(self.params)
+
+    def update(self, y, z=0.0):
+        if self._bank is None:
+            self._finish_construction()
+        ll = self._bank.step(float(np.ravel(y)[0]), float(np.ravel(z)[0]))
+        self._member_lcl = ll
+        self._lcl = float(np.sum(ll) / ll.size)
+        self._exp = [float(np.sum(self._bank.expectations(f)) / ll.size) for f in self._fs]
+        self.num_obs += 1
+
+    def getLogCondLike(self):
+        return self._lcl
+
+    def getExpectations(self):
+        return list(self._exp)
+
+    def close(self):
+        if self._bank is not None:
+            self._bank.close()
+            self._bank = None
+
+
+class svol_swarm_1(SwarmWithCovs):
+    """test/test_pswarm.cpp:146-208: SVOL-leverage members, parameters (phi, mu, sigma, rho) drawn from uniform priors."""
+
+    def __init__(self, fs, phi_l, phi_u, mu_l, mu_u, sig_l, sig_u, rho_l, rho_u, dte=0, nstateparts=500, nparamparts=100,
+                 prior_seed=0, **kw):
+        super().__init__(fs, nstateparts, nparamparts, **kw)
+        self._lo = np.array([phi_l, mu_l, sig_l, rho_l], dtype=np.float64)
+        self._hi = np.array([phi_u, mu_u, sig_u, rho_u], dtype=np.float64)
+        self._rng = np.random.default_rng(prior_seed)
+
+    def samp_untrans_params(self):
+        return self._lo + (self._hi - self._lo) * self._rng.random(4)
 
 
 # ---- Liu-West -------------------------------------------------------------------------------------------------

@@ -17,6 +17,16 @@ struct pack3 {                         // stand-in for param::pack<double,3>::ge
     vec1 get_untrans_params(unsigned a, unsigned) const { return vec1{p[a]}; }
 };
 
+// svol_swarm_1 of test/test_pswarm.cpp:146-208 with a deterministic stand-in for its uniform prior samplers
+struct test_swarm : ssme_gpu::swarm_with_covs_gpu<600, 5, double> {
+    using ssme_gpu::swarm_with_covs_gpu<600, 5, double>::swarm_with_covs_gpu;
+    int k = 0;
+    std::vector<double> samp_untrans_params() override {
+        const double u = 0.1 + 0.2 * k++;
+        return {0.8 + 0.19 * u, -0.1 + 0.2 * u, 0.01 + 0.09 * u, -0.5 + 0.49 * u};
+    }
+};
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::vector<vec1> data;
@@ -61,6 +71,16 @@ int main(int argc, char** argv) {
     // (7) utils::read_data stand-in
     const auto rows = ssme_gpu::read_data(argv[1], 1);
     std::printf("read_data %zu %.17g\n", rows.size(), rows.empty() ? 0.0 : rows[0](0));
+    // (8) particle swarm as test/test_pswarm.cpp:236-252 drives it
+    test_swarm sw({SSME_H_CONST42, SSME_H_X}, o);
+    double swll = 0.0;
+    for (size_t row = 0; row < 5; ++row) {
+        sw.update(data[row], vec1{row ? data[row - 1].v : 0.0});
+        swll += sw.getLogCondLike();
+    }
+    std::printf("swarm %.17g\n", swll);
+    std::printf("swarm42 %.17g\n", sw.getExpectations()[0]);
+    std::printf("swarmx %.17g\n", sw.getExpectations()[1]);
     // (4) error mapping
     try { std::vector<vec1> empty; ssme_gpu::log_like_eval_gpu(theta, empty, 100, 1, o); std::printf("no-throw\n"); }
     catch (const std::length_error&) { std::printf("length_error ok\n"); }

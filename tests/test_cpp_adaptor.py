@@ -41,6 +41,20 @@ def test_adaptor_matches_oracle(oracle, spy):
     assert abs(float(vals["evaluator"]) - oracle.log_mean_exp(np.array(lls))) < 1e-12
     lw = oracle.LWFilter(800, 77)
     assert float(vals["liu_west"]) == sum(lw.step(y[t], z[t]) for t in range(6))
+    # swarm: 5 members, theta rows as test_swarm::samp_untrans_params, plain averages over members
+    mem = []
+    for k in range(5):
+        u = 0.1 + 0.2 * k
+        th = [0.8 + 0.19 * u, -0.1 + 0.2 * u, 0.01 + 0.09 * u, -0.5 + 0.49 * u]
+        mem.append(oracle.Filter(oracle.MODEL_SVOL_LEVERAGE, 600, th, 77, rep=k))
+    tot, ex = 0.0, 0.0
+    for t in range(5):
+        lls = [m.step(y[t], z[t]) for m in mem]
+        tot += sum(lls) / 5
+        ex = sum(m.expectation(0) for m in mem) / 5
+    assert abs(float(vals["swarm"]) - tot) < 1e-12
+    assert abs(float(vals["swarm42"]) - 42.0) < 1e-4
+    assert abs(float(vals["swarmx"]) - ex) < 1e-9
     n, first = vals["read_data"].split()
     assert int(n) == spy.size and float(first) == spy[0]
 

@@ -587,3 +587,31 @@ def test_small_series_kernel_degenerate_weights(sa, oracle):
     _, po2 = oracle.Filter(oracle.MODEL_SVOL, 300, [1.0, 0.95, 0.25], 5).run_series(y2)
     assert_bits_equal(b.per_step()[0], po2, "extreme observations")
     b.close()
+
+
+# ---- particle swarm (pswarm_filter.h:325-560; test_pswarm.cpp:236-252) ------------------------------------------------
+def test_swarm_with_covs_matches_oracle_members(sa, oracle, spy):
+    from ssme_amd import _capi
+    R, n, T = 12, 1500, 6
+    sw = sa.svol_swarm_1([_capi.H_CONST42, _capi.H_X, _capi.H_VOL], .8, .99, -.1, .1, .01, .1, -.5, -.01, 10, nstateparts=n,
+                         nparamparts=R, prior_seed=3, seed=21)
+    y = spy[:T]
+    z = np.concatenate([[0.0], y[:-1]])
+    sw.update(y[0], z[0])                                  # the reference's test: one update, E[42] = 42, lcl^2 > 0
+    assert sw.getLogCondLike() ** 2 > 0.0 and abs(sw.getExpectations()[0] - 42.0) < 1e-4
+    th = sw.params
+    assert th.shape == (R, 4) and np.all(th[:, 0] >= .8) and np.all(th[:, 0] <= .99) and np.all(th[:, 3] <= -.01)
+    members = [oracle.Filter(oracle.MODEL_SVOL_LEVERAGE, n, th[r], 21, rep=r) for r in range(R)]
+    lls = np.array([m.step(y[0], z[0]) for m in members])
+    assert_bits_equal(sw._member_lcl, lls, "member log-cond-likes, t=0")
+    for t in range(1, T):
+        sw.update(y[t], z[t])
+        lls = np.array([m.step(y[t], z[t]) for m in members])
+        assert_bits_equal(sw._member_lcl, lls, f"member log-cond-likes, t={t}")
+        assert sw.getLogCondLike() == float(np.sum(lls) / R)
+        ex = sw.getExpectations()
+        assert abs(ex[0] - 42.0) < 1e-4
+        for k, kind in ((1, 0), (2, 2)):
+            want = sum(m.expectation(kind) for m in members) / R
+            assert abs(ex[k] - want) <= 1e-9 * max(1.0, abs(want))
+    sw.close()
