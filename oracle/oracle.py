@@ -25,6 +25,30 @@ def build(force=False):
     return _SO
 
 
+_REF_SO = os.path.join(_HERE, "_ref", "libref_thread_pool.so")
+
+
+def build_ref(reference="/root/reference"):
+    """oracle/_ref: the reference's own thread_pool.h behind a driver (only where /root/reference exists; the GPU box
+    uses the prebuilt file).  Returns the path or None."""
+    hdr = os.path.join(reference, "include", "ssme", "thread_pool.h")
+    if os.path.exists(hdr):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "_ref", "REF=" + reference], stdout=subprocess.DEVNULL)
+    return _REF_SO if os.path.exists(_REF_SO) else None
+
+
+def ref_log_mean_exp(v):
+    """log-mean-exp computed BY THE REFERENCE (thread_pool<>::work); None if oracle/_ref is not built."""
+    so = build_ref()
+    if so is None:
+        return None
+    L = C.CDLL(so)
+    L.ref_thread_pool_log_mean_exp.restype = C.c_double
+    L.ref_thread_pool_log_mean_exp.argtypes = [C.POINTER(C.c_double), C.c_int]
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    return float(L.ref_thread_pool_log_mean_exp(v.ctypes.data_as(C.POINTER(C.c_double)), v.size))
+
+
 _lib = None
 
 

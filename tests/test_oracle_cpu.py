@@ -311,3 +311,20 @@ def test_liu_west_delta_one_freezes_parameters(oracle):
     s = f.state()
     for d in range(4):
         assert set(np.unique(s["theta"][d]).tolist()) <= set(np.unique(th0[d]).tolist())
+
+
+# ---- oracle/_ref: the reference's own thread_pool.h (the one hot-path header that builds here) -----------------------
+def test_log_mean_exp_pinned_by_reference_thread_pool(oracle):
+    """thread_pool<>::work (thread_pool.h:189-215,263-268) computes the replicate log-mean-exp; the oracle's and the
+    product host code's versions must agree with it.  Skipped only if oracle/_ref could not be built or shipped."""
+    if oracle.build_ref() is None:
+        pytest.skip("oracle/_ref not available (no /root/reference and no prebuilt library)")
+    from ssme_amd.parallel import log_mean_exp
+    assert abs(oracle.ref_log_mean_exp(np.full(10000, 3.0)) - 3.0) < 1e-3        # the reference's own KAT, test_thread_pool.cpp:39-46
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 7, 100, 1000):
+        for scale in (1e-3, 1.0, 50.0, 700.0):
+            v = -4700.0 + scale * rng.standard_normal(n)
+            want = oracle.ref_log_mean_exp(v)
+            assert abs(oracle.log_mean_exp(v) - want) <= 1e-12 * abs(want)
+            assert abs(log_mean_exp(v) - want) <= 1e-12 * abs(want)

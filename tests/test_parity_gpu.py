@@ -615,3 +615,15 @@ def test_swarm_with_covs_matches_oracle_members(sa, oracle, spy):
             want = sum(m.expectation(kind) for m in members) / R
             assert abs(ex[k] - want) <= 1e-9 * max(1.0, abs(want))
     sw.close()
+
+
+def test_device_log_mean_exp_against_reference_thread_pool(sa, oracle, spy):
+    """ssme_pf_log_mean_exp over R replicate filters == the reference's thread_pool<>::work on the same R values."""
+    if oracle.build_ref() is None:
+        pytest.skip("oracle/_ref not available")
+    b = sa.ParticleFilterBank(sa.MODEL_SVOL, 3000, 16, 8)
+    b.set_params([1.0, 0.95, 0.25])
+    ll = b.run_series(spy[:200])
+    want = oracle.ref_log_mean_exp(ll)
+    assert abs(b.log_mean_exp() - want) <= 1e-12 * abs(want)
+    b.close()
