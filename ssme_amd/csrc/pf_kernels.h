@@ -421,6 +421,17 @@ __device__ __forceinline__ void level2_scan(const double (&A)[2048 / NT], const 
     S = carry;
 }
 
+// Workgroup -> tile map.  Workgroups are dispatched round-robin over the 8 XCDs (workgroup id mod 8), and each XCD has
+// its own L2.  Consecutive tiles share source cdf tiles (a tile's sorted targets fall into 1-3 neighbouring tiles), so
+// XCD k is given a CONTIGUOUS range of tiles: the re-reads of a neighbour's tile then hit that XCD's L2 instead of
+// being fetched once per XCD.  Any bijection is correct (results do not depend on the map).
+__device__ __forceinline__ int xcd_tile_of_block(int bid, int nblocks) {
+    constexpr int kXcd = 8;
+    const int q = nblocks / kXcd, r = nblocks % kXcd;
+    const int k = bid % kXcd, idx = bid / kXcd;
+    return k * q + (k < r ? k : r) + idx;
+}
+
 // Bounds [t_lo, t_hi] of the integer resampling targets of output tile b (first particle i_first, nvalid valid
 // outputs), known without the random spacings.  Shared by k_filter_step and the shard planner (k_shard_plan),
 // which must agree to the bit on which source tiles a tile touches.
@@ -466,7 +477,10 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     __shared__ double lds_d2[16];
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.x + a.tile0, r = blockIdx.y;   // global tile id (tile0 = 0 unless the filter is sharded over GPUs)
+    // (filter, tile) of this workgroup: the launch's tiles in filter-major order, a contiguous range per XCD
+    const int gtile = xcd_tile_of_block((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int r = gtile / (int)gridDim.x, bloc = gtile - r * (int)gridDim.x;
+    const int b = bloc + a.tile0;                       // global tile id (tile0 = 0 unless the filter is sharded over GPUs)
     const int out0 = a.tile0 * kTile, win0 = a.win_tile0 * kTile;
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const uint32_t key0 = a.keyp[0], key1 = a.keyp[1];
@@ -475,7 +489,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     const double y = a.y[a.yi];
     const double zcov = a.z ? a.z[a.yi] : 0.0;
     const bool resampled = (a.t > 0) && (a.t % a.resamp_sched == 0);
-    const bool need_l2 = (a.t > 0) && (resampled || (blockIdx.x == 0 && a.finalize_prev));
+    const bool need_l2 = (a.t > 0) && (resampled || (bloc == 0 && a.finalize_prev));
     const bool sorted = a.resampler != RESAMP_MULTINOMIAL_IID;
     const int i_first = b * kTile;
     const int nvalid = (a.N - i_first) < kTile ? (a.N - i_first) : kTile;    // valid outputs in this tile (>= 1)
@@ -531,7 +545,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             }
         }
         STAMP(a, 15);
-        if (blockIdx.x == 0 && tid == 0 && a.finalize_prev) {
+        if (bloc == 0 && tid == 0 && a.finalize_prev) {
             FilterScalars* sc = a.scal + r;
             const double Sdd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
             const double lse = m + dlog(Sdd);
