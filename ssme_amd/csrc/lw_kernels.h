@@ -274,7 +274,9 @@ __global__ __launch_bounds__(kLwNT) void k_lw_init(const LwArgs a) {
     constexpr int NT = kLwNT, NK = 2;
     __shared__ double lds_seg_c[16];
     __shared__ double lds_d2[16];
-    const int tid = threadIdx.x, b = blockIdx.x, r = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int gtile = xcd_tile_of_block((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int r = gtile / (int)gridDim.x, b = gtile - r * (int)gridDim.x;      // XCD-contiguous (filter, tile) map
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const size_t rowoff = (size_t)r * a.Npad;
     const double y = a.y[a.yi];
@@ -314,7 +316,9 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
     constexpr int NT = kLwNT, NK = 2;
     LW_LDS_SETUP(a)
     __shared__ double lds_mom[8][kNMom];
-    const int tid = threadIdx.x, b = blockIdx.x, r = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int gtile = xcd_tile_of_block((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int r = gtile / (int)gridDim.x, b = gtile - r * (int)gridDim.x;      // XCD-contiguous (filter, tile) map
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const size_t rowoff = (size_t)r * a.Npad;
     const double y = a.y[a.yi], z = a.z ? a.z[a.yi] : 0.0;
@@ -455,7 +459,9 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid(const LwArgs a) {
 __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
     constexpr int NT = kLwNT, NK = 2;
     LW_LDS_SETUP(a)
-    const int tid = threadIdx.x, b = blockIdx.x, r = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int gtile = xcd_tile_of_block((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int r = gtile / (int)gridDim.x, b = gtile - r * (int)gridDim.x;      // XCD-contiguous (filter, tile) map
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const size_t rowoff = (size_t)r * a.Npad;
     const double y = a.y[a.yi], z = a.z ? a.z[a.yi] : 0.0;
