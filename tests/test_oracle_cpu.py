@@ -1,5 +1,7 @@
 """CPU suite: pins the oracle (oracle/) against every known-answer value the reference's own
 files hold for this path, against independent anchors, and against the committed golden vectors."""
+import os
+
 import numpy as np
 import pytest
 
@@ -328,3 +330,16 @@ def test_log_mean_exp_pinned_by_reference_thread_pool(oracle):
             want = oracle.ref_log_mean_exp(v)
             assert abs(oracle.log_mean_exp(v) - want) <= 1e-12 * abs(want)
             assert abs(log_mean_exp(v) - want) <= 1e-12 * abs(want)
+
+
+@pytest.mark.parametrize("n", [300, 5000])
+@pytest.mark.parametrize("delta", [0.99, 0.9])
+def test_liu_west_oracle_reproduces_golden(oracle, n, delta):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "liu_west_golden.npz"))
+    f = oracle.LWFilter(n, int(g["seed"][0]), rep=1, delta=delta)
+    lls = [f.step(g["y"][t], g["z"][t]) for t in range(g["y"].size)]
+    k = f"lw_n{n}_d{int(round(delta * 100))}"
+    np.testing.assert_array_equal(np.array(lls), g[k + "_ll"])
+    st = f.state()
+    for name in ("x", "theta", "kidx", "anc", "thetabar", "L"):
+        np.testing.assert_array_equal(st[name], g[k + "_" + name])

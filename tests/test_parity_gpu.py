@@ -627,3 +627,25 @@ def test_device_log_mean_exp_against_reference_thread_pool(sa, oracle, spy):
     want = oracle.ref_log_mean_exp(ll)
     assert abs(b.log_mean_exp() - want) <= 1e-12 * abs(want)
     b.close()
+
+
+@pytest.mark.parametrize("n", [300, 5000])
+@pytest.mark.parametrize("delta", [0.99, 0.9])
+def test_liu_west_device_reproduces_golden(sa, n, delta):
+    """The HIP Liu-West filter against the committed golden vectors (no oracle involved at run time)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "liu_west_golden.npz"))
+    f = sa.svol_lw_1_par(delta, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, seed=int(g["seed"][0]), first_filter_id=1)
+    f.set_debug(True)
+    lls = []
+    for t in range(g["y"].size):
+        f.filter(g["y"][t], g["z"][t])
+        lls.append(f.getLogCondLike())
+    k = f"lw_n{n}_d{int(round(delta * 100))}"
+    assert_bits_equal(lls, g[k + "_ll"], "LW golden log-cond-likes")
+    st = f.state(0, indices=True)
+    assert_bits_equal(st["x"], g[k + "_x"], "LW golden x")
+    assert_bits_equal(st["theta"], g[k + "_theta"], "LW golden theta")
+    np.testing.assert_array_equal(st["kidx"], g[k + "_kidx"])
+    np.testing.assert_array_equal(st["anc"], g[k + "_anc"])
+    f.close()
