@@ -14,6 +14,9 @@
 //   * param::pack inverse transforms / log-Jacobian KATs   test/test_parameters.cpp:114-145
 //   * log-mean-exp of replicates KAT                       test/test_thread_pool.cpp:39-46
 //   * constant-functional expectation == 42                test/test_pswarm.cpp:252
+// and from the reference RUN here: include/ssme/thread_pool.h is the one hot-path header that needs only the
+// standard library; oracle/_ref builds it where it lies (oracle/ref_thread_pool_driver.cpp, `make _ref`) and
+// orc_log_mean_exp / the product's log-mean-exp are checked against thread_pool<>::work itself.
 // Independent anchors added by this repo: exact Kalman log-likelihood of a linear-Gaussian
 // model, agreement between the two RNG modes below, Random123 Philox4x32-10 KATs.
 //
