@@ -678,9 +678,13 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             const double R0 = lds_R[bb_min], R1 = lds_R[b1], R2 = lds_R[b2];
             __syncthreads();
             STAMP(a, 5);
+            // All 2*NK count-searches of a thread descend together, one level per iteration: the probes of a level are
+            // independent LDS reads, so the phase costs log2(2048) = 11 dependent LDS round trips instead of one chain
+            // per particle (this phase is bound by LDS latency, not by issue slots).
+            double tloc[NK][2];
+            int base[NK][2], pos[NK][2];
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                int sel_prev = -1, j_prev = 0;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const double target = tau[k][c];
@@ -688,14 +692,30 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                     sel = sel < span - 1 ? sel : span - 1;
                     const double Pb = sel == 0 ? Pm : (sel == 1 ? T0 : T1);
                     const double Rb = sel == 0 ? R0 : (sel == 1 ? R1 : R2);
-                    const double tloc = __builtin_ceil((target - Pb) * Rb);
-                    const double* tile = lds_stage + sel * kTile;
-                    int j;
-                    if (ABL(a, 2)) j = (int)(d2bits(tloc) >> 20) & 2047;
-                    else if (c == 1 && sel == sel_prev) j = count_less_gallop(tile, tloc, j_prev);   // sorted: count >= j_prev
-                    else j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
-                    sel_prev = sel; j_prev = j;
-                    int anc = (bb_min + sel) * kTile + j;
+                    tloc[k][c] = __builtin_ceil((target - Pb) * Rb);
+                    base[k][c] = sel * kTile;
+                    pos[k][c] = 0;
+                }
+            }
+            if (ABL(a, 2)) {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) { pos[k][0] = (int)(d2bits(tloc[k][0]) >> 20) & 2047; pos[k][1] = (int)(d2bits(tloc[k][1]) >> 20) & 2047; }
+            } else {
+#pragma unroll
+                for (int step = kTile >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            if (lds_stage[base[k][c] + pos[k][c] + step - 1] < tloc[k][c]) pos[k][c] += step;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    int anc = bb_min * kTile + base[k][c] + pos[k][c];
                     anc = anc < a.N - 1 ? anc : a.N - 1;
                     const int i = i_first + (k * NT + tid) * 2 + c;
                     if (a.anc && i < a.N) a.anc[rowoff + i - out0] = (uint32_t)anc;

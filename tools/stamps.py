@@ -43,3 +43,15 @@ for k in order[1:]:
     print(f"  {names[k]:28s}", np.round(d, 2))
     prev = k
 print("  block ids", idx)
+# first-dispatched (id < 256: one per CU) vs second-dispatched workgroups of each CU
+half = s.shape[0] // 2
+for nm, sl in (("first half ", slice(0, half)), ("second half", slice(half, None))):
+    d = (s[sl, 11] - s[sl, 0]) / 100.0
+    st = (s[sl, 0] - t0) / 100.0
+    en = (s[sl, 11] - t0) / 100.0
+    print(f"{nm}: start {st.mean():.2f}  duration {d.mean():.2f} (min {d.min():.2f} max {d.max():.2f})  end {en.mean():.2f}")
+    prev = 0
+    row = []
+    for k in order[1:]:
+        row.append(round(float(((s[sl, k] - s[sl, prev]) / 100.0).mean()), 2)); prev = k
+    print("   phases:", row)
