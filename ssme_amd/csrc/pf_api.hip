@@ -27,6 +27,7 @@ struct ssme_pf_s {
     int shard_rank, shard_world;   // particle-sharded filter: this handle computes tiles [rank*B/world, (rank+1)*B/world); world = 0: unsharded
     hipStream_t own_stream;  // the stream created with the handle (stream may be replaced by ssme_pf_set_stream)
     int32_t* plan_dev;       // [world][2] source-tile ranges (k_shard_plan)
+    int num_cus;             // compute units of the device (priority schedule of the step kernel)
     int small_series;        // 1: one-tile filters run the whole series in one launch (k_filter_series_small)
     int nt;                  // threads per 2048-particle tile of k_filter_step (256, 512, 1024)
     hipStream_t stream;
@@ -109,6 +110,11 @@ static StepArgs step_args(ssme_pf_handle h) {
     a.resampler = h->cfg.resampler; a.resamp_sched = h->cfg.resamp_sched;
     a.keyp = h->keybuf; a.first_filter = h->cfg.first_filter_id;
     a.logN = dlog((double)h->N);
+    {
+        // two 512-thread workgroups fit a CU (LDS): is the whole grid resident at once?
+        const long blocks = (long)(h->shard_world > 0 ? h->B / h->shard_world : h->B) * h->R;
+        a.prio_mode = (blocks <= 2L * h->num_cus) ? 1 : 2;
+    }
 #ifdef SSME_ABLATE
     { const char* e = getenv("SSME_ABLATE_MASK"); a.ablate = e ? atoi(e) : 0; }
     {
@@ -305,6 +311,10 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     h->nt = 512;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) { delete h; return SSME_ERR_HIP; }
+    {
+        int cus = 0;
+        h->num_cus = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) ? cus : 256;
+    }
     int rc = [&]() -> int {
         HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->own_stream = h->stream;

@@ -92,6 +92,7 @@ struct StepArgs {
     int32_t tile0;             // particle-sharded filter: global id of this launch's first OUTPUT tile (0 otherwise); outputs
                                // are stored at local offsets (tile - tile0)
     int32_t win_tile0;         // global id of the first SOURCE tile held in x_in / cdf_in (0 otherwise)
+    int32_t prio_mode;         // wave-priority schedule of k_filter_step (prio_at): 0 none, 1 single residency wave, 2 several
     const uint32_t* keyp;      // [2] Philox key (the seed), device resident so that a captured graph survives ssme_pf_set_seed
     uint32_t first_filter;
     double logN;
@@ -453,6 +454,25 @@ __device__ __forceinline__ void tile_target_bounds(int resampler, double S, int 
     }
 }
 
+
+// Wave priority by phase.  Two workgroups share a CU and the hardware issues the OLDER waves first, so without this the
+// first-dispatched workgroup runs at full speed, the second one lags by ~5 us, and for that tail the CU holds half its
+// waves.  Lowering the priority as a workgroup advances lets the one that is behind catch up:
+// both then finish together and the CU stays full.  mode 1 (the whole grid is resident at once: 20.3 -> 19.2 us at
+// N = 2^20): 3 | after the tile loads are issued 2 | after the search 1 | after logG 0.  mode 2 (several residency waves of
+// workgroups, e.g. 4096 filters' tiles; +2 %): 3 | 2 | after the LDS fill 1 | after the search 0.  Scheduling only --
+// results do not depend on it.
+__device__ __forceinline__ void prio_at(int mode, int idx) {
+    if (mode == 1) {
+        if (idx == 0) __builtin_amdgcn_s_setprio(3); else if (idx == 3) __builtin_amdgcn_s_setprio(2);
+        else if (idx == 6) __builtin_amdgcn_s_setprio(1); else if (idx == 8) __builtin_amdgcn_s_setprio(0);
+    } else if (mode == 2) {
+        if (idx == 0) __builtin_amdgcn_s_setprio(3); else if (idx == 3) __builtin_amdgcn_s_setprio(2);
+        else if (idx == 5) __builtin_amdgcn_s_setprio(1); else if (idx == 6) __builtin_amdgcn_s_setprio(0);
+    }
+}
+#define PRIO_AT(i) prio_at(a.prio_mode, i)
+
 // ---------------------------------------------------------------------------------------
 // k_filter_step: one bootstrap-filter step for every tile of every filter.
 // grid = (B tiles, R filters), block = NT (256/512/1024: NK = 1024/NT particle pairs per thread),
@@ -495,6 +515,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     const int nvalid = (a.N - i_first) < kTile ? (a.N - i_first) : kTile;    // valid outputs in this tile (>= 1)
 
     STAMP(a, 0);
+    PRIO_AT(0);
     // --- issue the level-2 loads first: previous step's tile sums and maxima ---
     constexpr int NE = 2048 / NT;
     double A2[NE], M2[NE];
@@ -509,6 +530,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     }
 
     STAMP(a, 1);
+    PRIO_AT(1);
     // --- level-2: global max, rescaled tile sums A', inclusive prefixes T', total S'; tile range of my targets ---
     double S = 0.0;
     double t_scale = 0.0, u0 = 0.0;
@@ -559,6 +581,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         }
     }
     STAMP(a, 2);
+    PRIO_AT(2);
 
     // --- request the cdf tiles my targets fall into (coalesced 16-byte loads into registers) ---
     int bb_min = 0, span = kStageTiles + 1;
@@ -592,6 +615,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         }
     }
     STAMP(a, 3);
+    PRIO_AT(3);
 
     // --- exponential spacings of the multinomial resampler (liu_west_filter.h:105-139), exact tile scan;
     //     this arithmetic hides the latency of the tile loads ---
@@ -613,6 +637,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         block_scan_f64<NT>(qe, le, se, lds_seg_a);
     }
     STAMP(a, 4);
+    PRIO_AT(4);
 
     double xin[NK][2], lw_old[NK][2];
     if (a.t == 0) {
@@ -678,6 +703,8 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             const double R0 = lds_R[bb_min], R1 = lds_R[b1], R2 = lds_R[b2];
             __syncthreads();
             STAMP(a, 5);
+            PRIO_AT(5);
+    PRIO_AT(5);
             // All 2*NK count-searches of a thread descend together, one level per iteration: the probes of a level are
             // independent LDS reads, so the phase costs log2(2048) = 11 dependent LDS round trips instead of one chain
             // per particle (this phase is bound by LDS latency, not by issue slots).
@@ -747,6 +774,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         }
     }
     STAMP(a, 6);
+    PRIO_AT(6);
 
     // --- standard normals (Box-Muller); this arithmetic hides the latency of the ancestor gather ---
     double zn[NK][2];
@@ -757,6 +785,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         else normal_pair(pair, (uint32_t)a.t, rep, key0, key1, &zn[k][0], &zn[k][1]);
     }
     STAMP(a, 7);
+    PRIO_AT(7);
 
     // --- fSamp / q1Samp, logGEv, tile max ---
     double lg[NK][2];
@@ -780,8 +809,10 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         if (a.logw) *reinterpret_cast<double2*>(a.logw + idx) = make_double2(lg[k][0], lg[k][1]);
     }
     STAMP(a, 8);
+    PRIO_AT(8);
     const double mb = block_max_nanprop<NT>(mx, nan, lds_d2);
     STAMP(a, 9);
+    PRIO_AT(9);
 
     // --- tile-local fixed-point weights and their exact inclusive scan (the next step's cdf) ---
     double q[NK][2], inc[NK][2], total;
@@ -800,12 +831,14 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         total = inc[0][1] + 1048576.0;
     } else block_scan_f64<NT>(q, inc, total, lds_seg_c);
     STAMP(a, 12);
+    PRIO_AT(12);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int i0 = i_first + (k * NT + tid) * 2;
         *reinterpret_cast<double2*>(a.cdf_out + rowoff + (i0 - out0)) = make_double2(inc[k][0], inc[k][1]);
     }
     STAMP(a, 10);
+    PRIO_AT(10);
     if (tid == 0) {
         a.tsum_out[(size_t)r * a.Bs + (b - a.tile0)] = total;
         a.tmax_out[(size_t)r * a.Bs + (b - a.tile0)] = mb;
@@ -813,6 +846,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 #ifdef SSME_ABLATE
     __syncthreads();
     STAMP(a, 11);
+    PRIO_AT(11);
 #endif
 }
 
