@@ -101,6 +101,7 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
     constexpr int NT = kLwNT, NK = 2, NE = 4;
     const int tid = threadIdx.x;
     const int i_first = b * kTile;
+    __builtin_amdgcn_s_setprio(3);                 // wave priority falls as the workgroup advances (see prio_at)
     double A2[NE], M2[NE];
     level2_load<NT>(tsum, tmax, B, A2, M2);
     if (tid == 0) { L.cnt[0] = 0; L.cnt[1] = 0; }
@@ -145,6 +146,7 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
             for (int k = 0; k < NK; ++k) stg2[k] = *reinterpret_cast<const double2*>(src + 2 * kTile + k * NT * 2);
         }
     }
+    __builtin_amdgcn_s_setprio(2);
     // exponential spacings (liu_west_filter.h:105-139), exact tile scan; hides the tile loads
     double qe[NK][2], le[NK][2], se;
 #pragma unroll
@@ -185,9 +187,11 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
         const double Pm = bb_min ? L.lds_T[bb_min - 1] : 0.0;
         const double R0 = L.lds_R[bb_min], R1 = L.lds_R[b1], R2 = L.lds_R[b2];
         __syncthreads();
+        // the four count-searches of a thread descend together (11 dependent LDS round trips; see k_filter_step)
+        double tloc[NK][2];
+        int base[NK][2], pos[NK][2];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            int sel_prev = -1, j_prev = 0;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const double target = tau[k][c];
@@ -195,13 +199,25 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
                 sel = sel < span - 1 ? sel : span - 1;
                 const double Pb = sel == 0 ? Pm : (sel == 1 ? T0 : T1);
                 const double Rb = sel == 0 ? R0 : (sel == 1 ? R1 : R2);
-                const double tloc = __builtin_ceil((target - Pb) * Rb);
-                const double* tile = L.lds_stage + sel * kTile;
-                int j;
-                if (c == 1 && sel == sel_prev) j = count_less_gallop(tile, tloc, j_prev);
-                else j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
-                sel_prev = sel; j_prev = j;
-                int a = (bb_min + sel) * kTile + j;
+                tloc[k][c] = __builtin_ceil((target - Pb) * Rb);
+                base[k][c] = sel * kTile;
+                pos[k][c] = 0;
+            }
+        }
+#pragma unroll
+        for (int step = kTile >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    if (L.lds_stage[base[k][c] + pos[k][c] + step - 1] < tloc[k][c]) pos[k][c] += step;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int a = bb_min * kTile + base[k][c] + pos[k][c];
                 idx[k][c] = a < N - 1 ? a : N - 1;
             }
         }
@@ -222,6 +238,7 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
             }
         }
     }
+    __builtin_amdgcn_s_setprio(1);
 }
 
 // log-weights lg[k][c] of this tile -> tile max, fixed-point weights, exact tile scan; stores cdf / tile sum / tile max
@@ -229,6 +246,7 @@ __device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int N, in
                                              double* tmax_row, int b, double* lds_d, double* lds_seg) {
     constexpr int NT = kLwNT, NK = 2;
     const int tid = threadIdx.x;
+    __builtin_amdgcn_s_setprio(0);
     double mx = -dinf();
     bool nan = false;
 #pragma unroll
