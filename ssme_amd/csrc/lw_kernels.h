@@ -424,24 +424,37 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid(const LwArgs a) {
     const int tid = threadIdx.x, r = blockIdx.x;
     double A2[8], Ap[8], Tinc[8], M2[8], S, m;
     level2_load<kThreads>(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.B, A2, M2);
-    level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
     // moment totals: wave w handles moments w, w+4, ...: 64 lanes add contiguous chunks of tiles in order, then the wave tree
     const int lane = tid & 63, wave = tid >> 6;
     const int c = (a.B + 63) / 64;
-    for (int q = wave; q < kNMom; q += 4) {
-        // same order of additions as a plain loop; the loads are issued eight at a time so that their latencies overlap
-        double acc = 0.0;
+    // wave w sums moments w, w+4, w+8, w+12; for each, lane l adds its chunk of tiles in order and the wave tree adds the
+    // 64 chunk sums.  The loads of all of a wave's moments are issued together (8 tiles x 4 moments per batch) so that
+    // one memory latency is paid per batch, not per moment; the order of the additions is that of a plain loop.
+    {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
         const int j0 = lane * c, j1 = ((lane + 1) * c < a.B) ? (lane + 1) * c : a.B;
         for (int j = j0; j < j1; j += 8) {
-            double v[8];
+            double v[4][8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (j + u < j1) ? a.mom[((size_t)r * a.B + j + u) * 16 + q] : 0.0;
+            for (int qi = 0; qi < 4; ++qi) {
+                const int q = wave + 4 * qi;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (j + u < j1) acc = acc + v[u];
+                for (int u = 0; u < 8; ++u) v[qi][u] = (q < kNMom && j + u < j1) ? a.mom[((size_t)r * a.B + j + u) * 16 + q] : 0.0;
+            }
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (j + u < j1) acc[qi] = acc[qi] + v[qi][u];
+            }
         }
-        const double s = wave_incl_scan_f64(acc);
-        if (lane == 63) sums[q] = s;
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            const int q = wave + 4 * qi;
+            const double sw = wave_incl_scan_f64(acc[qi]);
+            if (lane == 63 && q < kNMom) sums[q] = sw;
+        }
     }
+    level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
     __syncthreads();
     if (tid == 0) {
         LwScalars* sc = a.scal + r;
