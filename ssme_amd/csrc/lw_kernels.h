@@ -580,20 +580,24 @@ __global__ __launch_bounds__(kThreads) void k_lw_finalize(const LwArgs a) {
     }
 }
 
-// weighted means of the untransformed parameters under the last second-stage weights.  grid = (R), block = 256
-__global__ __launch_bounds__(kThreads) void k_lw_param_means(const LwArgs a, double* out /*[R][4]*/) {
+// Weighted means of the untransformed parameters under the last second-stage weights, two launches:
+// k_lw_param_partials, grid = (B tiles, R): per-tile sums of w and w * theta_d with w = q_j exp(m_tile - m), into the
+// moment scratch mom[r][b][0..4]; k_lw_param_means, grid = (R): adds the tile partials in tile order and divides.
+__global__ __launch_bounds__(kThreads) void k_lw_param_partials(const LwArgs a) {
     __shared__ double lds_n[4][kDP + 1];
     __shared__ double lds_m[16];
-    const int tid = threadIdx.x, r = blockIdx.x;
+    const int tid = threadIdx.x, b = blockIdx.x, r = blockIdx.y;
     double mx = -dinf();
     bool nan = false;
     for (int j = tid; j < a.B; j += kThreads) { const double v = a.tmaxB[(size_t)r * a.Bs + j]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
     const double m = block_max_nanprop<kThreads>(mx, nan, lds_m);
+    const double scale = dexp(a.tmaxB[(size_t)r * a.Bs + b] - m);
     double acc[kDP + 1] = {0, 0, 0, 0, 0};
-    for (int i = tid; i < a.N; i += kThreads) {
+    const int i_end = ((b + 1) * kTile < a.N) ? (b + 1) * kTile : a.N;
+    for (int i = b * kTile + tid; i < i_end; i += kThreads) {
         const double c1 = a.cdfB[(size_t)r * a.Npad + i];
         const double c0 = (i & (kTile - 1)) ? a.cdfB[(size_t)r * a.Npad + i - 1] : 0.0;
-        const double w = (c1 - c0) * dexp(a.tmaxB[(size_t)r * a.Bs + i / kTile] - m);
+        const double w = (c1 - c0) * scale;
         acc[kDP] += w;
         for (int d = 0; d < kDP; ++d) acc[d] += w * tr_inv(a.trans[d], a.thB[((size_t)r * kDP + d) * a.Npad + i]);
     }
@@ -603,11 +607,15 @@ __global__ __launch_bounds__(kThreads) void k_lw_param_means(const LwArgs a, dou
         if ((tid & 63) == 0) lds_n[tid >> 6][q] = v;
     }
     __syncthreads();
-    if (tid == 0) {
-        double t[kDP + 1];
-        for (int q = 0; q <= kDP; ++q) t[q] = ((lds_n[0][q] + lds_n[1][q]) + lds_n[2][q]) + lds_n[3][q];
-        for (int d = 0; d < kDP; ++d) out[(size_t)r * kDP + d] = t[d] / t[kDP];
-    }
+    if (tid <= kDP) a.mom[((size_t)r * a.B + b) * 16 + tid] = ((lds_n[0][tid] + lds_n[1][tid]) + lds_n[2][tid]) + lds_n[3][tid];
+}
+
+__global__ __launch_bounds__(kWave) void k_lw_param_means(const LwArgs a, double* out /*[R][4]*/) {
+    const int r = blockIdx.x, q = threadIdx.x;
+    double t = 0.0;
+    if (q <= kDP) for (int b = 0; b < a.B; ++b) t = t + a.mom[((size_t)r * a.B + b) * 16 + q];
+    const double den = __shfl(t, kDP, kWave);
+    if (q < kDP) out[(size_t)r * kDP + q] = t / den;
 }
 
 }  // namespace ssme

@@ -1182,7 +1182,9 @@ int ssme_lw_get_param_means(ssme_lw_handle h, double* out) {
     if (h->t < 1) return SSME_ERR_STATE;
     LWCHK(hipSetDevice(h->cfg.device));
     LwArgs a = lw_args(h);
-    hipLaunchKernelGGL(k_lw_param_means, dim3(h->R), dim3(kThreads), 0, h->stream, a, h->scratch);
+    // the per-tile moment scratch is free between steps (stage 1 rewrites it before k_lw_mid reads it)
+    hipLaunchKernelGGL(k_lw_param_partials, dim3(h->B, h->R), dim3(kThreads), 0, h->stream, a);
+    hipLaunchKernelGGL(k_lw_param_means, dim3(h->R), dim3(kWave), 0, h->stream, a, h->scratch);
     LWCHK(hipGetLastError());
     LWCHK(hipMemcpyAsync(out, h->scratch, sizeof(double) * h->R * kDP, hipMemcpyDeviceToHost, h->stream));
     LWCHK(hipStreamSynchronize(h->stream));
