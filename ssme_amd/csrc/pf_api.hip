@@ -27,6 +27,10 @@ struct ssme_pf_s {
     int shard_rank, shard_world;   // particle-sharded filter: this handle computes tiles [rank*B/world, (rank+1)*B/world); world = 0: unsharded
     hipStream_t own_stream;  // the stream created with the handle (stream may be replaced by ssme_pf_set_stream)
     int32_t* plan_dev;       // [world][2] source-tile ranges (k_shard_plan)
+    int split_l2;            // 1: level-2 by k_level2_plan (filters of more than 2048 tiles, or forced by set_debug bit 2)
+    double *l2_T, *l2_R;     // [R][Bs] split level-2 outputs
+    int32_t *l2_lo, *l2_hi;
+    size_t lds_bytes_big, lds_bytes_plan;
     int num_cus;             // compute units of the device (priority schedule of the step kernel)
     int small_series;        // 1: one-tile filters run the whole series in one launch (k_filter_series_small)
     int nt;                  // threads per 2048-particle tile of k_filter_step (256, 512, 1024)
@@ -110,6 +114,7 @@ static StepArgs step_args(ssme_pf_handle h) {
     a.resampler = h->cfg.resampler; a.resamp_sched = h->cfg.resamp_sched;
     a.keyp = h->keybuf; a.first_filter = h->cfg.first_filter_id;
     a.logN = dlog((double)h->N);
+    a.l2_T = h->l2_T; a.l2_R = h->l2_R; a.l2_lo = h->l2_lo; a.l2_hi = h->l2_hi;
     {
         // two 512-thread workgroups fit a CU (LDS): is the whole grid resident at once?
         const long blocks = (long)(h->shard_world > 0 ? h->B / h->shard_world : h->B) * h->R;
@@ -141,6 +146,11 @@ static hipError_t set_lds1(size_t bytes) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 template <int MODEL>
+static hipError_t set_lds_big(size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_step<MODEL, 512, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+template <int MODEL>
 static hipError_t set_lds(size_t bytes) {
     hipError_t e = set_lds1<MODEL, 256>(bytes);
     if (e == hipSuccess) e = set_lds1<MODEL, 512>(bytes);
@@ -151,6 +161,10 @@ static hipError_t set_lds(size_t bytes) {
 template <int MODEL>
 static void launch_step_m(ssme_pf_handle h, const StepArgs& a) {
     dim3 grid(h->B, h->R);
+    if (h->split_l2) {
+        hipLaunchKernelGGL((k_filter_step<MODEL, 512, true>), grid, dim3(512), h->lds_bytes_big, h->stream, a);
+        return;
+    }
     switch (h->nt) {
         case 256: hipLaunchKernelGGL((k_filter_step<MODEL, 256>), grid, dim3(256), h->lds_bytes, h->stream, a); break;
         case 512: hipLaunchKernelGGL((k_filter_step<MODEL, 512>), grid, dim3(512), h->lds_bytes, h->stream, a); break;
@@ -174,7 +188,15 @@ static void launch_gamma(ssme_pf_handle h, int t0, int nT) {
                        (uint32_t)STREAM_RESAMP_EXTRA);
 }
 // accounts the log conditional likelihood of step t from the buffers the step wrote (now `cur`)
+// split level-2 of the buffers `cur` holds: for the step t about to run (plan_ranges) or only the accounting of step t-1
+static void launch_plan(ssme_pf_handle h, int t, int gi, bool plan_ranges, bool finalize_prev, bool record_per_step) {
+    StepArgs a = step_args(h);
+    a.t = t; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
+    a.per_step = record_per_step ? h->per_step : nullptr;
+    hipLaunchKernelGGL(k_level2_plan, dim3(h->R), dim3(1024), h->lds_bytes_plan, h->stream, a, plan_ranges ? 1 : 0);
+}
 static void launch_kf(ssme_pf_handle h, int t, bool record_per_step) {
+    if (h->split_l2) { launch_plan(h, t + 1, 0, false, true, record_per_step); return; }
     StepArgs a = step_args(h);
     a.t = t;
     a.per_step = record_per_step ? h->per_step : nullptr;
@@ -187,6 +209,7 @@ static void enqueue_step(ssme_pf_handle h, int t, int yi, int gi, bool has_z, bo
     a.z = has_z ? h->zbuf : nullptr;
     a.per_step = record_per_step ? h->per_step : nullptr;
     a.t = t; a.yi = yi; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
+    if (h->split_l2 && t > 0) launch_plan(h, t, gi, true, finalize_prev, record_per_step);
     launch_step(h, a);
     h->cur ^= 1;
 }
@@ -297,7 +320,7 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     if (cfg->resamp_sched < 1) return SSME_ERR_INVALID_ARG;
     if (cfg->dtype != SSME_F64) return SSME_ERR_UNSUPPORTED;
     const int B = (cfg->n_particles + kTile - 1) / kTile;
-    if (B > kMaxTilesPerFilter) return SSME_ERR_UNSUPPORTED;   // N <= 2^22 per filter per GPU
+    if (B > kMaxTilesSplit || (shard_world > 0 && B > kMaxTilesPerFilter)) return SSME_ERR_UNSUPPORTED;   // N <= 2^25 per filter per GPU
     ssme_pf_handle h = new (std::nothrow) ssme_pf_s();
     if (!h) return SSME_ERR_INVALID_ARG;
     h->cfg = *cfg;
@@ -305,7 +328,10 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * kTile;
     h->Bs = (B + 1) & ~1; h->Bpow2 = next_pow2(B);
     h->rshift = 52 - ceil_log2(h->Npad);
-    h->lds_bytes = sizeof(double) * (2 * (size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2) + (size_t)kStageTiles * kTile);
+    h->split_l2 = B > kMaxTilesPerFilter ? 1 : 0;
+    h->lds_bytes = sizeof(double) * (2 * (size_t)(h->split_l2 ? 2 : (h->Bpow2 < 2 ? 2 : h->Bpow2)) + (size_t)kStageTiles * kTile);
+    h->lds_bytes_big = sizeof(double) * (4 + (size_t)kStageTiles * kTile);
+    h->lds_bytes_plan = sizeof(double) * (size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2);
     h->graph_mode = 1;
     h->small_series = 1;
     h->nt = 512;
@@ -335,6 +361,17 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
         HIPCHK(set_lds<MODEL_SVOL>(h->lds_bytes));
         HIPCHK(set_lds<MODEL_SVOL_LEVERAGE>(h->lds_bytes));
         HIPCHK(set_lds<MODEL_LIN_GAUSS>(h->lds_bytes));
+        HIPCHK(set_lds_big<MODEL_SVOL>(h->lds_bytes_big));
+        HIPCHK(set_lds_big<MODEL_SVOL_LEVERAGE>(h->lds_bytes_big));
+        HIPCHK(set_lds_big<MODEL_LIN_GAUSS>(h->lds_bytes_big));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level2_plan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lds_bytes_plan));
+        HIPCHK(hipMalloc(&h->l2_T, sizeof(double) * (size_t)h->R * h->Bs));
+        HIPCHK(hipMalloc(&h->l2_R, sizeof(double) * (size_t)h->R * h->Bs));
+        HIPCHK(hipMalloc(&h->l2_lo, sizeof(int32_t) * (size_t)h->R * h->Bs));
+        HIPCHK(hipMalloc(&h->l2_hi, sizeof(int32_t) * (size_t)h->R * h->Bs));
+        HIPCHK(hipMemset(h->l2_lo, 0, sizeof(int32_t) * (size_t)h->R * h->Bs));
+        HIPCHK(hipMemset(h->l2_hi, 0, sizeof(int32_t) * (size_t)h->R * h->Bs));
         HIPCHK(hipMalloc(&h->scal, sizeof(FilterScalars) * h->R));
         HIPCHK(hipMalloc(&h->mc, sizeof(ModelConst) * h->R));
         HIPCHK(hipMalloc(&h->scratchR, sizeof(double) * h->R));
@@ -358,7 +395,7 @@ int ssme_pf_destroy(ssme_pf_handle h) {
     h->stream = h->own_stream;
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     void* bufs[] = {h->x[0], h->x[1], h->cdf[0], h->cdf[1], h->tsum[0], h->tsum[1], h->tmax[0], h->tmax[1], h->logw,
-                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev};
+                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_lo, h->l2_hi};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -508,6 +545,11 @@ int ssme_pf_set_debug(ssme_pf_handle h, int32_t flags) {
     }
     h->debug_anc = (flags & 1) ? 1 : 0;
     h->keep_logw = (flags & 2) ? 1 : 0;
+    {
+        const int want = ((flags & 4) || h->B > kMaxTilesPerFilter) ? 1 : 0;      // bit 2: force the split level-2 (tests)
+        if (want != h->split_l2 && h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+        h->split_l2 = want;
+    }
     return ensure_logw(h);
 }
 

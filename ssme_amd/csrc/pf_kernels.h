@@ -30,7 +30,8 @@ constexpr int kThreads = 256;            // helper kernels; KA/KR are templated 
 constexpr int kWave = 64;
 constexpr int kRow = 512;
 constexpr int kTile = 2048;
-constexpr int kMaxTilesPerFilter = 2048;   // level-2 scan reuses the 2048-wide block scan
+constexpr int kMaxTilesPerFilter = 2048;   // in-kernel level-2 (one entry per thread at NT = 512 .. four at 512 threads)
+constexpr int kMaxTilesSplit = 16384;      // split level-2 (k_level2_plan + k_filter_step<.., true>): N <= 2^25
 constexpr int kStageTiles = 3;             // cdf tiles staged in LDS per output tile
 constexpr int kEShift = 35;                // exponential spacings: qE = rne(E * 2^35)
 constexpr int kTileShift = 41;             // tile-local fixed point: q = rne(exp(logw - m_tile) * 2^41), tile sums <= 2^52
@@ -92,6 +93,11 @@ struct StepArgs {
     int32_t tile0;             // particle-sharded filter: global id of this launch's first OUTPUT tile (0 otherwise); outputs
                                // are stored at local offsets (tile - tile0)
     int32_t win_tile0;         // global id of the first SOURCE tile held in x_in / cdf_in (0 otherwise)
+    // split level-2 (filters of more than 2048 tiles, or forced for tests): written by k_level2_plan, read by k_filter_step<..,true>
+    double* l2_T;              // [R][Bs] inclusive prefixes T'_b of the rescaled tile sums
+    double* l2_R;              // [R][Bs] A_b / A'_b
+    int32_t* l2_lo;            // [R][Bs] first / last source tile of every output tile's targets
+    int32_t* l2_hi;
     int32_t prio_mode;         // wave-priority schedule of k_filter_step (prio_at): 0 none, 1 single residency wave, 2 several
     const uint32_t* keyp;      // [2] Philox key (the seed), device resident so that a captured graph survives ssme_pf_set_seed
     uint32_t first_filter;
@@ -481,11 +487,11 @@ __device__ __forceinline__ void prio_at(int mode, int idx) {
 // then the Box-Muller radii are computed while they arrive; the ancestor states are requested,
 // then the Box-Muller angles are computed while they arrive.
 // ---------------------------------------------------------------------------------------
-template <int MODEL, int NT>
+template <int MODEL, int NT, bool BIG = false>
 __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     constexpr int NK = 1024 / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nT2 = a.Bpow2 < 2 ? 2 : a.Bpow2;
+    const int nT2 = (BIG || a.Bpow2 < 2) ? 2 : a.Bpow2;      // BIG: level-2 comes from k_level2_plan, no tables in LDS
     double* lds_T = reinterpret_cast<double*>(smem);             // [Bpow2] inclusive prefixes of A'
     double* lds_R = lds_T + nT2;                                 // [Bpow2] A_b / A'_b
     double* lds_stage = lds_T + 2 * nT2;                         // [3][2048] staged cdf tiles, 16-byte aligned
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     const double y = a.y[a.yi];
     const double zcov = a.z ? a.z[a.yi] : 0.0;
     const bool resampled = (a.t > 0) && (a.t % a.resamp_sched == 0);
-    const bool need_l2 = (a.t > 0) && (resampled || (bloc == 0 && a.finalize_prev));
+    const bool need_l2 = (a.t > 0) && (resampled || (!BIG && bloc == 0 && a.finalize_prev));
     const bool sorted = a.resampler != RESAMP_MULTINOMIAL_IID;
     const int i_first = b * kTile;
     const int nvalid = (a.N - i_first) < kTile ? (a.N - i_first) : kTile;    // valid outputs in this tile (>= 1)
@@ -519,7 +525,9 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     // --- issue the level-2 loads first: previous step's tile sums and maxima ---
     constexpr int NE = 2048 / NT;
     double A2[NE], M2[NE];
-    if (need_l2) level2_load<NT>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
+    if (need_l2 && !BIG) level2_load<NT>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
+    const double* l2T = a.l2_T + (size_t)r * a.Bs;
+    const double* l2R = a.l2_R + (size_t)r * a.Bs;
     if (tid == 0) { lds_cnt[0] = 0; lds_cnt[1] = 0; }
     double gam = 0.0, pgam = 0.0, pgam_next = 0.0, G = 1.0;
     const bool multinomial = resampled && a.resampler == RESAMP_MULTINOMIAL;
@@ -534,7 +542,17 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     // --- level-2: global max, rescaled tile sums A', inclusive prefixes T', total S'; tile range of my targets ---
     double S = 0.0;
     double t_scale = 0.0, u0 = 0.0;
-    if (need_l2) {
+    if (need_l2 && BIG) {
+        // split level-2: S', T', A/A' and this tile's source range were computed once per filter by k_level2_plan
+        S = a.scal[r].S;
+        double t_lo, t_hi;
+        if (a.resampler == RESAMP_SYSTEMATIC) {
+            const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, key0, key1);
+            u0 = u01_co(ox.v0, ox.v1);
+        }
+        tile_target_bounds(a.resampler, S, a.N, i_first, nvalid, pgam, pgam_next, G, u0, t_scale, t_lo, t_hi);
+    }
+    if (need_l2 && !BIG) {
         double Ap[NE], Tinc[NE];
         double m;
 #ifdef SSME_ABLATE
@@ -594,7 +612,9 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     if (resampled) {
         __syncthreads();          // lds_T, lds_R, lds_cnt visible
         if (sorted) {
-            int lo = lds_cnt[0], hi = lds_cnt[1];
+            int lo, hi;
+            if (BIG) { lo = a.l2_lo[(size_t)r * a.Bs + b]; hi = a.l2_hi[(size_t)r * a.Bs + b]; }
+            else { lo = lds_cnt[0]; hi = lds_cnt[1]; }
             lo = lo < a.B - 1 ? lo : a.B - 1;
             hi = hi < a.B - 1 ? hi : a.B - 1;
             bb_min = __builtin_amdgcn_readfirstlane(lo);
@@ -697,10 +717,10 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                 }
             }
             const int b1 = bb_min + 1 < a.B ? bb_min + 1 : a.B - 1, b2 = bb_min + 2 < a.B ? bb_min + 2 : a.B - 1;
-            const double T0 = lds_T[bb_min];
-            const double T1 = (bb_min + 1 < a.B) ? lds_T[bb_min + 1] : dinf();
-            const double Pm = bb_min ? lds_T[bb_min - 1] : 0.0;
-            const double R0 = lds_R[bb_min], R1 = lds_R[b1], R2 = lds_R[b2];
+            const double T0 = BIG ? l2T[bb_min] : lds_T[bb_min];
+            const double T1 = (bb_min + 1 < a.B) ? (BIG ? l2T[bb_min + 1] : lds_T[bb_min + 1]) : dinf();
+            const double Pm = bb_min ? (BIG ? l2T[bb_min - 1] : lds_T[bb_min - 1]) : 0.0;
+            const double R0 = BIG ? l2R[bb_min] : lds_R[bb_min], R1 = BIG ? l2R[b1] : lds_R[b1], R2 = BIG ? l2R[b2] : lds_R[b2];
             __syncthreads();
             STAMP(a, 5);
             PRIO_AT(5);
@@ -757,10 +777,10 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const double target = tau[k][c];
-                    int bb = count_less_pow2(a.Bpow2, target, [&](int j) { return lds_T[j]; });
+                    int bb = count_less_pow2(a.Bpow2, target, [&](int j) { return BIG ? (j < a.B ? l2T[j] : dinf()) : lds_T[j]; });
                     bb = bb < a.B - 1 ? bb : a.B - 1;
-                    const double Pb = bb ? lds_T[bb - 1] : 0.0;
-                    const double tloc = __builtin_ceil((target - Pb) * lds_R[bb]);
+                    const double Pb = bb ? (BIG ? l2T[bb - 1] : lds_T[bb - 1]) : 0.0;
+                    const double tloc = __builtin_ceil((target - Pb) * (BIG ? l2R[bb] : lds_R[bb]));
                     const double* tile = cdf_r + (size_t)(bb - a.win_tile0) * kTile;
                     const int j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
                     int anc = bb * kTile + j;
@@ -874,6 +894,95 @@ __global__ __launch_bounds__(kThreads) void kf_finalize(const StepArgs a) {
         sc->loglik = sc->loglik + ll;
         sc->prev = resample_now ? a.logN : lse;
         if (a.per_step) a.per_step[(size_t)r * a.Tcap + a.t] = ll;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Split level-2 for filters of more than 2048 tiles (N > 2^22; also selectable for tests): ONE workgroup per filter
+// does what every workgroup of k_filter_step otherwise repeats -- global max, rescaled integer tile sums A', their exact
+// inclusive scan T', the total S', A/A' -- and additionally the source-tile range [lo, hi] of every output tile
+// (same tile_target_bounds, same counts), and accounts log p(y_{t-1} | .).  Same arithmetic as level2_scan: integer
+// sums are exact and associative, so the results are those of the in-kernel level-2 to the bit.
+// grid = (R), block = 1024, dynamic LDS = Bpow2 doubles.  a.t = the step about to run (its targets); plan_ranges = 0
+// for the call that only accounts the last step's log-likelihood (the kf_finalize role).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_level2_plan(const StepArgs a, int plan_ranges) {
+    constexpr int NT = 1024, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_l2[];
+    double* lds_T = reinterpret_cast<double*>(smem_l2);          // [Bpow2]
+    __shared__ double lds_d[16];
+    __shared__ double lds_seg[16];
+    const int tid = threadIdx.x, r = blockIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double* ts = a.tsum_in + (size_t)r * a.Bs;
+    const double* tm = a.tmax_in + (size_t)r * a.Bs;
+    double* Tp = a.l2_T + (size_t)r * a.Bs;
+    double* Rp = a.l2_R + (size_t)r * a.Bs;
+    const uint32_t rep = a.first_filter + (uint32_t)r;
+    const bool resampled = (a.t % a.resamp_sched == 0);
+    // global max of the tile maxima, NaN propagating
+    double mx = -dinf();
+    bool nan = false;
+    for (int j = tid; j < a.B; j += NT) { const double v = tm[j]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
+    const double m = block_max_nanprop<NT>(mx, nan, lds_d);
+    // rescaled tile sums and their exact inclusive scan, 1024 tiles per round
+    double carry = 0.0;
+    for (int j0 = 0; j0 < a.Bpow2; j0 += NT) {
+        const int j = j0 + tid;
+        double A = 0.0, Ap = 0.0;
+        if (j < a.B) { A = ts[j]; Ap = __builtin_rint(A * dexp_scaled(tm[j] - m, a.rshift - kTileShift)); }
+        const double inc = wave_incl_scan_f64(Ap);
+        __syncthreads();                                         // lds_seg of the previous round has been read
+        if (lane == 63) lds_seg[wave] = inc;
+        __syncthreads();
+        double sv = (lane & 15) < NW ? lds_seg[lane & 15] : 0.0;
+        sv = sv + dpp_f64_zero<0x111, 0xF>(sv);
+        sv = sv + dpp_f64_zero<0x112, 0xF>(sv);
+        sv = sv + dpp_f64_zero<0x114, 0xF>(sv);
+        sv = sv + dpp_f64_zero<0x118, 0xF>(sv);
+        const double pre = wave ? readlane_f64(sv, wave - 1) : 0.0;
+        const double T = (carry + pre) + inc;
+        carry = carry + readlane_f64(sv, 15);
+        if (j < a.Bpow2) lds_T[j] = (j < a.B) ? T : dinf();
+        if (j < a.B) { Tp[j] = T; Rp[j] = A / Ap; }
+    }
+    const double S = carry;
+    __syncthreads();
+    if (plan_ranges && resampled && a.resampler != RESAMP_MULTINOMIAL_IID) {
+        const uint32_t key0 = a.keyp[0], key1 = a.keyp[1];
+        double G = 1.0, u0 = 0.0;
+        const size_t g0 = ((size_t)a.gi * a.R + r) * a.B;
+        if (a.resampler == RESAMP_MULTINOMIAL) G = a.gtot[(size_t)a.gi * a.R + r];
+        else if (a.resampler == RESAMP_SYSTEMATIC) {
+            const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, key0, key1);
+            u0 = u01_co(ox.v0, ox.v1);
+        }
+        for (int b = tid; b < a.B; b += NT) {
+            double pg = 0.0, pgn = 0.0;
+            if (a.resampler == RESAMP_MULTINOMIAL) { pg = a.pgam[g0 + b]; pgn = (b + 1 < a.B) ? a.pgam[g0 + b + 1] : G; }
+            const int i_first = b * kTile;
+            const int nvalid = (a.N - i_first) < kTile ? (a.N - i_first) : kTile;
+            double ts_, t_lo, t_hi;
+            tile_target_bounds(a.resampler, S, a.N, i_first, nvalid, pg, pgn, G, u0, ts_, t_lo, t_hi);
+            int lo = count_less_pow2(a.Bpow2, t_lo, [&](int j) { return lds_T[j]; });
+            int hi = count_less_pow2(a.Bpow2, t_hi, [&](int j) { return lds_T[j]; });
+            a.l2_lo[(size_t)r * a.Bs + b] = lo < a.B - 1 ? lo : a.B - 1;
+            a.l2_hi[(size_t)r * a.Bs + b] = hi < a.B - 1 ? hi : a.B - 1;
+        }
+    }
+    if (tid == 0) {
+        FilterScalars* sc = a.scal + r;
+        sc->m = m;
+        sc->S = S;
+        if (a.finalize_prev) {
+            const double Sdd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
+            const double lse = m + dlog(Sdd);
+            const double ll = lse - sc->prev;
+            sc->last_ll = ll;
+            sc->loglik = sc->loglik + ll;
+            sc->prev = resampled ? a.logN : lse;
+            if (a.per_step) a.per_step[(size_t)r * a.Tcap + (a.t - 1)] = ll;
+        }
     }
 }
 

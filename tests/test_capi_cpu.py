@@ -41,7 +41,7 @@ def test_strerror_and_null_handling():
 
 @pytest.mark.parametrize("field,value,status", [
     ("n_particles", 0, 1), ("n_filters", 0, 1), ("model", 9, 1), ("resampler", 7, 1), ("resamp_sched", 0, 1),
-    ("dtype", 1, 3), ("n_particles", (1 << 22) + 2048 + 1, 3),
+    ("dtype", 1, 3), ("n_particles", (1 << 25) + 1, 3),
 ])
 def test_create_validates_config(field, value, status):
     from ssme_amd import _capi

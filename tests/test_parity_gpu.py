@@ -649,3 +649,49 @@ def test_liu_west_device_reproduces_golden(sa, n, delta):
     np.testing.assert_array_equal(st["kidx"], g[k + "_kidx"])
     np.testing.assert_array_equal(st["anc"], g[k + "_anc"])
     f.close()
+
+
+# ---- split level-2 (filters of more than 2048 tiles; forced here at moderate sizes) --------------------------------------
+@pytest.mark.parametrize("model,th,rs,n", [(0, [1.0, 0.95, 0.25], 0, 40000), (0, [1.0, 0.95, 0.25], 1, 40000),
+                                           (0, [1.0, 0.95, 0.25], 2, 9000), (0, [1.0, 0.95, 0.25], 3, 9000),
+                                           (1, [0.9, 0.0, 1.0, -0.1], 0, 30000), (2, [0.9, 0.5, 0.7], 0, 5000)])
+def test_split_level2_matches_in_kernel_level2_and_oracle(sa, oracle, spy, model, th, rs, n):
+    y = spy[:16]
+    z = np.concatenate([[0.0], y[:-1]]) if model == 1 else None
+    outs = []
+    for split in (False, True):
+        b = sa.ParticleFilterBank(model, n, 2, 31, rs)
+        b.set_debug(True, True, split_level2=split)
+        b.set_params(th)
+        ll = b.run_series(y, z)
+        st = b.state(1, ancestors=True)
+        # the step API continues with the same policy
+        nxt = b.step(y[3], None if z is None else z[3])
+        outs.append((ll, b.per_step(), st, nxt))
+        b.close()
+    (l0, p0, s0, n0), (l1, p1, s1, n1) = outs
+    assert_bits_equal(l0, l1, "split level-2: series log-lik")
+    assert_bits_equal(p0, p1, "split level-2: per-step")
+    assert_bits_equal(n0, n1, "split level-2: step API")
+    assert_bits_equal(s0["x"], s1["x"], "x")
+    np.testing.assert_array_equal(s0["cdf"], s1["cdf"])
+    np.testing.assert_array_equal(s0["anc"], s1["anc"])
+    assert s0["S"] == s1["S"]
+    o = oracle.Filter(model, n, th, 31, rep=1, resampler=rs)
+    lo, po = o.run_series(y, z)
+    assert_bits_equal([l1[1]], [lo], "split level-2 vs oracle")
+    assert_bits_equal(p1[1], po, "split level-2 per-step vs oracle")
+
+
+def test_filter_of_more_than_2048_tiles(sa, oracle, spy):
+    """N > 2^22 (2054 tiles): the split level-2 path against the oracle, bit for bit."""
+    n = (1 << 22) + 5 * 2048 + 77
+    y = spy[:4]
+    b = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, 77)
+    b.set_params([1.0, 0.95, 0.25])
+    ll = b.run_series(y)
+    o = oracle.Filter(oracle.MODEL_SVOL, n, [1.0, 0.95, 0.25], 77)
+    lo, po = o.run_series(y)
+    assert_bits_equal(ll, [lo], "N > 2^22 log-lik")
+    assert_bits_equal(b.per_step()[0], po, "N > 2^22 per-step")
+    b.close()
