@@ -130,7 +130,8 @@ int ssme_pf_download_scalars(ssme_pf_handle h, int32_t filter, double* max_logw,
                              uint64_t* tile_sums, double* tile_max, int32_t* rshift);
 /* flags: bit 0 = record ancestor indices, bit 1 = keep log-weights in memory (parity tests), bit 2 = compute level-2 (global
  * max, rescaled tile sums, their scan, every tile's source range) once per filter in its own launch instead of in every
- * workgroup -- always on for filters of more than 2048 tiles (N > 2^22; limit N <= 2^25), same results to the bit. */
+ * workgroup; bit 3 = the opposite (in-kernel level-2, possible up to 2048 tiles).  Default: split above 512 tiles
+ * (N > 2^20), where it is faster; always split above 2048 tiles (N > 2^22; limit N <= 2^25).  Same results to the bit. */
 int ssme_pf_set_debug(ssme_pf_handle h, int32_t flags);
 
 /* Threads per 2048-particle tile of the step kernel: 256, 512 (default) or 1024.  Results do

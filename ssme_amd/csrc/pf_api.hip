@@ -328,8 +328,9 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * kTile;
     h->Bs = (B + 1) & ~1; h->Bpow2 = next_pow2(B);
     h->rshift = 52 - ceil_log2(h->Npad);
-    h->split_l2 = B > kMaxTilesPerFilter ? 1 : 0;
-    h->lds_bytes = sizeof(double) * (2 * (size_t)(h->split_l2 ? 2 : (h->Bpow2 < 2 ? 2 : h->Bpow2)) + (size_t)kStageTiles * kTile);
+    h->split_l2 = B > kSplitLevel2Above ? 1 : 0;
+    // in-kernel level-2 keeps T' and A/A' of all tiles in LDS (possible up to 2048 tiles, whichever policy is the default)
+    h->lds_bytes = sizeof(double) * (2 * (size_t)(B > kMaxTilesPerFilter ? 2 : (h->Bpow2 < 2 ? 2 : h->Bpow2)) + (size_t)kStageTiles * kTile);
     h->lds_bytes_big = sizeof(double) * (4 + (size_t)kStageTiles * kTile);
     h->lds_bytes_plan = sizeof(double) * (size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2);
     h->graph_mode = 1;
@@ -546,7 +547,8 @@ int ssme_pf_set_debug(ssme_pf_handle h, int32_t flags) {
     h->debug_anc = (flags & 1) ? 1 : 0;
     h->keep_logw = (flags & 2) ? 1 : 0;
     {
-        const int want = ((flags & 4) || h->B > kMaxTilesPerFilter) ? 1 : 0;      // bit 2: force the split level-2 (tests)
+        // bit 2 forces the split level-2, bit 3 the in-kernel one (where it exists: <= 2048 tiles); default by size
+        const int want = (h->B > kMaxTilesPerFilter || (flags & 4)) ? 1 : ((flags & 8) ? 0 : (h->B > kSplitLevel2Above ? 1 : 0));
         if (want != h->split_l2 && h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
         h->split_l2 = want;
     }

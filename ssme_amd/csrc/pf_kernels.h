@@ -31,6 +31,7 @@ constexpr int kWave = 64;
 constexpr int kRow = 512;
 constexpr int kTile = 2048;
 constexpr int kMaxTilesPerFilter = 2048;   // in-kernel level-2 (one entry per thread at NT = 512 .. four at 512 threads)
+constexpr int kSplitLevel2Above = 512;     // measured: with more than one tile sum per thread the split level-2 wins (N = 3 2^20: 81 -> 49 us)
 constexpr int kMaxTilesSplit = 16384;      // split level-2 (k_level2_plan + k_filter_step<.., true>): N <= 2^25
 constexpr int kStageTiles = 3;             // cdf tiles staged in LDS per output tile
 constexpr int kEShift = 35;                // exponential spacings: qE = rne(E * 2^35)

@@ -66,11 +66,11 @@ class ParticleFilterBank:
         """New random stream for the next evaluation (a fresh likelihood estimate per PMMH proposal); resets the filters."""
         self._chk(capi.lib().ssme_pf_set_seed(self._h, int(seed)))
 
-    def set_debug(self, record_ancestors=True, keep_logw=True, split_level2=False):
+    def set_debug(self, record_ancestors=True, keep_logw=True, split_level2=None):
         """Parity/debug: record ancestor indices and/or keep the log-weights in device memory; split_level2 forces the
-        one-launch-per-filter level-2 that filters of more than 2048 tiles always use."""
-        self._chk(capi.lib().ssme_pf_set_debug(self._h, (1 if record_ancestors else 0) | (2 if keep_logw else 0)
-                                               | (4 if split_level2 else 0)))
+        one-launch-per-filter level-2 (True) or the in-kernel one (False, up to 2048 tiles); None chooses by size."""
+        pol = 0 if split_level2 is None else (4 if split_level2 else 8)      # None: by size (split above 512 tiles)
+        self._chk(capi.lib().ssme_pf_set_debug(self._h, (1 if record_ancestors else 0) | (2 if keep_logw else 0) | pol))
 
     def set_graph_mode(self, on=True):
         self._chk(capi.lib().ssme_pf_set_graph_mode(self._h, int(on)))

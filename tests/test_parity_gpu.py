@@ -695,3 +695,18 @@ def test_filter_of_more_than_2048_tiles(sa, oracle, spy):
     assert_bits_equal(ll, [lo], "N > 2^22 log-lik")
     assert_bits_equal(b.per_step()[0], po, "N > 2^22 per-step")
     b.close()
+
+
+def test_level2_policy_by_size_is_result_invariant(sa, spy):
+    """1200 tiles: split level-2 (the default above 512 tiles) == in-kernel level-2 (four tile sums per thread)."""
+    n, y = 1200 * 2048 - 5, spy[:5]
+    res = []
+    for pol in (None, False, True):
+        b = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, 3)
+        b.set_debug(False, False, split_level2=pol)
+        b.set_params([1.0, 0.95, 0.25])
+        res.append((b.run_series(y), b.per_step()))
+        b.close()
+    for ll, per in res[1:]:
+        assert_bits_equal(ll, res[0][0], "level-2 policy: log-lik")
+        assert_bits_equal(per, res[0][1], "level-2 policy: per-step")

@@ -20,6 +20,7 @@ ap.add_argument("--model", type=int, default=0)
 ap.add_argument("--eager", action="store_true")
 ap.add_argument("--nt", type=int, default=0)
 ap.add_argument("--sweep", action="store_true")
+ap.add_argument("--split", type=int, default=-1, help="1: force the split level-2 (k_level2_plan), 0: force the in-kernel one")
 ap.add_argument("--lw", action="store_true", help="Liu-West filter instead of the bootstrap filter")
 a = ap.parse_args()
 y = np.loadtxt(os.path.join(ROOT, "tests", "golden", "spy_returns.csv"))[:a.T]
@@ -38,6 +39,8 @@ if a.lw:
 bank = ssme_amd.ParticleFilterBank(a.model, a.n, a.filters, 20260101, a.resampler)
 if a.eager:
     bank.set_graph_mode(False)
+if a.split >= 0:
+    bank.set_debug(False, False, split_level2=bool(a.split))
 bank.set_params(th)
 combos = [256, 512, 1024] if a.sweep else [a.nt or 512]
 for nt in combos:
