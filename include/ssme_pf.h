@@ -174,7 +174,7 @@ int ssme_pf_test_gamma(int32_t device, uint64_t seed, uint32_t rep, int32_t t, d
 /* ============================================================================================
  * Particle-sharded filter: ONE filter of cfg->n_particles particles over `world` GPUs,
  * one process per GPU.  Rank g owns tiles [g B/world, (g+1) B/world) (a tile = 2048 particles; n_particles must be a
- * multiple of 2048 world; n_filters = 1, resamp_sched = 1).  Per time step the host side (ssme_amd/sharded.py over
+ * multiple of 2048 world, at most 2^25; n_filters = 1, resamp_sched = 1).  Per time step the host side (ssme_amd/sharded.py over
  * torch.distributed) does:   all_gather of the tile sums / maxima  ->  ssme_pf_shard_plan (which source tiles each
  * rank's resampling touches)  ->  exchange of those tiles (cdf + particles)  ->  ssme_pf_shard_step.
  * The level-2 arithmetic, the RNG counters (global particle index) and the Gamma tables (global tile id) are those of

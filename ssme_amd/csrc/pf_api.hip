@@ -320,7 +320,7 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     if (cfg->resamp_sched < 1) return SSME_ERR_INVALID_ARG;
     if (cfg->dtype != SSME_F64) return SSME_ERR_UNSUPPORTED;
     const int B = (cfg->n_particles + kTile - 1) / kTile;
-    if (B > kMaxTilesSplit || (shard_world > 0 && B > kMaxTilesPerFilter)) return SSME_ERR_UNSUPPORTED;   // N <= 2^25 per filter per GPU
+    if (B > kMaxTilesSplit) return SSME_ERR_UNSUPPORTED;   // N <= 2^25 per filter
     ssme_pf_handle h = new (std::nothrow) ssme_pf_s();
     if (!h) return SSME_ERR_INVALID_ARG;
     h->cfg = *cfg;
@@ -459,6 +459,24 @@ int ssme_pf_shard_plan(ssme_pf_handle h, const double* tsum_all, const double* t
     if (h->shard_world < 1) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
     StepArgs a = shard_args(h, t, tsum_all, tmax_all);
+    if (h->split_l2) {
+        // more than 512 tiles in total: the split level-2 plans every tile (and accounts log p(y_{t-1} | .)); a rank's
+        // window is [lo of its first tile, hi of its last tile]
+        a.finalize_prev = 1;
+        hipLaunchKernelGGL(k_level2_plan, dim3(1), dim3(1024), h->lds_bytes_plan, h->stream, a, 1);
+        HIPCHK(hipGetLastError());
+        const int Bl = h->B / h->shard_world;
+        const bool sorted = h->cfg.resampler != SSME_RESAMP_MULTINOMIAL_IID;
+        for (int d = 0; d < h->shard_world; ++d) {
+            lo_hi[2 * d] = 0; lo_hi[2 * d + 1] = h->B - 1;
+            if (sorted) {
+                HIPCHK(hipMemcpyAsync(lo_hi + 2 * d, h->l2_lo + (size_t)d * Bl, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipMemcpyAsync(lo_hi + 2 * d + 1, h->l2_hi + (size_t)(d + 1) * Bl - 1, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            }
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return SSME_OK;
+    }
     hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(512), sizeof(double) * (h->Bpow2 < 2 ? 2 : h->Bpow2), h->stream, a,
                        h->shard_world, h->plan_dev);
     HIPCHK(hipGetLastError());
@@ -483,7 +501,13 @@ int ssme_pf_shard_step(ssme_pf_handle h, int32_t t, const double* x_win, const d
     const int Bl = h->B / h->shard_world;
     a.tile0 = h->shard_rank * Bl;
     const dim3 grid(Bl, 1);
-    switch (h->cfg.model) {
+    if (h->split_l2) {
+        switch (h->cfg.model) {
+            case SSME_MODEL_SVOL: hipLaunchKernelGGL((k_filter_step<MODEL_SVOL, 512, true>), grid, dim3(512), h->lds_bytes_big, h->stream, a); break;
+            case SSME_MODEL_SVOL_LEVERAGE: hipLaunchKernelGGL((k_filter_step<MODEL_SVOL_LEVERAGE, 512, true>), grid, dim3(512), h->lds_bytes_big, h->stream, a); break;
+            default: hipLaunchKernelGGL((k_filter_step<MODEL_LIN_GAUSS, 512, true>), grid, dim3(512), h->lds_bytes_big, h->stream, a); break;
+        }
+    } else switch (h->cfg.model) {
         case SSME_MODEL_SVOL: hipLaunchKernelGGL((k_filter_step<MODEL_SVOL, 512>), grid, dim3(512), h->lds_bytes, h->stream, a); break;
         case SSME_MODEL_SVOL_LEVERAGE: hipLaunchKernelGGL((k_filter_step<MODEL_SVOL_LEVERAGE, 512>), grid, dim3(512), h->lds_bytes, h->stream, a); break;
         default: hipLaunchKernelGGL((k_filter_step<MODEL_LIN_GAUSS, 512>), grid, dim3(512), h->lds_bytes, h->stream, a); break;
@@ -498,7 +522,11 @@ int ssme_pf_shard_finalize(ssme_pf_handle h, int32_t t, const double* tsum_all, 
     if (h->shard_world < 1) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
     StepArgs a = shard_args(h, t, tsum_all, tmax_all);
-    hipLaunchKernelGGL(kf_finalize, dim3(1), dim3(kThreads), 0, h->stream, a);
+    if (h->split_l2) {
+        a.t = t + 1; a.finalize_prev = 1;
+        hipLaunchKernelGGL(k_level2_plan, dim3(1), dim3(1024), h->lds_bytes_plan, h->stream, a, 0);
+    } else
+        hipLaunchKernelGGL(kf_finalize, dim3(1), dim3(kThreads), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     return SSME_OK;

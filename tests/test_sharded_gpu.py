@@ -35,11 +35,15 @@ def _run_sharded(tmp_path, world, model, n, T, rs, seed):
     return [np.load(o) for o in outs]
 
 
-@pytest.mark.parametrize("world,model,n,rs", [(2, 0, 16384, 0), (4, 0, 32768, 0), (2, 0, 16384, 1), (2, 1, 8192, 0),
-                                              (2, 0, 16384, 2), (2, 2, 8192, 3), (4, 0, 8192, 0)])
-def test_sharded_filter_is_bit_identical_to_unsharded(tmp_path, spy, world, model, n, rs):
+@pytest.mark.parametrize("world,model,n,rs,T", [(2, 0, 16384, 0, 24), (4, 0, 32768, 0, 24), (2, 0, 16384, 1, 24), (2, 1, 8192, 0, 24),
+                                                (2, 0, 16384, 2, 24), (2, 2, 8192, 3, 24), (4, 0, 8192, 0, 24),
+                                                # more than 512 tiles in total: the split level-2 plans the exchange
+                                                (2, 0, 2 * 640 * 2048, 0, 6), (4, 0, 4 * 300 * 2048, 1, 6),
+                                                # more than 2048 tiles (N > 2^22)
+                                                (2, 0, 2 * 1100 * 2048, 0, 4)])
+def test_sharded_filter_is_bit_identical_to_unsharded(tmp_path, spy, world, model, n, rs, T):
     import ssme_amd
-    T, seed = 24, 4242
+    seed = 4242
     res = _run_sharded(tmp_path, world, model, n, T, rs, seed)
     y = spy[:T]
     z = np.concatenate([[0.0], y[:-1]]) if model == 1 else None
