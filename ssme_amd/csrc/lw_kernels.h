@@ -47,6 +47,11 @@ struct LwArgs {
     int32_t N, Npad, B, Bs, Bpow2, rshift, R;
     int32_t t, yi, gi, Tcap;
     int32_t finalize_prev;                      // stage 1 accounts log p(y_{t-1} | .) (series mode); 0 in step mode
+    // particle-sharded filter (all zero / Npad otherwise): this launch computes tiles tile0 .. tile0 + gridDim.x - 1 and
+    // stores them at local offsets; the arrays a stage READS (stage 1: xB, thB, cdfB; stage 2: xr, thr, lw1, cdfA) are
+    // windows starting at tile win_tile0 with parameter planes th_src_stride apart; written planes are th_dst_stride apart
+    int32_t tile0, win_tile0;
+    int64_t th_src_stride, th_dst_stride;
     uint32_t key0, key1, first_filter;
     double logN, a_shrink;
     int32_t trans[kDP];
@@ -97,7 +102,7 @@ struct LwLds {
 __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax, const double* cdf, int B, int Bpow2, int rshift,
                                           int N, int b, double gam, double pgam, double pgam_next, double G, int spacing_stream,
                                           uint32_t t, uint32_t rep, uint32_t k0, uint32_t k1, const LwLds& L, int (&idx)[2][2],
-                                          double& m_out, double& S_out) {
+                                          double& m_out, double& S_out, int win_tile0 = 0) {
     constexpr int NT = kLwNT, NK = 2, NE = 4;
     const int tid = threadIdx.x;
     const int i_first = b * kTile;
@@ -134,7 +139,7 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
 #pragma unroll
     for (int k = 0; k < NK; ++k) { stg0[k] = make_double2(0.0, 0.0); stg1[k] = stg0[k]; stg2[k] = stg0[k]; }
     if (span <= kStageTiles) {
-        const double* src = cdf + (size_t)bb_min * kTile + tid * 2;
+        const double* src = cdf + (size_t)(bb_min - win_tile0) * kTile + tid * 2;
 #pragma unroll
         for (int k = 0; k < NK; ++k) stg0[k] = *reinterpret_cast<const double2*>(src + k * NT * 2);
         if (span >= 2) {
@@ -231,7 +236,7 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
                 bb = bb < B - 1 ? bb : B - 1;
                 const double Pb = bb ? L.lds_T[bb - 1] : 0.0;
                 const double tloc = __builtin_ceil((target - Pb) * L.lds_R[bb]);
-                const double* tile = cdf + (size_t)bb * kTile;
+                const double* tile = cdf + (size_t)(bb - win_tile0) * kTile;
                 const int j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
                 int a = bb * kTile + j;
                 idx[k][c] = a < N - 1 ? a : N - 1;
@@ -243,7 +248,7 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
 
 // log-weights lg[k][c] of this tile -> tile max, fixed-point weights, exact tile scan; stores cdf / tile sum / tile max
 __device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int N, int i_first, double* cdf_row, double* tsum_row,
-                                             double* tmax_row, int b, double* lds_d, double* lds_seg) {
+                                             double* tmax_row, int b, double* lds_d, double* lds_seg, int tile0 = 0) {
     constexpr int NT = kLwNT, NK = 2;
     const int tid = threadIdx.x;
     __builtin_amdgcn_s_setprio(0);
@@ -268,8 +273,8 @@ __device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int N, in
     block_scan_f64<NT>(q, inc, total, lds_seg);
 #pragma unroll
     for (int k = 0; k < NK; ++k)
-        *reinterpret_cast<double2*>(cdf_row + i_first + (k * NT + tid) * 2) = make_double2(inc[k][0], inc[k][1]);
-    if (tid == 0) { tsum_row[b] = total; tmax_row[b] = mb; }
+        *reinterpret_cast<double2*>(cdf_row + (i_first - tile0 * kTile) + (k * NT + tid) * 2) = make_double2(inc[k][0], inc[k][1]);
+    if (tid == 0) { tsum_row[b - tile0] = total; tmax_row[b - tile0] = mb; }
 }
 
 #define LW_LDS_SETUP(a)                                                                                   \
@@ -294,7 +299,8 @@ __global__ __launch_bounds__(kLwNT) void k_lw_init(const LwArgs a) {
     __shared__ double lds_d2[16];
     const int tid = threadIdx.x;
     const int gtile = xcd_tile_of_block((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
-    const int r = gtile / (int)gridDim.x, b = gtile - r * (int)gridDim.x;      // XCD-contiguous (filter, tile) map
+    const int r = gtile / (int)gridDim.x, b = (gtile - r * (int)gridDim.x) + a.tile0;      // XCD-contiguous (filter, tile) map; global tile id
+    const int out0 = a.tile0 * kTile;
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const size_t rowoff = (size_t)r * a.Npad;
     const double y = a.y[a.yi];
@@ -319,12 +325,12 @@ __global__ __launch_bounds__(kLwNT) void k_lw_init(const LwArgs a) {
             lg[k][c] = lw_logg(y, xo[c]);
             if (i >= a.N) { xo[c] = 0.0; lg[k][c] = -dinf(); for (int d = 0; d < kDP; ++d) tho[d][c] = 0.0; }
         }
-        *reinterpret_cast<double2*>(a.xB + rowoff + i0) = make_double2(xo[0], xo[1]);
+        *reinterpret_cast<double2*>(a.xB + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
 #pragma unroll
         for (int d = 0; d < kDP; ++d)
-            *reinterpret_cast<double2*>(a.thB + ((size_t)r * kDP + d) * a.Npad + i0) = make_double2(tho[d][0], tho[d][1]);
+            *reinterpret_cast<double2*>(a.thB + ((size_t)r * kDP + d) * a.th_dst_stride + (i0 - out0)) = make_double2(tho[d][0], tho[d][1]);
     }
-    lw_store_cdf(lg, a.N, i_first, a.cdfB + rowoff, a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, b, lds_d2, lds_seg_c);
+    lw_store_cdf(lg, a.N, i_first, a.cdfB + rowoff, a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, a.tile0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -336,7 +342,9 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
     __shared__ double lds_mom[8][kNMom];
     const int tid = threadIdx.x;
     const int gtile = xcd_tile_of_block((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
-    const int r = gtile / (int)gridDim.x, b = gtile - r * (int)gridDim.x;      // XCD-contiguous (filter, tile) map
+    const int r = gtile / (int)gridDim.x, bloc = gtile - r * (int)gridDim.x;   // XCD-contiguous (filter, tile) map
+    const int b = bloc + a.tile0;                                              // global tile id
+    const int out0 = a.tile0 * kTile, win0 = a.win_tile0 * kTile;
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const size_t rowoff = (size_t)r * a.Npad;
     const double y = a.y[a.yi], z = a.z ? a.z[a.yi] : 0.0;
@@ -349,8 +357,8 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
     int anc[NK][2];
     double mB, SB;
     lw_select(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.cdfB + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
-              a.gamB[gidx], a.pgamB[gidx], pgam_next, G, STREAM_RESAMP, (uint32_t)a.t, rep, a.key0, a.key1, L, anc, mB, SB);
-    if (b == 0 && tid == 0 && a.finalize_prev) {
+              a.gamB[gidx], a.pgamB[gidx], pgam_next, G, STREAM_RESAMP, (uint32_t)a.t, rep, a.key0, a.key1, L, anc, mB, SB, a.win_tile0);
+    if (bloc == 0 && tid == 0 && a.finalize_prev) {
         // log p(y_{t-1} | y_{1:t-2}): :1047 with all old weights equal after resampling; :1136 at t-1 = 0
         LwScalars* sc = a.scal + r;
         const double Sd = (SB > 0.0) ? dldexp(SB, -a.rshift) : dnan();
@@ -369,10 +377,10 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int j = anc[k][c];
-            xo[c] = xB[j];
+            xo[c] = xB[j - win0];
 #pragma unroll
-            for (int d = 0; d < kDP; ++d) tt[d][c] = a.thB[((size_t)r * kDP + d) * a.Npad + j];
-            if (a.anc && i0 + c < a.N) a.anc[rowoff + i0 + c] = (uint32_t)j;
+            for (int d = 0; d < kDP; ++d) tt[d][c] = a.thB[((size_t)r * kDP + d) * a.th_src_stride + (j - win0)];
+            if (a.anc && i0 + c < a.N) a.anc[rowoff + (i0 - out0) + c] = (uint32_t)j;
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -392,11 +400,11 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
                 for (int e = 0; e <= d; ++e) { const double v = valid ? tt[d][c] * tt[e][c] : 0.0; fold[q][c] = (k == 0) ? v : fold[q][c] + v; ++q; }
             }
         }
-        *reinterpret_cast<double2*>(a.xr + rowoff + i0) = make_double2(xo[0], xo[1]);
-        *reinterpret_cast<double2*>(a.lw1 + rowoff + i0) = make_double2(lg[k][0], lg[k][1]);
+        *reinterpret_cast<double2*>(a.xr + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
+        *reinterpret_cast<double2*>(a.lw1 + rowoff + (i0 - out0)) = make_double2(lg[k][0], lg[k][1]);
 #pragma unroll
         for (int d = 0; d < kDP; ++d)
-            *reinterpret_cast<double2*>(a.thr + ((size_t)r * kDP + d) * a.Npad + i0) = make_double2(tt[d][0], tt[d][1]);
+            *reinterpret_cast<double2*>(a.thr + ((size_t)r * kDP + d) * a.th_dst_stride + (i0 - out0)) = make_double2(tt[d][0], tt[d][1]);
     }
     // wave tree per 128-element segment of the folded half tile, then the 8 segments in order
 #pragma unroll
@@ -404,13 +412,13 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
         const double s = wave_incl_scan_f64(fold[q][0] + fold[q][1]);
         if ((tid & 63) == 63) lds_mom[tid >> 6][q] = s;
     }
-    lw_store_cdf(lg, a.N, i_first, a.cdfA + rowoff, a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, b, lds_d2, lds_seg_c);
+    lw_store_cdf(lg, a.N, i_first, a.cdfA + rowoff, a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, a.tile0);
     // (lw_store_cdf contains barriers after the lds_mom writes)
     if (tid < kNMom) {
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < 8; ++w) s = s + lds_mom[w][tid];
-        a.mom[((size_t)r * a.B + b) * 16 + tid] = s;
+        a.mom[((size_t)r * gridDim.x + bloc) * 16 + tid] = s;       // gridDim.x = B unless the filter is sharded
     }
 }
 
@@ -492,7 +500,8 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
     LW_LDS_SETUP(a)
     const int tid = threadIdx.x;
     const int gtile = xcd_tile_of_block((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
-    const int r = gtile / (int)gridDim.x, b = gtile - r * (int)gridDim.x;      // XCD-contiguous (filter, tile) map
+    const int r = gtile / (int)gridDim.x, b = (gtile - r * (int)gridDim.x) + a.tile0;      // XCD-contiguous (filter, tile) map; global tile id
+    const int out0 = a.tile0 * kTile, win0 = a.win_tile0 * kTile;
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const size_t rowoff = (size_t)r * a.Npad;
     const double y = a.y[a.yi], z = a.z ? a.z[a.yi] : 0.0;
@@ -508,7 +517,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
     int kk[NK][2];
     double mA, SA;
     lw_select(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.cdfA + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
-              a.gamA[gidx], a.pgamA[gidx], pgam_next, G, STREAM_LW_K, (uint32_t)a.t, rep, a.key0, a.key1, L, kk, mA, SA);
+              a.gamA[gidx], a.pgamA[gidx], pgam_next, G, STREAM_LW_K, (uint32_t)a.t, rep, a.key0, a.key1, L, kk, mA, SA, a.win_tile0);
     double lg[NK][2];
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -520,8 +529,8 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
         for (int c = 0; c < 2; ++c) {
             const int i = i0 + c;
             const int j = kk[k][c];
-            const double xk = a.xr[rowoff + j];
-            const double lw1k = a.lw1[rowoff + j];
+            const double xk = a.xr[rowoff + (j - win0)];
+            const double lw1k = a.lw1[rowoff + (j - win0)];
             double e[kDP];
             {
                 const u32x4 o1 = philox4x32_10((uint32_t)i, (uint32_t)a.t, rep, STREAM_LW_JIT, a.key0, a.key1);
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
             int q = kDP;
 #pragma unroll
             for (int d = 0; d < kDP; ++d) {
-                const double thk = a.thr[((size_t)r * kDP + d) * a.Npad + j];
+                const double thk = a.thr[((size_t)r * kDP + d) * a.th_src_stride + (j - win0)];
                 const double mm = a.a_shrink * thk + (1.0 - a.a_shrink) * prop[d];      // :1024
                 double acc = 0.0;
 #pragma unroll
@@ -549,15 +558,15 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
             const double mean = (tu[1] + tu[0] * (xk - tu[1])) + ((z * tu[3]) * tu[2]) * dexp(-0.5 * xk);       // fSamp :114-121
             xo[c] = mean + zs[c] * (tu[2] * dsqrt(1.0 - tu[3] * tu[3]));
             lg[k][c] = lw_logg(y, xo[c]) - lw1k;                                         // :1032-1033
-            if (a.kidx && i < a.N) a.kidx[rowoff + i] = (uint32_t)j;
+            if (a.kidx && i < a.N) a.kidx[rowoff + (i - out0)] = (uint32_t)j;
             if (i >= a.N) { xo[c] = 0.0; lg[k][c] = -dinf(); }
         }
-        *reinterpret_cast<double2*>(a.xB + rowoff + i0) = make_double2(xo[0], xo[1]);
+        *reinterpret_cast<double2*>(a.xB + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
 #pragma unroll
         for (int d = 0; d < kDP; ++d)
-            *reinterpret_cast<double2*>(a.thB + ((size_t)r * kDP + d) * a.Npad + i0) = make_double2(tho[d][0], tho[d][1]);
+            *reinterpret_cast<double2*>(a.thB + ((size_t)r * kDP + d) * a.th_dst_stride + (i0 - out0)) = make_double2(tho[d][0], tho[d][1]);
     }
-    lw_store_cdf(lg, a.N, i_first, a.cdfB + rowoff, a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, b, lds_d2, lds_seg_c);
+    lw_store_cdf(lg, a.N, i_first, a.cdfB + rowoff, a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, a.tile0);
 }
 
 // ---------------------------------------------------------------------------------------

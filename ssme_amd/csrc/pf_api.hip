@@ -1037,6 +1037,7 @@ static LwArgs lw_args(ssme_lw_handle h) {
     a.key0 = (uint32_t)h->cfg.seed; a.key1 = (uint32_t)(h->cfg.seed >> 32); a.first_filter = h->cfg.first_filter_id;
     a.logN = dlog((double)h->N);
     a.a_shrink = (3.0 * h->cfg.delta - 1.0) / (2.0 * h->cfg.delta);          // liu_west_filter.h:960
+    a.tile0 = 0; a.win_tile0 = 0; a.th_src_stride = h->Npad; a.th_dst_stride = h->Npad;
     for (int d = 0; d < kDP; ++d) { a.trans[d] = h->cfg.transforms[d]; a.lo[d] = h->cfg.prior_lo[d]; a.hi[d] = h->cfg.prior_hi[d]; }
     return a;
 }
