@@ -236,6 +236,34 @@ int ssme_lw_set_debug(ssme_lw_handle h, int32_t flags);
 int ssme_lw_last_elapsed_ms(ssme_lw_handle h, float* ms);
 const char* ssme_lw_last_error(ssme_lw_handle h);
 
+/* ---- particle-sharded Liu-West filter: ONE filter of cfg->n_particles particles over `world` GPUs (BASELINE.json configs[4]).
+ * Rank g owns B/world consecutive tiles (n_particles a multiple of 2048 world, at most 2^22; n_filters = 1).  Per step the
+ * host side (ssme_amd/sharded.py, ShardedLiuWest) gathers the tile sums / maxima of the second-stage weights, plans and
+ * exchanges windows of (cdfB, x, theta) for the resampling draw (stage 1), gathers the first-stage tile sums / maxima and
+ * the 14 moment partials per tile, runs ssme_lw_shard_mid on every rank (theta-bar, Cholesky factor: the moment sums are
+ * added in tile order, so every rank gets the unsharded filter's bits), plans and exchanges windows of (cdfA, lw1, x, theta)
+ * for the k draw (stage 2).  theta buffers are 4 planes: [4][tiles * 2048].  Bit-identical to ssme_lw_run_series. */
+int ssme_lw_shard_create(const ssme_lw_config* cfg, int32_t rank, int32_t world, ssme_lw_handle* out);
+int ssme_lw_set_stream(ssme_lw_handle h, void* hip_stream);
+int ssme_lw_shard_prepare(ssme_lw_handle h, const double* y, const double* z, int32_t T);
+/* t = 0 on this rank's tiles: prior draws, q1Samp, first weights */
+int ssme_lw_shard_init(ssme_lw_handle h, double* xB, double* thB, double* cdfB, double* tsumB, double* tmaxB);
+/* which = 0: source-tile ranges of the resampling draw (from the gathered second-stage tile sums), 1: of the k draw
+ * (from the gathered first-stage tile sums); lo_hi_host[2g], [2g+1] per rank.  Synchronises the stream. */
+int ssme_lw_shard_plan(ssme_lw_handle h, int32_t which, int32_t t, const double* tsum_all, const double* tmax_all,
+                       int32_t* lo_hi_host);
+int ssme_lw_shard_stage1(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t win_tiles, const double* w_xB, const double* w_thB,
+                         const double* w_cdfB, const double* tsumB_all, const double* tmaxB_all, double* xr, double* thr, double* lw1,
+                         double* cdfA, double* tsumA, double* tmaxA, double* mom /*[tiles][16]*/, uint32_t* anc);
+int ssme_lw_shard_mid(ssme_lw_handle h, int32_t t, const double* tsumA_all, const double* tmaxA_all, const double* mom_all);
+int ssme_lw_shard_stage2(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t win_tiles, const double* w_xr, const double* w_thr,
+                         const double* w_lw1, const double* w_cdfA, const double* tsumA_all, const double* tmaxA_all, double* xB,
+                         double* thB, double* cdfB, double* tsumB, double* tmaxB, uint32_t* kidx);
+/* accounts the last step t from its gathered second-stage tile sums; then ssme_lw_get_loglik / get_per_step */
+int ssme_lw_shard_finalize(ssme_lw_handle h, int32_t t, const double* tsumB_all, const double* tmaxB_all);
+int ssme_lw_get_loglik(ssme_lw_handle h, double* out);
+
+
 const char* ssme_pf_strerror(int status);
 const char* ssme_pf_last_error(ssme_pf_handle h);
 int ssme_pf_version(void);

@@ -1013,6 +1013,9 @@ struct ssme_lw_s {
     double *ybuf, *zbuf, *per_step, *scratch;
     double *gamA, *pgamA, *gtotA, *gamB, *pgamB, *gtotB;
     uint32_t *anc, *kidx, *keybuf;
+    int shard_rank, shard_world;     // particle-sharded filter (world = 0: unsharded)
+    hipStream_t own_stream;
+    int32_t* plan_dev;
     LwScalars* scal;
     int ycap, tcap, gcap;
     std::string err;
@@ -1116,9 +1119,10 @@ int ssme_lw_destroy(ssme_lw_handle h) {
     if (!h) return SSME_ERR_INVALID_ARG;
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    h->stream = h->own_stream;
     void* bufs[] = {h->xB, h->thB, h->xr, h->thr, h->lw1, h->cdfA, h->tsumA, h->tmaxA, h->cdfB, h->tsumB, h->tmaxB, h->mom, h->prop,
                     h->ybuf, h->zbuf, h->per_step, h->scratch, h->gamA, h->pgamA, h->gtotA, h->gamB, h->pgamB, h->gtotB, h->anc,
-                    h->kidx, h->scal, h->keybuf};
+                    h->kidx, h->scal, h->keybuf, h->plan_dev};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -1127,7 +1131,7 @@ int ssme_lw_destroy(ssme_lw_handle h) {
     return SSME_OK;
 }
 
-int ssme_lw_create(const ssme_lw_config* cfg, ssme_lw_handle* out) {
+static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_world, ssme_lw_handle* out) {
     if (!cfg || !out) return SSME_ERR_INVALID_ARG;
     *out = nullptr;
     if (cfg->n_particles < 1 || cfg->n_filters < 1 || cfg->n_filters > 65535) return SSME_ERR_INVALID_ARG;
@@ -1141,6 +1145,7 @@ int ssme_lw_create(const ssme_lw_config* cfg, ssme_lw_handle* out) {
     ssme_lw_handle h = new (std::nothrow) ssme_lw_s();
     if (!h) return SSME_ERR_INVALID_ARG;
     h->cfg = *cfg;
+    h->shard_rank = shard_rank; h->shard_world = shard_world;
     h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * kTile;
     h->Bs = (B + 1) & ~1; h->Bpow2 = next_pow2(B);
     h->rshift = 52 - ceil_log2(h->Npad);
@@ -1148,15 +1153,20 @@ int ssme_lw_create(const ssme_lw_config* cfg, ssme_lw_handle* out) {
     if (hipSetDevice(cfg->device) != hipSuccess) { delete h; return SSME_ERR_HIP; }
     int rc = [&]() -> int {
         LWCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = h->stream;
         LWCHK(hipEventCreate(&h->ev0));
         LWCHK(hipEventCreate(&h->ev1));
         const size_t np = (size_t)h->R * h->Npad, nb = (size_t)h->R * h->Bs;
-        double** big[] = {&h->xB, &h->xr, &h->lw1, &h->cdfA, &h->cdfB};
-        for (auto p : big) { LWCHK(hipMalloc(p, sizeof(double) * np)); LWCHK(hipMemset(*p, 0, sizeof(double) * np)); }
-        double** big4[] = {&h->thB, &h->thr};
-        for (auto p : big4) { LWCHK(hipMalloc(p, sizeof(double) * np * kDP)); LWCHK(hipMemset(*p, 0, sizeof(double) * np * kDP)); }
-        double** small[] = {&h->tsumA, &h->tmaxA, &h->tsumB, &h->tmaxB};
-        for (auto p : small) { LWCHK(hipMalloc(p, sizeof(double) * nb)); LWCHK(hipMemset(*p, 0, sizeof(double) * nb)); }
+        if (h->shard_world == 0) {               // a sharded handle works on the caller's buffers
+            double** big[] = {&h->xB, &h->xr, &h->lw1, &h->cdfA, &h->cdfB};
+            for (auto p : big) { LWCHK(hipMalloc(p, sizeof(double) * np)); LWCHK(hipMemset(*p, 0, sizeof(double) * np)); }
+            double** big4[] = {&h->thB, &h->thr};
+            for (auto p : big4) { LWCHK(hipMalloc(p, sizeof(double) * np * kDP)); LWCHK(hipMemset(*p, 0, sizeof(double) * np * kDP)); }
+            double** small[] = {&h->tsumA, &h->tmaxA, &h->tsumB, &h->tmaxB};
+            for (auto p : small) { LWCHK(hipMalloc(p, sizeof(double) * nb)); LWCHK(hipMemset(*p, 0, sizeof(double) * nb)); }
+        } else {
+            LWCHK(hipMalloc(&h->plan_dev, sizeof(int32_t) * 2 * h->shard_world));
+        }
         LWCHK(hipMalloc(&h->mom, sizeof(double) * (size_t)h->R * h->B * 16));
         LWCHK(hipMalloc(&h->prop, sizeof(double) * (size_t)h->R * 16));
         LWCHK(hipMemset(h->prop, 0, sizeof(double) * (size_t)h->R * 16));
@@ -1175,6 +1185,161 @@ int ssme_lw_create(const ssme_lw_config* cfg, ssme_lw_handle* out) {
     }();
     if (rc != SSME_OK) { ssme_lw_destroy(h); return rc; }
     *out = h;
+    return SSME_OK;
+}
+
+int ssme_lw_create(const ssme_lw_config* cfg, ssme_lw_handle* out) { return lw_create_impl(cfg, 0, 0, out); }
+
+// ---- particle-sharded Liu-West filter: one filter over `world` GPUs (BASELINE.json configs[4]) ------------------------
+// Same scheme as ssme_pf_shard_* with two exchanges per step: the resampling draw reads windows of (cdfB, x, theta) and the
+// k draw windows of (cdfA, lw1, x, theta); the 14 moment partials of every tile are gathered like the tile sums and summed
+// in tile order by every rank (k_lw_mid), so theta-bar, the Cholesky factor and all draws equal the unsharded filter's.
+int ssme_lw_shard_create(const ssme_lw_config* cfg, int32_t rank, int32_t world, ssme_lw_handle* out) {
+    if (!cfg || !out) return SSME_ERR_INVALID_ARG;
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) return SSME_ERR_INVALID_ARG;
+    if (cfg->n_filters != 1) return SSME_ERR_UNSUPPORTED;
+    if (cfg->n_particles < 1 || cfg->n_particles % (kTile * world) != 0) return SSME_ERR_UNSUPPORTED;
+    return lw_create_impl(cfg, rank, world, out);
+}
+
+int ssme_lw_set_stream(ssme_lw_handle h, void* hip_stream) {
+    if (!h) return SSME_ERR_INVALID_ARG;
+    LWCHK(hipSetDevice(h->cfg.device));
+    LWCHK(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return SSME_OK;
+}
+
+int ssme_lw_shard_prepare(ssme_lw_handle h, const double* y, const double* z, int32_t T) {
+    if (!h || !y) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1) return SSME_ERR_STATE;
+    if (T < 1) return SSME_ERR_LENGTH;
+    LWCHK(hipSetDevice(h->cfg.device));
+    int rc = lw_ensure_capacity(h, T);
+    if (rc != SSME_OK) return rc;
+    LWCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    if (z) LWCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    else LWCHK(hipMemsetAsync(h->zbuf, 0, sizeof(double) * T, h->stream));
+    rc = lw_reset(h);
+    if (rc != SSME_OK) return rc;
+    lw_launch_gamma(h, 0, T);
+    LWCHK(hipGetLastError());
+    return SSME_OK;
+}
+
+static LwArgs lw_shard_args(ssme_lw_handle h, int t) {
+    LwArgs a = lw_args(h);
+    const int Bl = h->B / h->shard_world;
+    a.t = t; a.yi = t; a.gi = t; a.finalize_prev = t > 1 || t == 1 ? 1 : 0;
+    a.per_step = h->per_step;
+    a.tile0 = h->shard_rank * Bl;
+    a.th_dst_stride = (int64_t)Bl * kTile;
+    a.anc = nullptr; a.kidx = nullptr;
+    return a;
+}
+
+int ssme_lw_shard_init(ssme_lw_handle h, double* xB, double* thB, double* cdfB, double* tsumB, double* tmaxB) {
+    if (!h || !xB || !thB || !cdfB || !tsumB || !tmaxB) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1) return SSME_ERR_STATE;
+    LWCHK(hipSetDevice(h->cfg.device));
+    LwArgs a = lw_shard_args(h, 0);
+    a.xB = xB; a.thB = thB; a.cdfB = cdfB; a.tsumB = tsumB; a.tmaxB = tmaxB;
+    hipLaunchKernelGGL(k_lw_init, dim3(h->B / h->shard_world, 1), dim3(kLwNT), 0, h->stream, a);
+    LWCHK(hipGetLastError());
+    h->t = 1;
+    return SSME_OK;
+}
+
+// which = 0: the resampling draw of stage 1 (second-stage weights, Gamma tables B); 1: the k draw of stage 2 (first-stage weights)
+int ssme_lw_shard_plan(ssme_lw_handle h, int32_t which, int32_t t, const double* tsum_all, const double* tmax_all, int32_t* lo_hi) {
+    if (!h || !tsum_all || !tmax_all || !lo_hi || t < 1 || which < 0 || which > 1) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1) return SSME_ERR_STATE;
+    LWCHK(hipSetDevice(h->cfg.device));
+    StepArgs a{};                                   // the fields k_shard_plan reads
+    a.tsum_in = tsum_all; a.tmax_in = tmax_all;
+    a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = 1; a.N = h->N;
+    a.resampler = RESAMP_MULTINOMIAL; a.resamp_sched = 1;
+    a.t = t; a.gi = t;
+    a.pgam = which ? h->pgamA : h->pgamB; a.gtot = which ? h->gtotA : h->gtotB;
+    a.keyp = h->keybuf; a.first_filter = h->cfg.first_filter_id;
+    hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(512), sizeof(double) * (h->Bpow2 < 2 ? 2 : h->Bpow2), h->stream, a,
+                       h->shard_world, h->plan_dev);
+    LWCHK(hipGetLastError());
+    LWCHK(hipMemcpyAsync(lo_hi, h->plan_dev, sizeof(int32_t) * 2 * h->shard_world, hipMemcpyDeviceToHost, h->stream));
+    LWCHK(hipStreamSynchronize(h->stream));
+    return SSME_OK;
+}
+
+int ssme_lw_shard_stage1(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t win_tiles, const double* w_xB, const double* w_thB,
+                         const double* w_cdfB, const double* tsumB_all, const double* tmaxB_all, double* xr, double* thr, double* lw1,
+                         double* cdfA, double* tsumA, double* tmaxA, double* mom, uint32_t* anc) {
+    if (!h || t < 1 || win_tile0 < 0 || win_tiles < 1 || !w_xB || !w_thB || !w_cdfB || !tsumB_all || !tmaxB_all || !xr || !thr || !lw1 ||
+        !cdfA || !tsumA || !tmaxA || !mom)
+        return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1) return SSME_ERR_STATE;
+    if (t >= h->tcap) return SSME_ERR_STATE;
+    LWCHK(hipSetDevice(h->cfg.device));
+    LwArgs a = lw_shard_args(h, t);
+    a.xB = const_cast<double*>(w_xB); a.thB = const_cast<double*>(w_thB); a.cdfB = const_cast<double*>(w_cdfB);
+    a.tsumB = const_cast<double*>(tsumB_all); a.tmaxB = const_cast<double*>(tmaxB_all);
+    a.win_tile0 = win_tile0; a.th_src_stride = (int64_t)win_tiles * kTile;
+    a.xr = xr; a.thr = thr; a.lw1 = lw1; a.cdfA = cdfA; a.tsumA = tsumA; a.tmaxA = tmaxA; a.mom = mom;
+    a.anc = anc;
+    hipLaunchKernelGGL(k_lw_stage1, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes, h->stream, a);
+    LWCHK(hipGetLastError());
+    return SSME_OK;
+}
+
+int ssme_lw_shard_mid(ssme_lw_handle h, int32_t t, const double* tsumA_all, const double* tmaxA_all, const double* mom_all) {
+    if (!h || t < 1 || !tsumA_all || !tmaxA_all || !mom_all) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1) return SSME_ERR_STATE;
+    LWCHK(hipSetDevice(h->cfg.device));
+    LwArgs a = lw_shard_args(h, t);
+    a.tsumA = const_cast<double*>(tsumA_all); a.tmaxA = const_cast<double*>(tmaxA_all); a.mom = const_cast<double*>(mom_all);
+    hipLaunchKernelGGL(k_lw_mid, dim3(1), dim3(kThreads), 0, h->stream, a);
+    LWCHK(hipGetLastError());
+    return SSME_OK;
+}
+
+int ssme_lw_shard_stage2(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t win_tiles, const double* w_xr, const double* w_thr,
+                         const double* w_lw1, const double* w_cdfA, const double* tsumA_all, const double* tmaxA_all, double* xB,
+                         double* thB, double* cdfB, double* tsumB, double* tmaxB, uint32_t* kidx) {
+    if (!h || t < 1 || win_tile0 < 0 || win_tiles < 1 || !w_xr || !w_thr || !w_lw1 || !w_cdfA || !tsumA_all || !tmaxA_all || !xB || !thB ||
+        !cdfB || !tsumB || !tmaxB)
+        return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1) return SSME_ERR_STATE;
+    LWCHK(hipSetDevice(h->cfg.device));
+    LwArgs a = lw_shard_args(h, t);
+    a.xr = const_cast<double*>(w_xr); a.thr = const_cast<double*>(w_thr); a.lw1 = const_cast<double*>(w_lw1);
+    a.cdfA = const_cast<double*>(w_cdfA); a.tsumA = const_cast<double*>(tsumA_all); a.tmaxA = const_cast<double*>(tmaxA_all);
+    a.win_tile0 = win_tile0; a.th_src_stride = (int64_t)win_tiles * kTile;
+    a.xB = xB; a.thB = thB; a.cdfB = cdfB; a.tsumB = tsumB; a.tmaxB = tmaxB;
+    a.kidx = kidx;
+    hipLaunchKernelGGL(k_lw_stage2, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes, h->stream, a);
+    LWCHK(hipGetLastError());
+    h->t = t + 1;
+    return SSME_OK;
+}
+
+int ssme_lw_shard_finalize(ssme_lw_handle h, int32_t t, const double* tsumB_all, const double* tmaxB_all) {
+    if (!h || t < 0 || !tsumB_all || !tmaxB_all) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1) return SSME_ERR_STATE;
+    LWCHK(hipSetDevice(h->cfg.device));
+    LwArgs a = lw_shard_args(h, t);
+    a.tsumB = const_cast<double*>(tsumB_all); a.tmaxB = const_cast<double*>(tmaxB_all);
+    hipLaunchKernelGGL(k_lw_finalize, dim3(1), dim3(kThreads), 0, h->stream, a);
+    LWCHK(hipGetLastError());
+    LWCHK(hipStreamSynchronize(h->stream));
+    return SSME_OK;
+}
+
+int ssme_lw_get_loglik(ssme_lw_handle h, double* out) {
+    if (!h || !out) return SSME_ERR_INVALID_ARG;
+    LWCHK(hipSetDevice(h->cfg.device));
+    std::vector<LwScalars> sc(h->R);
+    LWCHK(hipMemcpyAsync(sc.data(), h->scal, sizeof(LwScalars) * h->R, hipMemcpyDeviceToHost, h->stream));
+    LWCHK(hipStreamSynchronize(h->stream));
+    for (int r = 0; r < h->R; ++r) out[r] = sc[r].loglik;
     return SSME_OK;
 }
 

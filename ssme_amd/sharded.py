@@ -29,7 +29,7 @@ from ._capi import SsmeError
 
 TILE = 2048
 
-__all__ = ["ShardedParticleFilter", "exchange_plan", "TILE"]
+__all__ = ["ShardedParticleFilter", "ShardedLiuWest", "exchange_plan", "TILE"]
 
 
 def exchange_plan(lo_hi, tiles_per_rank, rank):
@@ -213,3 +213,138 @@ class ShardedParticleFilter:
 
     def local_cdf(self):
         return self.cdf.reshape(-1).cpu().numpy()
+
+
+class ShardedLiuWest:
+    """Liu-West filter (svol_lw_1_par: test/test_liu_west.cpp:22-157) with its particles sharded over the ranks of a
+    torch.distributed group -- BASELINE.json configs[4].  Two exchanges per time step (module docstring scheme, twice):
+
+        gather (tsumB, tmaxB)                -> plan 0 -> windows of (cdfB, x, theta)        -> stage 1 (resample, lw1, moments)
+        gather (tsumA, tmaxA, 14 moments)    -> mid (theta-bar, Cholesky; every rank, same bits)
+                                             -> plan 1 -> windows of (cdfA, lw1, x, theta)   -> stage 2 (k draw, jitter, fSamp)
+
+    Bit-identical to the unsharded `svol_lw_1_par.run_series` with the same N and seed (tests/test_sharded_gpu.py).
+    """
+
+    def __init__(self, delta, phi_l, phi_u, mu_l, mu_u, sig_l, sig_u, rho_l, rho_u, nparts, seed=0, transforms=(2, 0, 3, 1),
+                 device=None, group=None, filter_id=0):
+        import torch
+        import torch.distributed as dist
+        assert dist.is_initialized(), "init_process_group first (one process per GPU)"
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.stage = dist.get_backend(group) != "nccl"
+        if nparts % (TILE * self.world) != 0:
+            raise SsmeError(capi.ERR_UNSUPPORTED, f"nparts must be a multiple of {TILE} x world ({self.world})")
+        self.n, self.B = int(nparts), nparts // TILE
+        self.Bl = self.B // self.world
+        self.tile0 = self.rank * self.Bl
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        cfg = capi.LwConfig(n_particles=nparts, n_filters=1, seed=seed, device=self.device.index or 0, first_filter_id=filter_id,
+                            delta=delta)
+        cfg.transforms[:] = list(transforms)
+        cfg.prior_lo[:] = [phi_l, mu_l, sig_l, rho_l]
+        cfg.prior_hi[:] = [phi_u, mu_u, sig_u, rho_u]
+        self._h = C.c_void_p()
+        capi.check(capi.lib().ssme_lw_shard_create(C.byref(cfg), self.rank, self.world, C.byref(self._h)))
+        self._stream = torch.cuda.Stream(self.device)
+        self._chk(capi.lib().ssme_lw_set_stream(self._h, C.c_void_p(self._stream.cuda_stream)))
+        f64 = dict(dtype=torch.float64, device=self.device)
+        Bl = self.Bl
+        self.xB, self.cdfB = torch.zeros((Bl, TILE), **f64), torch.zeros((Bl, TILE), **f64)
+        self.thB = torch.zeros((4, Bl, TILE), **f64)
+        self.xr, self.lw1, self.cdfA = (torch.zeros((Bl, TILE), **f64) for _ in range(3))
+        self.thr = torch.zeros((4, Bl, TILE), **f64)
+        self.tilesB = torch.zeros((2, Bl), **f64)            # rows: tile sums, tile maxima (second-stage weights)
+        self.tilesA = torch.zeros((2, Bl), **f64)
+        self.mom = torch.zeros((Bl, 16), **f64)
+        self.allB = torch.zeros((2, self.B), **f64)
+        self.allA = torch.zeros((2, self.B), **f64)
+        self.mom_all = torch.zeros((self.B, 16), **f64)
+        self.exchanged_tiles = 0
+        self._T = 0
+        torch.cuda.synchronize(self.device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            capi.lib().ssme_lw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _chk(self, status):
+        if status != capi.OK:
+            msg = capi.lib().ssme_pf_strerror(status).decode()
+            if status == capi.ERR_HIP:
+                msg += " (" + capi.lib().ssme_lw_last_error(self._h).decode() + ")"
+            raise SsmeError(status, msg)
+
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr())
+
+    def _gather(self, loc, out_cat_dim):
+        """all_gather of a small per-rank tensor; concatenated over ranks along out_cat_dim."""
+        import torch
+        import torch.distributed as dist
+        src = loc.cpu() if self.stage else loc
+        parts = [torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(parts, src.contiguous(), group=self.group)
+        return torch.cat(parts, dim=out_cat_dim).to(self.device)
+
+    def _windows(self, which, t, tiles_all, planes2d, planes4):
+        """plan + exchange: returns (win_tile0, win_tiles, [2-D windows], [4-plane window])."""
+        import torch
+        lo_hi = (C.c_int32 * (2 * self.world))()
+        self._chk(capi.lib().ssme_lw_shard_plan(self._h, which, t, self._ptr(tiles_all[0]), self._ptr(tiles_all[1]), lo_hi))
+        plan = [(lo_hi[2 * g], lo_hi[2 * g + 1]) for g in range(self.world)]
+        sends, recvs = exchange_plan(plan, self.Bl, self.rank)
+        self.exchanged_tiles += sum(c for s, (_, c) in enumerate(recvs) if s != self.rank)
+        wins = [exchange_tiles(p, self.tile0, sends, recvs, self.rank, self.group, self.stage) for p in planes2d]
+        w4 = torch.stack([exchange_tiles(planes4[d], self.tile0, sends, recvs, self.rank, self.group, self.stage) for d in range(4)])
+        return plan[self.rank][0], plan[self.rank][1] - plan[self.rank][0] + 1, wins, w4.contiguous()
+
+    def run_series(self, y, z=None):
+        import torch
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._stream):
+            return self._run_series(y, z)
+
+    def _run_series(self, y, z):
+        L, p = capi.lib(), self._ptr
+        yv = capi.as_f64(y)
+        zv = None if z is None else capi.as_f64(z)
+        T = yv.size
+        self._chk(L.ssme_lw_shard_prepare(self._h, capi.dptr(yv), capi.dptr(zv), T))
+        self.exchanged_tiles = 0
+        self._chk(L.ssme_lw_shard_init(self._h, p(self.xB), p(self.thB), p(self.cdfB), p(self.tilesB[0]), p(self.tilesB[1])))
+        for t in range(1, T):
+            self.allB.copy_(self._gather(self.tilesB, 1))
+            w0, wt, (w_x, w_cdf), w_th = self._windows(0, t, self.allB, [self.xB, self.cdfB], self.thB)
+            self._chk(L.ssme_lw_shard_stage1(self._h, t, w0, wt, p(w_x), p(w_th), p(w_cdf), p(self.allB[0]), p(self.allB[1]),
+                                             p(self.xr), p(self.thr), p(self.lw1), p(self.cdfA), p(self.tilesA[0]),
+                                             p(self.tilesA[1]), p(self.mom), None))
+            self.allA.copy_(self._gather(self.tilesA, 1))
+            self.mom_all.copy_(self._gather(self.mom, 0))
+            self._chk(L.ssme_lw_shard_mid(self._h, t, p(self.allA[0]), p(self.allA[1]), p(self.mom_all)))
+            w0, wt, (w_x, w_lw1, w_cdf), w_th = self._windows(1, t, self.allA, [self.xr, self.lw1, self.cdfA], self.thr)
+            self._chk(L.ssme_lw_shard_stage2(self._h, t, w0, wt, p(w_x), p(w_th), p(w_lw1), p(w_cdf), p(self.allA[0]),
+                                             p(self.allA[1]), p(self.xB), p(self.thB), p(self.cdfB), p(self.tilesB[0]),
+                                             p(self.tilesB[1]), None))
+        self.allB.copy_(self._gather(self.tilesB, 1))
+        self._chk(L.ssme_lw_shard_finalize(self._h, T - 1, p(self.allB[0]), p(self.allB[1])))
+        self._T = T
+        out = np.empty(1)
+        self._chk(L.ssme_lw_get_loglik(self._h, capi.dptr(out)))
+        return float(out[0])
+
+    def per_step(self):
+        out = np.empty((1, self._T))
+        self._chk(capi.lib().ssme_lw_get_per_step(self._h, capi.dptr(out), self._T))
+        return out[0]
+
+    def local_particles(self):
+        return self.xB.reshape(-1).cpu().numpy()
+
+    def local_theta(self):
+        return self.thB.reshape(4, -1).cpu().numpy()

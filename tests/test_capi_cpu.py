@@ -111,6 +111,9 @@ def test_shard_and_liu_west_entry_points_validate_arguments():
     bad.prior_lo[0], bad.prior_hi[0] = 0.9, 0.8                                                  # empty prior interval
     assert L.ssme_lw_create(C.byref(bad), C.byref(h)) == _capi.ERR_INVALID_ARG
     assert L.ssme_lw_destroy(None) == _capi.ERR_INVALID_ARG
+    assert L.ssme_lw_shard_create(C.byref(lw), 0, 0, C.byref(h)) == _capi.ERR_INVALID_ARG      # world < 1
+    assert L.ssme_lw_shard_create(C.byref(lw), 0, 2, C.byref(h)) == _capi.ERR_UNSUPPORTED      # 100 particles: not whole tiles per rank
+    assert L.ssme_lw_set_stream(None, None) == _capi.ERR_INVALID_ARG
     assert not h.value
 
 

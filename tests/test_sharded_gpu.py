@@ -78,3 +78,43 @@ def test_sharded_filter_with_degenerate_weights(tmp_path, spy):
     ref.set_params(TH[1])
     assert float(res[0]["ll"]) == ref.run_series(y, z)[0]
     ref.close()
+
+
+def _run_sharded_lw(tmp_path, world, n, T, seed, delta):
+    port = _free_port()
+    outs = [str(tmp_path / f"lw_rank{r}.npz") for r in range(world)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker_lw.py"), str(r), str(world), str(port),
+                               outs[r], str(n), str(T), str(seed), str(delta)], env=env) for r in range(world)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=240) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return [np.load(o) for o in outs]
+
+
+@pytest.mark.parametrize("world,n,delta", [(2, 16384, 0.99), (4, 32768, 0.95), (2, 8192, 1.0)])
+def test_sharded_liu_west_is_bit_identical_to_unsharded(tmp_path, spy, world, n, delta):
+    """BASELINE.json configs[4] in small: Liu-West filter over G ranks == the unsharded filter (log-likelihoods, particles,
+    transformed parameters), two window exchanges and one moment gather per step."""
+    import ssme_amd
+    T, seed = 10, 99
+    res = _run_sharded_lw(tmp_path, world, n, T, seed, delta)
+    y = spy[:T]
+    z = np.concatenate([[0.0], y[:-1]])
+    ref = ssme_amd.svol_lw_1_par(delta, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, seed=seed)
+    ll = ref.run_series(y, z)[0]
+    per = ref.per_step()[0]
+    st = ref.state(0)
+    ref.close()
+    for r in res:
+        assert float(r["ll"]) == ll
+        assert np.array_equal(r["per_step"].view(np.uint64), per.view(np.uint64))
+    x = np.concatenate([r["x"] for r in res])
+    th = np.concatenate([r["theta"] for r in res], axis=1)
+    assert np.array_equal(x.view(np.uint64), st["x"].view(np.uint64))
+    assert np.array_equal(th.view(np.uint64), st["theta"].view(np.uint64))
+    assert sum(int(r["exchanged"]) for r in res) > 0

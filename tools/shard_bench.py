@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--resampler", type=int, default=0)
+    ap.add_argument("--lw", action="store_true", help="Liu-West filter (BASELINE.json configs[4]) instead of the bootstrap filter")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -39,21 +40,25 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local % ndev))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    from ssme_amd.sharded import ShardedParticleFilter
+    from ssme_amd.sharded import ShardedLiuWest, ShardedParticleFilter
     y = np.loadtxt(os.path.join(ROOT, "tests", "golden", "spy_returns.csv"))[:a.T]
-    f = ShardedParticleFilter(0, a.particles, seed=20260101, resampler=a.resampler)
-    f.set_params([1.0, 0.95, 0.25])
+    z = np.concatenate([[0.0], y[:-1]]) if a.lw else None
+    if a.lw:
+        f = ShardedLiuWest(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=a.particles, seed=20260101)
+    else:
+        f = ShardedParticleFilter(0, a.particles, seed=20260101, resampler=a.resampler)
+        f.set_params([1.0, 0.95, 0.25])
     best, ll = 1e30, None
     for _ in range(a.passes):
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        ll = f.run_series(y)
+        ll = f.run_series(y, z)
         torch.cuda.synchronize()
         dist.barrier()
         best = min(best, time.perf_counter() - t0)
     if rank == 0:
-        print(json.dumps({"sharded_filter": True, "world": world, "backend": a.backend, "particles": a.particles, "T": a.T,
+        print(json.dumps({"sharded_filter": "liu-west" if a.lw else "bootstrap", "world": world, "backend": a.backend, "particles": a.particles, "T": a.T,
                           "loglik": ll, "us_per_step": best / a.T * 1e6, "particle_steps_per_s": a.particles * a.T / best,
                           "tiles_received_from_peers": f.exchanged_tiles}), flush=True)
     f.close()
