@@ -52,6 +52,10 @@ struct LwArgs {
     // windows starting at tile win_tile0 with parameter planes th_src_stride apart; written planes are th_dst_stride apart
     int32_t tile0, win_tile0;
     int64_t th_src_stride, th_dst_stride;
+    // split level-2 (k_level2_plan; filters of more than 2048 tiles or by policy): per draw T', A/A', source ranges, (m, S)
+    const double *l2B_T, *l2B_R, *l2A_T, *l2A_R;      // [R][Bs]
+    const int32_t *l2B_lo, *l2B_hi, *l2A_lo, *l2A_hi;
+    const FilterScalars *l2B_s, *l2A_s;              // [R]: m and S of the draw's weights
     uint32_t key0, key1, first_filter;
     double logN, a_shrink;
     int32_t trans[kDP];
@@ -99,38 +103,50 @@ struct LwLds {
     double* seg_a; double* seg_l2; double* d1; int* cnt;
 };
 
+// level-2 results of one draw as k_level2_plan left them (split level-2)
+struct L2View { const double* T; const double* R; const int32_t* lo; const int32_t* hi; double m, S; };
+
+template <bool BIG>
 __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax, const double* cdf, int B, int Bpow2, int rshift,
                                           int N, int b, double gam, double pgam, double pgam_next, double G, int spacing_stream,
                                           uint32_t t, uint32_t rep, uint32_t k0, uint32_t k1, const LwLds& L, int (&idx)[2][2],
-                                          double& m_out, double& S_out, int win_tile0 = 0) {
+                                          double& m_out, double& S_out, int win_tile0, const L2View& v) {
     constexpr int NT = kLwNT, NK = 2, NE = 4;
     const int tid = threadIdx.x;
     const int i_first = b * kTile;
     __builtin_amdgcn_s_setprio(3);                 // wave priority falls as the workgroup advances (see prio_at)
-    double A2[NE], M2[NE];
-    level2_load<NT>(tsum, tmax, B, A2, M2);
-    if (tid == 0) { L.cnt[0] = 0; L.cnt[1] = 0; }
-    double Ap[NE], Tinc[NE], m, S;
-    level2_scan<NT>(A2, M2, B, rshift, m, Ap, Tinc, S, L.d1, L.seg_l2);
-    m_out = m; S_out = S;
-    const double t_scale = S / G;
-    const double t_lo = __builtin_ceil(pgam * t_scale);
-    const double t_hi = __builtin_ceil(pgam_next * t_scale) + (S * 0x1.0p-40 + 2.0);
+    double t_scale;
+    int lo, hi;
+    if constexpr (BIG) {
+        m_out = v.m; S_out = v.S;
+        t_scale = v.S / G;
+        lo = v.lo[b]; hi = v.hi[b];
+    } else {
+        double A2[NE], M2[NE];
+        level2_load<NT>(tsum, tmax, B, A2, M2);
+        if (tid == 0) { L.cnt[0] = 0; L.cnt[1] = 0; }
+        double Ap[NE], Tinc[NE], m, S;
+        level2_scan<NT>(A2, M2, B, rshift, m, Ap, Tinc, S, L.d1, L.seg_l2);
+        m_out = m; S_out = S;
+        t_scale = S / G;
+        const double t_lo = __builtin_ceil(pgam * t_scale);
+        const double t_hi = __builtin_ceil(pgam_next * t_scale) + (S * 0x1.0p-40 + 2.0);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        if (e * NT < Bpow2) {
-            const int j = e * NT + tid;
-            if (j < Bpow2) {
-                L.lds_T[j] = (j < B) ? Tinc[e] : dinf();
-                L.lds_R[j] = (j < B) ? A2[e] / Ap[e] : 0.0;
+        for (int e = 0; e < NE; ++e) {
+            if (e * NT < Bpow2) {
+                const int j = e * NT + tid;
+                if (j < Bpow2) {
+                    L.lds_T[j] = (j < B) ? Tinc[e] : dinf();
+                    L.lds_R[j] = (j < B) ? A2[e] / Ap[e] : 0.0;
+                }
+                const int w_lo = __popcll(__ballot(j < B && Tinc[e] < t_lo));
+                const int w_hi = __popcll(__ballot(j < B && Tinc[e] < t_hi));
+                if ((tid & 63) == 0) { if (w_lo) atomicAdd(&L.cnt[0], w_lo); if (w_hi) atomicAdd(&L.cnt[1], w_hi); }
             }
-            const int w_lo = __popcll(__ballot(j < B && Tinc[e] < t_lo));
-            const int w_hi = __popcll(__ballot(j < B && Tinc[e] < t_hi));
-            if ((tid & 63) == 0) { if (w_lo) atomicAdd(&L.cnt[0], w_lo); if (w_hi) atomicAdd(&L.cnt[1], w_hi); }
         }
+        __syncthreads();
+        lo = L.cnt[0]; hi = L.cnt[1];
     }
-    __syncthreads();
-    int lo = L.cnt[0], hi = L.cnt[1];
     lo = lo < B - 1 ? lo : B - 1;
     hi = hi < B - 1 ? hi : B - 1;
     const int bb_min = __builtin_amdgcn_readfirstlane(lo);
@@ -187,10 +203,10 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
             for (int k = 0; k < NK; ++k) *reinterpret_cast<double2*>(dst + 2 * kTile + k * NT * 2) = stg2[k];
         }
         const int b1 = bb_min + 1 < B ? bb_min + 1 : B - 1, b2 = bb_min + 2 < B ? bb_min + 2 : B - 1;
-        const double T0 = L.lds_T[bb_min];
-        const double T1 = (bb_min + 1 < B) ? L.lds_T[bb_min + 1] : dinf();
-        const double Pm = bb_min ? L.lds_T[bb_min - 1] : 0.0;
-        const double R0 = L.lds_R[bb_min], R1 = L.lds_R[b1], R2 = L.lds_R[b2];
+        const double T0 = BIG ? v.T[bb_min] : L.lds_T[bb_min];
+        const double T1 = (bb_min + 1 < B) ? (BIG ? v.T[bb_min + 1] : L.lds_T[bb_min + 1]) : dinf();
+        const double Pm = bb_min ? (BIG ? v.T[bb_min - 1] : L.lds_T[bb_min - 1]) : 0.0;
+        const double R0 = BIG ? v.R[bb_min] : L.lds_R[bb_min], R1 = BIG ? v.R[b1] : L.lds_R[b1], R2 = BIG ? v.R[b2] : L.lds_R[b2];
         __syncthreads();
         // the four count-searches of a thread descend together (11 dependent LDS round trips; see k_filter_step)
         double tloc[NK][2];
@@ -232,10 +248,10 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const double target = tau[k][c];
-                int bb = count_less_pow2(Bpow2, target, [&](int j) { return L.lds_T[j]; });
+                int bb = count_less_pow2(Bpow2, target, [&](int j) { return BIG ? (j < B ? v.T[j] : dinf()) : L.lds_T[j]; });
                 bb = bb < B - 1 ? bb : B - 1;
-                const double Pb = bb ? L.lds_T[bb - 1] : 0.0;
-                const double tloc = __builtin_ceil((target - Pb) * L.lds_R[bb]);
+                const double Pb = bb ? (BIG ? v.T[bb - 1] : L.lds_T[bb - 1]) : 0.0;
+                const double tloc = __builtin_ceil((target - Pb) * (BIG ? v.R[bb] : L.lds_R[bb]));
                 const double* tile = cdf + (size_t)(bb - win_tile0) * kTile;
                 const int j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
                 int a = bb * kTile + j;
@@ -279,7 +295,7 @@ __device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int N, in
 
 #define LW_LDS_SETUP(a)                                                                                   \
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                                  \
-    const int nT2 = (a).Bpow2 < 2 ? 2 : (a).Bpow2;                                                        \
+    const int nT2 = (BIG || (a).Bpow2 < 2) ? 2 : (a).Bpow2;                                               \
     __shared__ double lds_seg_a[16];                                                                      \
     __shared__ double lds_seg_l2[64];                                                                     \
     __shared__ double lds_seg_c[16];                                                                      \
@@ -336,6 +352,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_init(const LwArgs a) {
 // ---------------------------------------------------------------------------------------
 // Stage 1 (t >= 1).  grid = (B, R), block = 512, dynamic LDS as k_filter_step
 // ---------------------------------------------------------------------------------------
+template <bool BIG>
 __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
     constexpr int NT = kLwNT, NK = 2;
     LW_LDS_SETUP(a)
@@ -356,8 +373,14 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
     // resample (x, theta) by the previous second-stage weights: liu_west_filter.h:91-145 via the exact cdf
     int anc[NK][2];
     double mB, SB;
-    lw_select(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.cdfB + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
-              a.gamB[gidx], a.pgamB[gidx], pgam_next, G, STREAM_RESAMP, (uint32_t)a.t, rep, a.key0, a.key1, L, anc, mB, SB, a.win_tile0);
+    L2View vB{};
+    if (BIG) {
+        vB.T = a.l2B_T + (size_t)r * a.Bs; vB.R = a.l2B_R + (size_t)r * a.Bs; vB.lo = a.l2B_lo + (size_t)r * a.Bs;
+        vB.hi = a.l2B_hi + (size_t)r * a.Bs; vB.m = a.l2B_s[r].m; vB.S = a.l2B_s[r].S;
+    }
+    lw_select<BIG>(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.cdfB + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
+                   a.gamB[gidx], a.pgamB[gidx], pgam_next, G, STREAM_RESAMP, (uint32_t)a.t, rep, a.key0, a.key1, L, anc, mB, SB,
+                   a.win_tile0, vB);
     if (bloc == 0 && tid == 0 && a.finalize_prev) {
         // log p(y_{t-1} | y_{1:t-2}): :1047 with all old weights equal after resampling; :1136 at t-1 = 0
         LwScalars* sc = a.scal + r;
@@ -425,13 +448,14 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
 // ---------------------------------------------------------------------------------------
 // Mid: proposal components (:1184-1198) + log-sum-exp of the first-stage weights.  grid = (R), block = 256
 // ---------------------------------------------------------------------------------------
+template <bool BIG>
 __global__ __launch_bounds__(kThreads) void k_lw_mid(const LwArgs a) {
     __shared__ double lds_seg[128];
     __shared__ double lds_d[16];
     __shared__ double sums[kNMom];
     const int tid = threadIdx.x, r = blockIdx.x;
     double A2[8], Ap[8], Tinc[8], M2[8], S, m;
-    level2_load<kThreads>(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.B, A2, M2);
+    if (!BIG) level2_load<kThreads>(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.B, A2, M2);
     // moment totals: wave w handles moments w, w+4, ...: 64 lanes add contiguous chunks of tiles in order, then the wave tree
     const int lane = tid & 63, wave = tid >> 6;
     const int c = (a.B + 63) / 64;
@@ -462,7 +486,8 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid(const LwArgs a) {
             if (lane == 63 && q < kNMom) sums[q] = sw;
         }
     }
-    level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
+    if (BIG) { m = a.l2A_s[r].m; S = a.l2A_s[r].S; }
+    else level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
     __syncthreads();
     if (tid == 0) {
         LwScalars* sc = a.scal + r;
@@ -495,6 +520,7 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid(const LwArgs a) {
 // ---------------------------------------------------------------------------------------
 // Stage 2 (t >= 1).  grid = (B, R), block = 512
 // ---------------------------------------------------------------------------------------
+template <bool BIG>
 __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
     constexpr int NT = kLwNT, NK = 2;
     LW_LDS_SETUP(a)
@@ -516,8 +542,14 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
     // k ~ Categorical(first-stage weights): k_gen.sample, :1006
     int kk[NK][2];
     double mA, SA;
-    lw_select(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.cdfA + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
-              a.gamA[gidx], a.pgamA[gidx], pgam_next, G, STREAM_LW_K, (uint32_t)a.t, rep, a.key0, a.key1, L, kk, mA, SA, a.win_tile0);
+    L2View vA{};
+    if (BIG) {
+        vA.T = a.l2A_T + (size_t)r * a.Bs; vA.R = a.l2A_R + (size_t)r * a.Bs; vA.lo = a.l2A_lo + (size_t)r * a.Bs;
+        vA.hi = a.l2A_hi + (size_t)r * a.Bs; vA.m = a.l2A_s[r].m; vA.S = a.l2A_s[r].S;
+    }
+    lw_select<BIG>(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.cdfA + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
+                   a.gamA[gidx], a.pgamA[gidx], pgam_next, G, STREAM_LW_K, (uint32_t)a.t, rep, a.key0, a.key1, L, kk, mA, SA,
+                   a.win_tile0, vA);
     double lg[NK][2];
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -572,13 +604,17 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
 // ---------------------------------------------------------------------------------------
 // Accounts the last step's log conditional likelihood.  grid = (R), block = 256
 // ---------------------------------------------------------------------------------------
+template <bool BIG>
 __global__ __launch_bounds__(kThreads) void k_lw_finalize(const LwArgs a) {
     __shared__ double lds_seg[128];
     __shared__ double lds_d[16];
     const int tid = threadIdx.x, r = blockIdx.x;
     double A2[8], Ap[8], Tinc[8], M2[8], S, m;
-    level2_load<kThreads>(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.B, A2, M2);
-    level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
+    if (BIG) { m = a.l2B_s[r].m; S = a.l2B_s[r].S; }
+    else {
+        level2_load<kThreads>(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.B, A2, M2);
+        level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
+    }
     if (tid == 0) {
         LwScalars* sc = a.scal + r;
         const double Sd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();

@@ -1016,6 +1016,11 @@ struct ssme_lw_s {
     int shard_rank, shard_world;     // particle-sharded filter (world = 0: unsharded)
     hipStream_t own_stream;
     int32_t* plan_dev;
+    int split_l2;                    // level-2 of both draws by k_level2_plan (more than 512 tiles)
+    double *l2T[2], *l2R[2];         // [draw: 0 resampling (B), 1 k draw (A)][R][Bs]
+    int32_t *l2lo[2], *l2hi[2];
+    FilterScalars* l2s[2];
+    size_t lds_bytes_big, lds_bytes_plan;
     LwScalars* scal;
     int ycap, tcap, gcap;
     std::string err;
@@ -1041,6 +1046,8 @@ static LwArgs lw_args(ssme_lw_handle h) {
     a.logN = dlog((double)h->N);
     a.a_shrink = (3.0 * h->cfg.delta - 1.0) / (2.0 * h->cfg.delta);          // liu_west_filter.h:960
     a.tile0 = 0; a.win_tile0 = 0; a.th_src_stride = h->Npad; a.th_dst_stride = h->Npad;
+    a.l2B_T = h->l2T[0]; a.l2B_R = h->l2R[0]; a.l2B_lo = h->l2lo[0]; a.l2B_hi = h->l2hi[0]; a.l2B_s = h->l2s[0];
+    a.l2A_T = h->l2T[1]; a.l2A_R = h->l2R[1]; a.l2A_lo = h->l2lo[1]; a.l2A_hi = h->l2hi[1]; a.l2A_s = h->l2s[1];
     for (int d = 0; d < kDP; ++d) { a.trans[d] = h->cfg.transforms[d]; a.lo[d] = h->cfg.prior_lo[d]; a.hi[d] = h->cfg.prior_hi[d]; }
     return a;
 }
@@ -1084,6 +1091,20 @@ static void lw_launch_gamma(ssme_lw_handle h, int t0, int nT) {
                        h->cfg.first_filter_id, (uint32_t)STREAM_LW_K_EXTRA);
 }
 
+// split level-2 of one draw (0: resampling draw over the second-stage weights, 1: k draw over the first-stage weights)
+static void lw_launch_plan(ssme_lw_handle h, int draw, int t, int gi, const double* tsum, const double* tmax, bool ranges) {
+    StepArgs a{};
+    a.tsum_in = tsum; a.tmax_in = tmax;
+    a.l2_T = h->l2T[draw]; a.l2_R = h->l2R[draw]; a.l2_lo = h->l2lo[draw]; a.l2_hi = h->l2hi[draw];
+    a.scal = h->l2s[draw];
+    a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = h->R; a.N = h->N;
+    a.resampler = RESAMP_MULTINOMIAL; a.resamp_sched = 1;
+    a.t = t; a.gi = gi; a.finalize_prev = 0;
+    a.pgam = draw ? h->pgamA : h->pgamB; a.gtot = draw ? h->gtotA : h->gtotB;
+    a.keyp = h->keybuf; a.first_filter = h->cfg.first_filter_id;
+    hipLaunchKernelGGL(k_level2_plan, dim3(h->shard_world > 0 ? 1 : h->R), dim3(1024), h->lds_bytes_plan, h->stream, a, ranges ? 1 : 0);
+}
+
 static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record, bool finalize_prev) {
     LwArgs a = lw_args(h);
     a.t = t; a.yi = yi; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
@@ -1091,17 +1112,27 @@ static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record
     const dim3 grid(h->B, h->R);
     if (t == 0) {
         hipLaunchKernelGGL(k_lw_init, grid, dim3(kLwNT), 0, h->stream, a);
+    } else if (h->split_l2) {
+        lw_launch_plan(h, 0, t, gi, h->tsumB, h->tmaxB, true);
+        hipLaunchKernelGGL(k_lw_stage1<true>, grid, dim3(kLwNT), h->lds_bytes_big, h->stream, a);
+        lw_launch_plan(h, 1, t, gi, h->tsumA, h->tmaxA, true);
+        hipLaunchKernelGGL(k_lw_mid<true>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
+        hipLaunchKernelGGL(k_lw_stage2<true>, grid, dim3(kLwNT), h->lds_bytes_big, h->stream, a);
     } else {
-        hipLaunchKernelGGL(k_lw_stage1, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
-        hipLaunchKernelGGL(k_lw_mid, dim3(h->R), dim3(kThreads), 0, h->stream, a);
-        hipLaunchKernelGGL(k_lw_stage2, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
+        hipLaunchKernelGGL(k_lw_stage1<false>, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
+        hipLaunchKernelGGL(k_lw_mid<false>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
+        hipLaunchKernelGGL(k_lw_stage2<false>, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
     }
 }
 static void lw_enqueue_finalize(ssme_lw_handle h, int t, bool record) {
     LwArgs a = lw_args(h);
     a.t = t;
     a.per_step = record ? h->per_step : nullptr;
-    hipLaunchKernelGGL(k_lw_finalize, dim3(h->R), dim3(kThreads), 0, h->stream, a);
+    if (h->split_l2) {
+        lw_launch_plan(h, 0, t + 1, 0, h->tsumB, h->tmaxB, false);
+        hipLaunchKernelGGL(k_lw_finalize<true>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
+    } else
+        hipLaunchKernelGGL(k_lw_finalize<false>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
 }
 
 static int lw_reset(ssme_lw_handle h) {
@@ -1122,7 +1153,8 @@ int ssme_lw_destroy(ssme_lw_handle h) {
     h->stream = h->own_stream;
     void* bufs[] = {h->xB, h->thB, h->xr, h->thr, h->lw1, h->cdfA, h->tsumA, h->tmaxA, h->cdfB, h->tsumB, h->tmaxB, h->mom, h->prop,
                     h->ybuf, h->zbuf, h->per_step, h->scratch, h->gamA, h->pgamA, h->gtotA, h->gamB, h->pgamB, h->gtotB, h->anc,
-                    h->kidx, h->scal, h->keybuf, h->plan_dev};
+                    h->kidx, h->scal, h->keybuf, h->plan_dev, h->l2T[0], h->l2T[1], h->l2R[0], h->l2R[1], h->l2lo[0], h->l2lo[1],
+                    h->l2hi[0], h->l2hi[1], h->l2s[0], h->l2s[1]};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -1141,7 +1173,7 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
         if (!(cfg->prior_lo[d] <= cfg->prior_hi[d])) return SSME_ERR_INVALID_ARG;
     }
     const int B = (cfg->n_particles + kTile - 1) / kTile;
-    if (B > kMaxTilesPerFilter) return SSME_ERR_UNSUPPORTED;
+    if (B > kMaxTilesSplit) return SSME_ERR_UNSUPPORTED;          // N <= 2^25
     ssme_lw_handle h = new (std::nothrow) ssme_lw_s();
     if (!h) return SSME_ERR_INVALID_ARG;
     h->cfg = *cfg;
@@ -1149,11 +1181,26 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
     h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * kTile;
     h->Bs = (B + 1) & ~1; h->Bpow2 = next_pow2(B);
     h->rshift = 52 - ceil_log2(h->Npad);
-    h->lds_bytes = sizeof(double) * (2 * (size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2) + (size_t)kStageTiles * kTile);
+    h->split_l2 = B > kSplitLevel2Above ? 1 : 0;
+    h->lds_bytes = sizeof(double) * (2 * (size_t)(B > kMaxTilesPerFilter ? 2 : (h->Bpow2 < 2 ? 2 : h->Bpow2)) + (size_t)kStageTiles * kTile);
+    h->lds_bytes_big = sizeof(double) * (4 + (size_t)kStageTiles * kTile);
+    h->lds_bytes_plan = sizeof(double) * (size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2);
     if (hipSetDevice(cfg->device) != hipSuccess) { delete h; return SSME_ERR_HIP; }
     int rc = [&]() -> int {
         LWCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->own_stream = h->stream;
+        for (int d = 0; d < 2; ++d) {
+            LWCHK(hipMalloc(&h->l2T[d], sizeof(double) * (size_t)h->R * h->Bs));
+            LWCHK(hipMalloc(&h->l2R[d], sizeof(double) * (size_t)h->R * h->Bs));
+            LWCHK(hipMalloc(&h->l2lo[d], sizeof(int32_t) * (size_t)h->R * h->Bs));
+            LWCHK(hipMalloc(&h->l2hi[d], sizeof(int32_t) * (size_t)h->R * h->Bs));
+            LWCHK(hipMalloc(&h->l2s[d], sizeof(FilterScalars) * (size_t)h->R));
+            LWCHK(hipMemset(h->l2lo[d], 0, sizeof(int32_t) * (size_t)h->R * h->Bs));
+            LWCHK(hipMemset(h->l2hi[d], 0, sizeof(int32_t) * (size_t)h->R * h->Bs));
+            LWCHK(hipMemset(h->l2s[d], 0, sizeof(FilterScalars) * (size_t)h->R));
+        }
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level2_plan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)h->lds_bytes_plan));
         LWCHK(hipEventCreate(&h->ev0));
         LWCHK(hipEventCreate(&h->ev1));
         const size_t np = (size_t)h->R * h->Npad, nb = (size_t)h->R * h->Bs;
@@ -1177,8 +1224,10 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
             const uint32_t k[2] = {(uint32_t)h->cfg.seed, (uint32_t)(h->cfg.seed >> 32)};
             LWCHK(hipMemcpy(h->keybuf, k, sizeof(k), hipMemcpyHostToDevice));
         }
-        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage1<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage1<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_big));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_big));
         int rc2 = lw_ensure_capacity(h, 1);
         if (rc2 != SSME_OK) return rc2;
         return lw_reset(h);
@@ -1255,6 +1304,17 @@ int ssme_lw_shard_plan(ssme_lw_handle h, int32_t which, int32_t t, const double*
     if (!h || !tsum_all || !tmax_all || !lo_hi || t < 1 || which < 0 || which > 1) return SSME_ERR_INVALID_ARG;
     if (h->shard_world < 1) return SSME_ERR_STATE;
     LWCHK(hipSetDevice(h->cfg.device));
+    if (h->split_l2) {
+        lw_launch_plan(h, which, t, t, tsum_all, tmax_all, true);
+        LWCHK(hipGetLastError());
+        const int Bl = h->B / h->shard_world;
+        for (int d = 0; d < h->shard_world; ++d) {
+            LWCHK(hipMemcpyAsync(lo_hi + 2 * d, h->l2lo[which] + (size_t)d * Bl, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            LWCHK(hipMemcpyAsync(lo_hi + 2 * d + 1, h->l2hi[which] + (size_t)(d + 1) * Bl - 1, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        }
+        LWCHK(hipStreamSynchronize(h->stream));
+        return SSME_OK;
+    }
     StepArgs a{};                                   // the fields k_shard_plan reads
     a.tsum_in = tsum_all; a.tmax_in = tmax_all;
     a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = 1; a.N = h->N;
@@ -1285,7 +1345,8 @@ int ssme_lw_shard_stage1(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t
     a.win_tile0 = win_tile0; a.th_src_stride = (int64_t)win_tiles * kTile;
     a.xr = xr; a.thr = thr; a.lw1 = lw1; a.cdfA = cdfA; a.tsumA = tsumA; a.tmaxA = tmaxA; a.mom = mom;
     a.anc = anc;
-    hipLaunchKernelGGL(k_lw_stage1, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes, h->stream, a);
+    if (h->split_l2) hipLaunchKernelGGL(k_lw_stage1<true>, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes_big, h->stream, a);
+    else hipLaunchKernelGGL(k_lw_stage1<false>, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes, h->stream, a);
     LWCHK(hipGetLastError());
     return SSME_OK;
 }
@@ -1296,7 +1357,9 @@ int ssme_lw_shard_mid(ssme_lw_handle h, int32_t t, const double* tsumA_all, cons
     LWCHK(hipSetDevice(h->cfg.device));
     LwArgs a = lw_shard_args(h, t);
     a.tsumA = const_cast<double*>(tsumA_all); a.tmaxA = const_cast<double*>(tmaxA_all); a.mom = const_cast<double*>(mom_all);
-    hipLaunchKernelGGL(k_lw_mid, dim3(1), dim3(kThreads), 0, h->stream, a);
+    // split level-2: the plan of the k draw (ssme_lw_shard_plan(which = 1)) must precede this call -- it provides m and S
+    if (h->split_l2) hipLaunchKernelGGL(k_lw_mid<true>, dim3(1), dim3(kThreads), 0, h->stream, a);
+    else hipLaunchKernelGGL(k_lw_mid<false>, dim3(1), dim3(kThreads), 0, h->stream, a);
     LWCHK(hipGetLastError());
     return SSME_OK;
 }
@@ -1315,7 +1378,8 @@ int ssme_lw_shard_stage2(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t
     a.win_tile0 = win_tile0; a.th_src_stride = (int64_t)win_tiles * kTile;
     a.xB = xB; a.thB = thB; a.cdfB = cdfB; a.tsumB = tsumB; a.tmaxB = tmaxB;
     a.kidx = kidx;
-    hipLaunchKernelGGL(k_lw_stage2, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes, h->stream, a);
+    if (h->split_l2) hipLaunchKernelGGL(k_lw_stage2<true>, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes_big, h->stream, a);
+    else hipLaunchKernelGGL(k_lw_stage2<false>, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes, h->stream, a);
     LWCHK(hipGetLastError());
     h->t = t + 1;
     return SSME_OK;
@@ -1327,7 +1391,11 @@ int ssme_lw_shard_finalize(ssme_lw_handle h, int32_t t, const double* tsumB_all,
     LWCHK(hipSetDevice(h->cfg.device));
     LwArgs a = lw_shard_args(h, t);
     a.tsumB = const_cast<double*>(tsumB_all); a.tmaxB = const_cast<double*>(tmaxB_all);
-    hipLaunchKernelGGL(k_lw_finalize, dim3(1), dim3(kThreads), 0, h->stream, a);
+    if (h->split_l2) {
+        lw_launch_plan(h, 0, t + 1, 0, tsumB_all, tmaxB_all, false);
+        hipLaunchKernelGGL(k_lw_finalize<true>, dim3(1), dim3(kThreads), 0, h->stream, a);
+    } else
+        hipLaunchKernelGGL(k_lw_finalize<false>, dim3(1), dim3(kThreads), 0, h->stream, a);
     LWCHK(hipGetLastError());
     LWCHK(hipStreamSynchronize(h->stream));
     return SSME_OK;
@@ -1359,6 +1427,7 @@ int ssme_lw_set_debug(ssme_lw_handle h, int32_t flags) {
         LWCHK(hipMemset(h->kidx, 0, sizeof(uint32_t) * (size_t)h->R * h->Npad));
     }
     h->debug = flags;
+    h->split_l2 = (h->B > kMaxTilesPerFilter || (flags & 4)) ? 1 : ((flags & 8) ? 0 : (h->B > kSplitLevel2Above ? 1 : 0));
     return SSME_OK;
 }
 

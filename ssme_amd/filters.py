@@ -328,8 +328,10 @@ class svol_lw_1_par:
                 msg += " (" + capi.lib().ssme_lw_last_error(self._h).decode() + ")"
             raise SsmeError(status, msg)
 
-    def set_debug(self, on=True):
-        self._chk(capi.lib().ssme_lw_set_debug(self._h, 1 if on else 0))
+    def set_debug(self, on=True, split_level2=None):
+        """Record k / ancestor indices; split_level2: True / False force the level-2 policy (None: split above 512 tiles)."""
+        pol = 0 if split_level2 is None else (4 if split_level2 else 8)
+        self._chk(capi.lib().ssme_lw_set_debug(self._h, (1 if on else 0) | pol))
 
     def reset(self):
         self._chk(capi.lib().ssme_lw_reset(self._h))

@@ -326,8 +326,9 @@ class ShardedLiuWest:
                                              p(self.tilesA[1]), p(self.mom), None))
             self.allA.copy_(self._gather(self.tilesA, 1))
             self.mom_all.copy_(self._gather(self.mom, 0))
-            self._chk(L.ssme_lw_shard_mid(self._h, t, p(self.allA[0]), p(self.allA[1]), p(self.mom_all)))
+            # the plan of the k draw first: with the split level-2 it also provides the (m, S) that mid turns into lse1
             w0, wt, (w_x, w_lw1, w_cdf), w_th = self._windows(1, t, self.allA, [self.xr, self.lw1, self.cdfA], self.thr)
+            self._chk(L.ssme_lw_shard_mid(self._h, t, p(self.allA[0]), p(self.allA[1]), p(self.mom_all)))
             self._chk(L.ssme_lw_shard_stage2(self._h, t, w0, wt, p(w_x), p(w_th), p(w_lw1), p(w_cdf), p(self.allA[0]),
                                              p(self.allA[1]), p(self.xB), p(self.thB), p(self.cdfB), p(self.tilesB[0]),
                                              p(self.tilesB[1]), None))

@@ -710,3 +710,41 @@ def test_level2_policy_by_size_is_result_invariant(sa, spy):
     for ll, per in res[1:]:
         assert_bits_equal(ll, res[0][0], "level-2 policy: log-lik")
         assert_bits_equal(per, res[0][1], "level-2 policy: per-step")
+
+
+@pytest.mark.parametrize("n", [30000, 700 * 2048 - 9])
+def test_liu_west_split_level2_matches_in_kernel_level2(sa, oracle, n):
+    """Liu-West with the level-2 of both draws in k_level2_plan == in-kernel level-2 (and the oracle at the small size)."""
+    T = 5
+    y, z = _lw_series(T, seed=8)
+    outs = []
+    for split in (False, True):
+        g = sa.svol_lw_1_par(0.97, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, n_filters=2, seed=44)
+        g.set_debug(True, split_level2=split)
+        ll = g.run_series(y, z)
+        st = g.state(1, indices=True)
+        outs.append((ll, g.per_step(), st))
+        g.close()
+    (l0, p0, s0), (l1, p1, s1) = outs
+    assert_bits_equal(l0, l1, "LW split level-2: log-lik")
+    assert_bits_equal(p0, p1, "LW split level-2: per-step")
+    for key in ("x", "theta", "thetabar"):
+        assert_bits_equal(s0[key], s1[key], f"LW split level-2: {key}")
+    np.testing.assert_array_equal(s0["kidx"], s1["kidx"])
+    np.testing.assert_array_equal(s0["anc"], s1["anc"])
+    if n <= 30000:
+        o = oracle.LWFilter(n, 44, rep=1, delta=0.97)
+        po = np.array([o.step(y[t], z[t]) for t in range(T)])
+        assert_bits_equal(p1[1], po, "LW split level-2 vs oracle")
+
+
+def test_liu_west_of_more_than_2048_tiles(sa, oracle):
+    n = 2050 * 2048 - 3
+    y, z = _lw_series(3, seed=2)
+    g = sa.svol_lw_1_par(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, seed=6)
+    g.run_series(y, z)
+    per = g.per_step()[0]
+    o = oracle.LWFilter(n, 6, delta=0.99)
+    po = np.array([o.step(y[t], z[t]) for t in range(3)])
+    assert_bits_equal(per, po, "LW N > 2^22 vs oracle")
+    g.close()

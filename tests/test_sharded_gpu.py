@@ -96,12 +96,13 @@ def _run_sharded_lw(tmp_path, world, n, T, seed, delta):
     return [np.load(o) for o in outs]
 
 
-@pytest.mark.parametrize("world,n,delta", [(2, 16384, 0.99), (4, 32768, 0.95), (2, 8192, 1.0)])
+@pytest.mark.parametrize("world,n,delta", [(2, 16384, 0.99), (4, 32768, 0.95), (2, 8192, 1.0),
+                                           (2, 2 * 300 * 2048, 0.99)])          # 600 tiles: split level-2
 def test_sharded_liu_west_is_bit_identical_to_unsharded(tmp_path, spy, world, n, delta):
     """BASELINE.json configs[4] in small: Liu-West filter over G ranks == the unsharded filter (log-likelihoods, particles,
     transformed parameters), two window exchanges and one moment gather per step."""
     import ssme_amd
-    T, seed = 10, 99
+    T, seed = (10 if n < 100000 else 4), 99
     res = _run_sharded_lw(tmp_path, world, n, T, seed, delta)
     y = spy[:T]
     z = np.concatenate([[0.0], y[:-1]])
