@@ -237,12 +237,13 @@ int ssme_lw_last_elapsed_ms(ssme_lw_handle h, float* ms);
 const char* ssme_lw_last_error(ssme_lw_handle h);
 
 /* ---- particle-sharded Liu-West filter: ONE filter of cfg->n_particles particles over `world` GPUs (BASELINE.json configs[4]).
- * Rank g owns B/world consecutive tiles (n_particles a multiple of 2048 world, at most 2^22; n_filters = 1).  Per step the
+ * Rank g owns B/world consecutive tiles (n_particles a multiple of 2048 world, at most 2^25; n_filters = 1).  Per step the
  * host side (ssme_amd/sharded.py, ShardedLiuWest) gathers the tile sums / maxima of the second-stage weights, plans and
  * exchanges windows of (cdfB, x, theta) for the resampling draw (stage 1), gathers the first-stage tile sums / maxima and
  * the 14 moment partials per tile, runs ssme_lw_shard_mid on every rank (theta-bar, Cholesky factor: the moment sums are
  * added in tile order, so every rank gets the unsharded filter's bits), plans and exchanges windows of (cdfA, lw1, x, theta)
- * for the k draw (stage 2).  theta buffers are 4 planes: [4][tiles * 2048].  Bit-identical to ssme_lw_run_series. */
+ * for the k draw (stage 2) -- call ssme_lw_shard_plan(which = 1) BEFORE ssme_lw_shard_mid: above 512 tiles the plan also
+ * provides the first-stage (m, S) that mid turns into the log-sum-exp.  theta buffers are 4 planes: [4][tiles * 2048].  Bit-identical to ssme_lw_run_series. */
 int ssme_lw_shard_create(const ssme_lw_config* cfg, int32_t rank, int32_t world, ssme_lw_handle* out);
 int ssme_lw_set_stream(ssme_lw_handle h, void* hip_stream);
 int ssme_lw_shard_prepare(ssme_lw_handle h, const double* y, const double* z, int32_t T);

@@ -29,6 +29,8 @@ th = {0: [1.0, 0.95, 0.25], 1: [0.9, 0.0, 1.0, -0.1], 2: [0.9, 0.5, 0.7]}[a.mode
 if a.lw:
     zz = np.concatenate([[0.0], y[:-1]])
     g = ssme_amd.svol_lw_1_par(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=a.n, n_filters=a.filters, seed=20260101)
+    if a.split >= 0:
+        g.set_debug(False, split_level2=bool(a.split))
     best = 1e9
     for _ in range(a.passes):
         ll = g.run_series(y, zz)
