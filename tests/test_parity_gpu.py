@@ -748,3 +748,18 @@ def test_liu_west_of_more_than_2048_tiles(sa, oracle):
     po = np.array([o.step(y[t], z[t]) for t in range(3)])
     assert_bits_equal(per, po, "LW N > 2^22 vs oracle")
     g.close()
+
+
+def test_split_level2_with_resampling_schedule(sa, oracle, spy):
+    """resamp_sched = 3 with the split level-2: non-resampling steps carry log-weights, the plan still accounts every step."""
+    y = spy[:14]
+    n, th = 25000, [1.0, 0.95, 0.25]
+    b = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 2, 17, sa.RESAMP_MULTINOMIAL, 3)
+    b.set_debug(False, False, split_level2=True)
+    b.set_params(th)
+    ll = b.run_series(y)
+    o = oracle.Filter(oracle.MODEL_SVOL, n, th, 17, rep=1, resampler=0, resamp_sched=3)
+    lo, po = o.run_series(y)
+    assert_bits_equal([ll[1]], [lo], "split level-2, schedule 3: log-lik")
+    assert_bits_equal(b.per_step()[1], po, "split level-2, schedule 3: per-step")
+    b.close()
