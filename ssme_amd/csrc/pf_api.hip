@@ -31,6 +31,7 @@ struct ssme_pf_s {
     double *l2_T, *l2_R;     // [R][Bs] split level-2 outputs
     int32_t *l2_lo, *l2_hi;
     size_t lds_bytes_big, lds_bytes_plan;
+    int gamma_t0, gamma_rows;   // step API: the Gamma tables hold time indices gamma_t0 .. gamma_t0 + gamma_rows - 1
     int num_cus;             // compute units of the device (priority schedule of the step kernel)
     int small_series;        // 1: one-tile filters run the whole series in one launch (k_filter_series_small)
     int nt;                  // threads per 2048-particle tile of k_filter_step (256, 512, 1024)
@@ -94,6 +95,7 @@ static ModelConst derive(int model, const double* th) {
     return c;
 }
 
+constexpr int kStepGammaChunk = 64;
 static int n_theta_of(int model) { return model == SSME_MODEL_SVOL_LEVERAGE ? 4 : 3; }
 static bool logw_needed(ssme_pf_handle h) { return h->keep_logw || h->cfg.resamp_sched > 1; }
 
@@ -183,9 +185,14 @@ static void launch_gamma(ssme_pf_handle h, int t0, int nT) {
     if (h->cfg.resampler != SSME_RESAMP_MULTINOMIAL) return;
     hipLaunchKernelGGL(k_gamma_draw, dim3((h->B + kThreads - 1) / kThreads, nT, h->R), dim3(kThreads), 0, h->stream,
                        h->gam, h->N, h->B, h->R, t0, (const uint32_t*)h->keybuf, h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA);
-    hipLaunchKernelGGL(k_gamma_prefix, dim3((nT * h->R + kThreads - 1) / kThreads), dim3(kThreads), 0, h->stream,
-                       h->gam, h->pgam, h->gtot, h->B, h->R, nT, t0, (const uint32_t*)h->keybuf, h->cfg.first_filter_id,
-                       (uint32_t)STREAM_RESAMP_EXTRA);
+    if (h->B <= 64)
+        hipLaunchKernelGGL(k_gamma_prefix_rows, dim3((nT * h->R + kThreads - 1) / kThreads), dim3(kThreads), 0, h->stream,
+                           h->gam, h->pgam, h->gtot, h->B, h->R, nT, t0, (const uint32_t*)h->keybuf, h->cfg.first_filter_id,
+                           (uint32_t)STREAM_RESAMP_EXTRA);
+    else
+        hipLaunchKernelGGL(k_gamma_prefix, dim3(nT * h->R), dim3(kThreads), 0, h->stream,
+                           h->gam, h->pgam, h->gtot, h->B, h->R, nT, t0, (const uint32_t*)h->keybuf, h->cfg.first_filter_id,
+                           (uint32_t)STREAM_RESAMP_EXTRA);
 }
 // accounts the log conditional likelihood of step t from the buffers the step wrote (now `cur`)
 // split level-2 of the buffers `cur` holds: for the step t about to run (plan_ranges) or only the accounting of step t-1
@@ -237,16 +244,8 @@ static void enqueue_series_small(ssme_pf_handle h, int T, bool has_z) {
     h->cur = 1;
 }
 
-static int ensure_series_capacity(ssme_pf_handle h, int T) {
-    if (T > h->ycap) {
-        if (h->ybuf) hipFree(h->ybuf);
-        if (h->zbuf) hipFree(h->zbuf);
-        h->ybuf = h->zbuf = nullptr;
-        HIPCHK(hipMalloc(&h->ybuf, sizeof(double) * T));
-        HIPCHK(hipMalloc(&h->zbuf, sizeof(double) * T));
-        h->ycap = T;
-        if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
-    }
+// Gamma tables of the multinomial resampler for T time rows (nothing else moves: the step API grows them on its own)
+static int ensure_gamma_capacity(ssme_pf_handle h, int T) {
     if (h->cfg.resampler == SSME_RESAMP_MULTINOMIAL && T > h->gcap) {
         if (h->gam) hipFree(h->gam);
         if (h->pgam) hipFree(h->pgam);
@@ -258,6 +257,21 @@ static int ensure_series_capacity(ssme_pf_handle h, int T) {
         h->gcap = T;
         if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     }
+    return SSME_OK;
+}
+
+static int ensure_series_capacity(ssme_pf_handle h, int T) {
+    if (T > h->ycap) {
+        if (h->ybuf) hipFree(h->ybuf);
+        if (h->zbuf) hipFree(h->zbuf);
+        h->ybuf = h->zbuf = nullptr;
+        HIPCHK(hipMalloc(&h->ybuf, sizeof(double) * T));
+        HIPCHK(hipMalloc(&h->zbuf, sizeof(double) * T));
+        h->ycap = T;
+        if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+    }
+    int rcg = ensure_gamma_capacity(h, T);
+    if (rcg != SSME_OK) return rcg;
     if (T > h->tcap) {
         if (h->per_step) hipFree(h->per_step);
         h->per_step = nullptr;
@@ -291,6 +305,7 @@ static int do_reset(ssme_pf_handle h) {
     HIPCHK(hipMemcpyAsync(h->scal, sc.data(), sizeof(FilterScalars) * h->R, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));   // sc is a temporary
     h->t = 0; h->cur = 0;
+    h->gamma_rows = 0;                          // tables are redrawn for the new stream / the new series
     return SSME_OK;
 }
 
@@ -607,10 +622,23 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
     if (h->shard_world > 0) return SSME_ERR_STATE;     // sharded handles are driven by ssme_pf_shard_*
     if (!h->params_set) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (h->cfg.resampler == SSME_RESAMP_MULTINOMIAL && h->gcap < kStepGammaChunk) {
+        int rc = ensure_gamma_capacity(h, kStepGammaChunk);
+        if (rc != SSME_OK) return rc;
+    }
     HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (z) HIPCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (h->t > 0 && h->t % h->cfg.resamp_sched == 0) launch_gamma(h, h->t, 1);
-    enqueue_step(h, h->t, 0, 0, z != nullptr, /*finalize_prev=*/false, /*per_step=*/false);
+    // Gamma tables are drawn kStepGammaChunk time steps at a time (data independent), so that the two table launches are paid
+    // once per chunk and not once per filter() call
+    int gi = 0;
+    if (h->cfg.resampler == SSME_RESAMP_MULTINOMIAL) {
+        if (h->t < h->gamma_t0 || h->t >= h->gamma_t0 + h->gamma_rows) {
+            launch_gamma(h, h->t, kStepGammaChunk);
+            h->gamma_t0 = h->t; h->gamma_rows = kStepGammaChunk;
+        }
+        gi = h->t - h->gamma_t0;
+    }
+    enqueue_step(h, h->t, 0, gi, z != nullptr, /*finalize_prev=*/false, /*per_step=*/false);
     launch_kf(h, h->t, false);
     HIPCHK(hipGetLastError());
     h->t += 1;
@@ -1016,6 +1044,7 @@ struct ssme_lw_s {
     int shard_rank, shard_world;     // particle-sharded filter (world = 0: unsharded)
     hipStream_t own_stream;
     int32_t* plan_dev;
+    int gamma_t0, gamma_rows;        // step API: the Gamma tables hold time indices gamma_t0 .. gamma_t0 + gamma_rows - 1
     int split_l2;                    // level-2 of both draws by k_level2_plan (more than 512 tiles)
     double *l2T[2], *l2R[2];         // [draw: 0 resampling (B), 1 k draw (A)][R][Bs]
     int32_t *l2lo[2], *l2hi[2];
@@ -1052,6 +1081,18 @@ static LwArgs lw_args(ssme_lw_handle h) {
     return a;
 }
 
+static int lw_ensure_gamma(ssme_lw_handle h, int T) {
+    if (T > h->gcap) {
+        double** tabs[] = {&h->gamA, &h->pgamA, &h->gtotA, &h->gamB, &h->pgamB, &h->gtotB};
+        for (auto t : tabs) { if (*t) hipFree(*t); *t = nullptr; }
+        const size_t nb = sizeof(double) * (size_t)T * h->R * h->B, nr = sizeof(double) * (size_t)T * h->R;
+        LWCHK(hipMalloc(&h->gamA, nb)); LWCHK(hipMalloc(&h->pgamA, nb)); LWCHK(hipMalloc(&h->gtotA, nr));
+        LWCHK(hipMalloc(&h->gamB, nb)); LWCHK(hipMalloc(&h->pgamB, nb)); LWCHK(hipMalloc(&h->gtotB, nr));
+        h->gcap = T;
+    }
+    return SSME_OK;
+}
+
 static int lw_ensure_capacity(ssme_lw_handle h, int T) {
     if (T > h->ycap) {
         if (h->ybuf) hipFree(h->ybuf);
@@ -1061,14 +1102,7 @@ static int lw_ensure_capacity(ssme_lw_handle h, int T) {
         LWCHK(hipMemset(h->zbuf, 0, sizeof(double) * T));
         h->ycap = T;
     }
-    if (T > h->gcap) {
-        double** tabs[] = {&h->gamA, &h->pgamA, &h->gtotA, &h->gamB, &h->pgamB, &h->gtotB};
-        for (auto t : tabs) { if (*t) hipFree(*t); *t = nullptr; }
-        const size_t nb = sizeof(double) * (size_t)T * h->R * h->B, nr = sizeof(double) * (size_t)T * h->R;
-        LWCHK(hipMalloc(&h->gamA, nb)); LWCHK(hipMalloc(&h->pgamA, nb)); LWCHK(hipMalloc(&h->gtotA, nr));
-        LWCHK(hipMalloc(&h->gamB, nb)); LWCHK(hipMalloc(&h->pgamB, nb)); LWCHK(hipMalloc(&h->gtotB, nr));
-        h->gcap = T;
-    }
+    { int rcg = lw_ensure_gamma(h, T); if (rcg != SSME_OK) return rcg; }
     if (T > h->tcap) {
         if (h->per_step) hipFree(h->per_step);
         LWCHK(hipMalloc(&h->per_step, sizeof(double) * (size_t)T * h->R));
@@ -1080,18 +1114,23 @@ static int lw_ensure_capacity(ssme_lw_handle h, int T) {
 // Gamma tables of both draws for time indices t0 .. t0+nT-1 into rows 0 .. nT-1
 static void lw_launch_gamma(ssme_lw_handle h, int t0, int nT) {
     const uint32_t* kp = h->keybuf;
-    const dim3 g1((h->B + kThreads - 1) / kThreads, nT, h->R), g2((nT * h->R + kThreads - 1) / kThreads);
+    const dim3 g1((h->B + kThreads - 1) / kThreads, nT, h->R);
+    const bool rows = h->B <= 64;                    // short rows: one thread per row; else one workgroup per row
+    const dim3 g2(rows ? (nT * h->R + kThreads - 1) / kThreads : nT * h->R);
+    auto prefix = [&](double* gam, double* pgam, double* gtot, uint32_t extra) {
+        if (rows) hipLaunchKernelGGL(k_gamma_prefix_rows, g2, dim3(kThreads), 0, h->stream, gam, pgam, gtot, h->B, h->R, nT, t0, kp,
+                                     h->cfg.first_filter_id, extra);
+        else hipLaunchKernelGGL(k_gamma_prefix, g2, dim3(kThreads), 0, h->stream, gam, pgam, gtot, h->B, h->R, nT, t0, kp,
+                                h->cfg.first_filter_id, extra);
+    };
     hipLaunchKernelGGL(k_gamma_draw, g1, dim3(kThreads), 0, h->stream, h->gamB, h->N, h->B, h->R, t0, kp,
                        h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA);
-    hipLaunchKernelGGL(k_gamma_prefix, g2, dim3(kThreads), 0, h->stream, h->gamB, h->pgamB, h->gtotB, h->B, h->R, nT, t0, kp,
-                       h->cfg.first_filter_id, (uint32_t)STREAM_RESAMP_EXTRA);
+    prefix(h->gamB, h->pgamB, h->gtotB, (uint32_t)STREAM_RESAMP_EXTRA);
     hipLaunchKernelGGL(k_gamma_draw, g1, dim3(kThreads), 0, h->stream, h->gamA, h->N, h->B, h->R, t0, kp,
                        h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA_K);
-    hipLaunchKernelGGL(k_gamma_prefix, g2, dim3(kThreads), 0, h->stream, h->gamA, h->pgamA, h->gtotA, h->B, h->R, nT, t0, kp,
-                       h->cfg.first_filter_id, (uint32_t)STREAM_LW_K_EXTRA);
+    prefix(h->gamA, h->pgamA, h->gtotA, (uint32_t)STREAM_LW_K_EXTRA);
 }
 
-// split level-2 of one draw (0: resampling draw over the second-stage weights, 1: k draw over the first-stage weights)
 static void lw_launch_plan(ssme_lw_handle h, int draw, int t, int gi, const double* tsum, const double* tmax, bool ranges) {
     StepArgs a{};
     a.tsum_in = tsum; a.tmax_in = tmax;
@@ -1141,6 +1180,7 @@ static int lw_reset(ssme_lw_handle h) {
     LWCHK(hipMemcpyAsync(h->scal, sc.data(), sizeof(LwScalars) * h->R, hipMemcpyHostToDevice, h->stream));
     LWCHK(hipStreamSynchronize(h->stream));
     h->t = 0;
+    h->gamma_rows = 0;
     return SSME_OK;
 }
 
@@ -1435,10 +1475,21 @@ int ssme_lw_step(ssme_lw_handle h, const double* y, const double* z, double* out
     if (!h || !y) return SSME_ERR_INVALID_ARG;
     LWCHK(hipSetDevice(h->cfg.device));
     const double z0 = z ? *z : 0.0;
+    if (h->gcap < kStepGammaChunk) {
+        int rc = lw_ensure_gamma(h, kStepGammaChunk);
+        if (rc != SSME_OK) return rc;
+    }
     LWCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double), hipMemcpyHostToDevice, h->stream));
     LWCHK(hipMemcpyAsync(h->zbuf, &z0, sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (h->t > 0) lw_launch_gamma(h, h->t, 1);
-    lw_enqueue_step(h, h->t, 0, 0, false, /*finalize_prev=*/false);
+    int gi = 0;
+    if (h->t > 0) {                              // Gamma tables of both draws, kStepGammaChunk steps at a time
+        if (h->t < h->gamma_t0 || h->t >= h->gamma_t0 + h->gamma_rows) {
+            lw_launch_gamma(h, h->t, kStepGammaChunk);
+            h->gamma_t0 = h->t; h->gamma_rows = kStepGammaChunk;
+        }
+        gi = h->t - h->gamma_t0;
+    }
+    lw_enqueue_step(h, h->t, 0, gi, false, /*finalize_prev=*/false);
     lw_enqueue_finalize(h, h->t, false);          // the step API accounts each step right away
     LWCHK(hipGetLastError());
     std::vector<LwScalars> sc(h->R);

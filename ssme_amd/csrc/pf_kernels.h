@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(512) void k_shard_plan(const StepArgs a, int world,
 
 // ---------------------------------------------------------------------------------------
 // Gamma tables for the multinomial resampler (data independent: seed, t, filter, tile only).
-// k_gamma_draw: grid = (ceil(B/256), nT, R).  k_gamma_prefix: one thread per (ti, r).
+// k_gamma_draw: grid = (ceil(B/256), nT, R).  k_gamma_prefix: one workgroup per (ti, r).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_gamma_draw(double* gam, int N, int B, int R, int t0, const uint32_t* keyp,
                                                          uint32_t first_filter, uint32_t gamma_stream) {
@@ -1054,9 +1054,41 @@ __global__ __launch_bounds__(kThreads) void k_gamma_draw(double* gam, int N, int
                                                    gamma_stream);
 }
 
+// One workgroup per (ti, r) row.  The exclusive prefix is the SEQUENTIAL sum run = run + g[b] (its rounding is part of
+// the specification), so one lane adds; but the row is brought into LDS by all 256 threads first and the prefixes leave
+// through LDS as well, in chunks of 2048 tiles: the adding lane then sees LDS latency instead of one dependent global
+// load per tile (a single filter step of the step API spent ~100 us here at 512 tiles).
 __global__ __launch_bounds__(kThreads) void k_gamma_prefix(const double* gam, double* pgam, double* gtot, int B, int R,
                                                            int nT, int t0, const uint32_t* keyp, uint32_t first_filter,
                                                            uint32_t extra_stream) {
+    __shared__ double buf[2048];
+    const int id = blockIdx.x, tid = threadIdx.x;
+    const int ti = id / R, r = id % R;
+    const double* g = gam + (size_t)id * B;
+    double* p = pgam + (size_t)id * B;
+    double run = 0.0;                                  // meaningful in thread 0 only
+    for (int c0 = 0; c0 < B; c0 += 2048) {
+        const int n = (B - c0) < 2048 ? (B - c0) : 2048;
+        for (int j = tid; j < n; j += kThreads) buf[j] = g[c0 + j];
+        __syncthreads();
+        if (tid == 0) {
+            for (int j = 0; j < n; ++j) { const double v = buf[j]; buf[j] = run; run = run + v; }
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += kThreads) p[c0 + j] = buf[j];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t key0 = keyp[0], key1 = keyp[1];
+        const u32x4 ox = philox4x32_10(0u, (uint32_t)(t0 + ti), first_filter + (uint32_t)r, extra_stream, key0, key1);
+        gtot[id] = run + (-dlog_pn(u01_oc(ox.v0, ox.v1)));
+    }
+}
+
+// the same for short rows (few tiles per filter, many filters): one thread per (ti, r)
+__global__ __launch_bounds__(kThreads) void k_gamma_prefix_rows(const double* gam, double* pgam, double* gtot, int B, int R,
+                                                                int nT, int t0, const uint32_t* keyp, uint32_t first_filter,
+                                                                uint32_t extra_stream) {
     const uint32_t key0 = keyp[0], key1 = keyp[1];
     const int id = blockIdx.x * kThreads + threadIdx.x;
     if (id >= nT * R) return;
