@@ -31,6 +31,7 @@ struct ssme_pf_s {
     double *l2_T, *l2_R;     // [R][Bs] split level-2 outputs
     int32_t *l2_lo, *l2_hi;
     size_t lds_bytes_big, lds_bytes_plan;
+    double* pin;             // pinned host staging of the step API: [0] y, [1] z, [2 .. 2+R) log conditional likelihoods
     int gamma_t0, gamma_rows;   // step API: the Gamma tables hold time indices gamma_t0 .. gamma_t0 + gamma_rows - 1
     int num_cus;             // compute units of the device (priority schedule of the step kernel)
     int small_series;        // 1: one-tile filters run the whole series in one launch (k_filter_series_small)
@@ -392,6 +393,7 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
         HIPCHK(hipMalloc(&h->mc, sizeof(ModelConst) * h->R));
         HIPCHK(hipMalloc(&h->scratchR, sizeof(double) * h->R));
         HIPCHK(hipMalloc(&h->keybuf, sizeof(uint32_t) * 2));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pin), sizeof(double) * (2 + (size_t)h->R), hipHostMallocDefault));
         int rc2 = upload_key(h);
         if (rc2 != SSME_OK) return rc2;
         if (h->shard_world > 0) return ensure_series_capacity(h, 1);
@@ -413,6 +415,7 @@ int ssme_pf_destroy(ssme_pf_handle h) {
     void* bufs[] = {h->x[0], h->x[1], h->cdf[0], h->cdf[1], h->tsum[0], h->tsum[1], h->tmax[0], h->tmax[1], h->logw,
                     h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_lo, h->l2_hi};
     for (void* p : bufs) if (p) hipFree(p);
+    if (h->pin) hipHostFree(h->pin);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -626,8 +629,10 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
         int rc = ensure_gamma_capacity(h, kStepGammaChunk);
         if (rc != SSME_OK) return rc;
     }
-    HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (z) HIPCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // y, z and the results travel through pinned memory: pageable copies cost a staging round trip each
+    h->pin[0] = *y; h->pin[1] = z ? *z : 0.0;
+    HIPCHK(hipMemcpyAsync(h->ybuf, h->pin, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (z) HIPCHK(hipMemcpyAsync(h->zbuf, h->pin + 1, sizeof(double), hipMemcpyHostToDevice, h->stream));
     // Gamma tables are drawn kStepGammaChunk time steps at a time (data independent), so that the two table launches are paid
     // once per chunk and not once per filter() call
     int gi = 0;
@@ -643,10 +648,11 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
     HIPCHK(hipGetLastError());
     h->t += 1;
     if (out) {
-        std::vector<FilterScalars> sc(h->R);
-        HIPCHK(hipMemcpyAsync(sc.data(), h->scal, sizeof(FilterScalars) * h->R, hipMemcpyDeviceToHost, h->stream));
+        // one strided copy of the R last_ll fields into pinned memory
+        HIPCHK(hipMemcpy2DAsync(h->pin + 2, sizeof(double), &h->scal[0].last_ll, sizeof(FilterScalars), sizeof(double), (size_t)h->R,
+                                hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        for (int r = 0; r < h->R; ++r) out[r] = sc[r].last_ll;
+        for (int r = 0; r < h->R; ++r) out[r] = h->pin[2 + r];
     } else {
         HIPCHK(hipStreamSynchronize(h->stream));
     }
