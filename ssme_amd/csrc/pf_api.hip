@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -31,6 +32,7 @@ struct ssme_pf_s {
     double *l2_T, *l2_R;     // [R][Bs] split level-2 outputs
     int32_t *l2_lo, *l2_hi;
     size_t lds_bytes_big, lds_bytes_plan;
+    double* yz_step;         // device [2]: y and z of the step API, uploaded by ONE copy
     double* pin;             // pinned host staging of the step API: [0] y, [1] z, [2 .. 2+R) log conditional likelihoods
     int gamma_t0, gamma_rows;   // step API: the Gamma tables hold time indices gamma_t0 .. gamma_t0 + gamma_rows - 1
     int num_cus;             // compute units of the device (priority schedule of the step kernel)
@@ -64,6 +66,18 @@ static int fail(ssme_pf_handle h, int code, const char* what, hipError_t e) {
     return code;
 }
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, SSME_ERR_HIP, #call, e_); } while (0)
+
+// Wait for a stream with the latency of a poll: hipStreamSynchronize spins only briefly and then sleeps on an interrupt,
+// which adds ~200 us to a filter() call whose kernels take longer than that window (measured: 512 filters x 2^14
+// particles, 146 vs 420 us per call).  Poll for up to ~5 ms, then fall back to the blocking wait.
+static hipError_t wait_stream_low_latency(hipStream_t s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q != hipErrorNotReady) return q;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) return hipStreamSynchronize(s);
+    }
+}
 
 static int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 static int ceil_log2(int n) { int k = 0; while ((1ll << k) < n) ++k; return k; }
@@ -99,6 +113,12 @@ static ModelConst derive(int model, const double* th) {
 constexpr int kStepGammaChunk = 64;
 static int n_theta_of(int model) { return model == SSME_MODEL_SVOL_LEVERAGE ? 4 : 3; }
 static bool logw_needed(ssme_pf_handle h) { return h->keep_logw || h->cfg.resamp_sched > 1; }
+
+// the R log conditional likelihoods of the last step, contiguous (the step API returns them through one small copy)
+__global__ void k_collect_last_ll(const FilterScalars* scal, double* out, int R) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) out[r] = scal[r].last_ll;
+}
 
 // arguments of the step that reads buffers `cur` and writes `cur ^ 1`
 static StepArgs step_args(ssme_pf_handle h) {
@@ -212,9 +232,11 @@ static void launch_kf(ssme_pf_handle h, int t, bool record_per_step) {
 }
 
 // enqueue one filter step at time index t reading y[yi] and gamma-table row gi
-static void enqueue_step(ssme_pf_handle h, int t, int yi, int gi, bool has_z, bool finalize_prev, bool record_per_step) {
+static void enqueue_step(ssme_pf_handle h, int t, int yi, int gi, bool has_z, bool finalize_prev, bool record_per_step,
+                         bool from_step_staging = false) {
     StepArgs a = step_args(h);
     a.z = has_z ? h->zbuf : nullptr;
+    if (from_step_staging) { a.y = h->yz_step; a.z = has_z ? h->yz_step + 1 : nullptr; }
     a.per_step = record_per_step ? h->per_step : nullptr;
     a.t = t; a.yi = yi; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
     if (h->split_l2 && t > 0) launch_plan(h, t, gi, true, finalize_prev, record_per_step);
@@ -393,6 +415,7 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
         HIPCHK(hipMalloc(&h->mc, sizeof(ModelConst) * h->R));
         HIPCHK(hipMalloc(&h->scratchR, sizeof(double) * h->R));
         HIPCHK(hipMalloc(&h->keybuf, sizeof(uint32_t) * 2));
+        HIPCHK(hipMalloc(&h->yz_step, sizeof(double) * 2));
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pin), sizeof(double) * (2 + (size_t)h->R), hipHostMallocDefault));
         int rc2 = upload_key(h);
         if (rc2 != SSME_OK) return rc2;
@@ -413,7 +436,7 @@ int ssme_pf_destroy(ssme_pf_handle h) {
     h->stream = h->own_stream;
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     void* bufs[] = {h->x[0], h->x[1], h->cdf[0], h->cdf[1], h->tsum[0], h->tsum[1], h->tmax[0], h->tmax[1], h->logw,
-                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_lo, h->l2_hi};
+                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_lo, h->l2_hi, h->yz_step};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->pin) hipHostFree(h->pin);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -631,8 +654,7 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
     }
     // y, z and the results travel through pinned memory: pageable copies cost a staging round trip each
     h->pin[0] = *y; h->pin[1] = z ? *z : 0.0;
-    HIPCHK(hipMemcpyAsync(h->ybuf, h->pin, sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (z) HIPCHK(hipMemcpyAsync(h->zbuf, h->pin + 1, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->yz_step, h->pin, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     // Gamma tables are drawn kStepGammaChunk time steps at a time (data independent), so that the two table launches are paid
     // once per chunk and not once per filter() call
     int gi = 0;
@@ -643,18 +665,17 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
         }
         gi = h->t - h->gamma_t0;
     }
-    enqueue_step(h, h->t, 0, gi, z != nullptr, /*finalize_prev=*/false, /*per_step=*/false);
+    enqueue_step(h, h->t, 0, gi, z != nullptr, /*finalize_prev=*/false, /*per_step=*/false, /*from_step_staging=*/true);
     launch_kf(h, h->t, false);
     HIPCHK(hipGetLastError());
     h->t += 1;
     if (out) {
-        // one strided copy of the R last_ll fields into pinned memory
-        HIPCHK(hipMemcpy2DAsync(h->pin + 2, sizeof(double), &h->scal[0].last_ll, sizeof(FilterScalars), sizeof(double), (size_t)h->R,
-                                hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        hipLaunchKernelGGL(k_collect_last_ll, dim3((h->R + 255) / 256), dim3(256), 0, h->stream, (const FilterScalars*)h->scal, h->scratchR, h->R);
+        HIPCHK(hipMemcpyAsync(h->pin + 2, h->scratchR, sizeof(double) * h->R, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(wait_stream_low_latency(h->stream));
         for (int r = 0; r < h->R; ++r) out[r] = h->pin[2 + r];
     } else {
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(wait_stream_low_latency(h->stream));
     }
     return SSME_OK;
 }
@@ -1500,7 +1521,7 @@ int ssme_lw_step(ssme_lw_handle h, const double* y, const double* z, double* out
     LWCHK(hipGetLastError());
     std::vector<LwScalars> sc(h->R);
     LWCHK(hipMemcpyAsync(sc.data(), h->scal, sizeof(LwScalars) * h->R, hipMemcpyDeviceToHost, h->stream));
-    LWCHK(hipStreamSynchronize(h->stream));
+    LWCHK(wait_stream_low_latency(h->stream));
     if (out) for (int r = 0; r < h->R; ++r) out[r] = sc[r].last_ll;
     h->t += 1;
     return SSME_OK;
