@@ -69,8 +69,9 @@ __device__ __forceinline__ double tr_inv(int kind, double tp) {
     if (kind == TR_LOG) return dexp(tp);
     const double t = dexp((tp >= 0.0) ? -tp : tp);
     const double den = 1.0 + t;
-    if (kind == TR_LOGIT) return (tp >= 0.0) ? 1.0 / den : t / den;
-    return (tp >= 0.0) ? 2.0 / den - 1.0 : 1.0 - 2.0 / den;
+    if (kind == TR_LOGIT) return ((tp >= 0.0) ? 1.0 : t) / den;       // one division: the numerator is selected first
+    const double q = 2.0 / den;
+    return (tp >= 0.0) ? q - 1.0 : 1.0 - q;
 }
 __device__ __forceinline__ double tr_fwd(int kind, double p) {
     switch (kind) {
