@@ -763,3 +763,58 @@ def test_split_level2_with_resampling_schedule(sa, oracle, spy):
     assert_bits_equal([ll[1]], [lo], "split level-2, schedule 3: log-lik")
     assert_bits_equal(b.per_step()[1], po, "split level-2, schedule 3: per-step")
     b.close()
+
+
+def test_randomized_configurations_against_oracle(sa, oracle, spy):
+    """A deterministic sweep of 36 mixed configurations (sizes around tile boundaries, several filters, all resamplers and
+    models, resampling schedules, both level-2 policies, both series paths): per-step log-likelihoods bit-exact."""
+    rng = np.random.default_rng(20261004)
+    sizes = [1, 3, 255, 256, 2047, 2048, 2049, 4095, 4097, 6000, 10240, 12289, 20481]
+    thetas = {0: [1.0, 0.95, 0.25], 1: [0.9, 0.0, 1.0, -0.1], 2: [0.9, 0.5, 0.7]}
+    for case in range(36):
+        model = int(rng.integers(0, 3))
+        n = int(sizes[rng.integers(0, len(sizes))])
+        r = int(rng.integers(1, 5))
+        rs = int(rng.integers(0, 4))
+        sched = int(rng.choice([1, 1, 1, 2, 5]))
+        T = int(rng.integers(2, 12))
+        seed = int(rng.integers(1, 1 << 40))
+        split = [None, True, False][int(rng.integers(0, 3))]
+        small = bool(rng.integers(0, 2))
+        y = spy[case:case + T]
+        z = np.concatenate([[0.0], y[:-1]]) if model == 1 else None
+        b = sa.ParticleFilterBank(model, n, r, seed, rs, sched)
+        b.set_small_series(small)
+        b.set_debug(False, False, split_level2=split)
+        b.set_params(thetas[model])
+        ll = b.run_series(y, z)
+        per = b.per_step()
+        rep = int(rng.integers(0, r))
+        o = oracle.Filter(model, n, thetas[model], seed, rep=rep, resampler=rs, resamp_sched=sched)
+        lo, po = o.run_series(y, z)
+        what = f"case {case}: model {model} N {n} R {r} rs {rs} sched {sched} T {T} split {split} small {small}"
+        assert_bits_equal(per[rep], po, what)
+        assert_bits_equal([ll[rep]], [lo], what)
+        b.close()
+
+
+def test_randomized_liu_west_configurations_against_oracle(sa, oracle):
+    rng = np.random.default_rng(4)
+    sizes = [2, 100, 2047, 2048, 2049, 4100, 9000, 12289]
+    for case in range(14):
+        n = int(sizes[rng.integers(0, len(sizes))])
+        r = int(rng.integers(1, 4))
+        delta = float(rng.choice([0.9, 0.95, 0.99, 1.0]))
+        T = int(rng.integers(2, 8))
+        seed = int(rng.integers(1, 1 << 40))
+        split = [None, True, False][int(rng.integers(0, 3))]
+        y, z = _lw_series(T, seed=case)
+        g = sa.svol_lw_1_par(delta, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, n_filters=r, seed=seed)
+        g.set_debug(False, split_level2=split)
+        g.run_series(y, z)
+        per = g.per_step()
+        rep = int(rng.integers(0, r))
+        o = oracle.LWFilter(n, seed, rep=rep, delta=delta)
+        po = np.array([o.step(y[t], z[t]) for t in range(T)])
+        assert_bits_equal(per[rep], po, f"LW case {case}: N {n} R {r} delta {delta} T {T} split {split}")
+        g.close()
