@@ -180,6 +180,8 @@ int ssme_pf_test_gamma(int32_t device, uint64_t seed, uint32_t rep, int32_t t, d
  * The level-2 arithmetic, the RNG counters (global particle index) and the Gamma tables (global tile id) are those of
  * the unsharded filter, so a sharded run is bit-identical to ssme_pf_run_series with the same N and seed.
  * Buffers are the caller's device pointers; all launches go to the stream given to ssme_pf_set_stream.
+ * Reference counterpart: none (the reference is single-process); the semantics reproduced are those of BSFilter::filter
+ * driven by the log_like_eval loop (example/estimate_univ_svol.h:121-127), the decomposition is SURVEY.md section 8e's.
  * ============================================================================================ */
 int ssme_pf_shard_create(const ssme_pf_config* cfg, int32_t rank, int32_t world, ssme_pf_handle* out);
 /* Launch on the caller's HIP stream (hipStream_t as void*; NULL = the handle's own stream). */
