@@ -416,7 +416,7 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
         HIPCHK(hipMalloc(&h->scratchR, sizeof(double) * h->R));
         HIPCHK(hipMalloc(&h->keybuf, sizeof(uint32_t) * 2));
         HIPCHK(hipMalloc(&h->yz_step, sizeof(double) * 2));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pin), sizeof(double) * (2 + (size_t)h->R), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pin), sizeof(double) * (2 + (size_t)h->R + 64), hipHostMallocDefault));   // + 128 ints for the shard plan
         int rc2 = upload_key(h);
         if (rc2 != SSME_OK) return rc2;
         if (h->shard_world > 0) return ensure_series_capacity(h, 1);
@@ -508,21 +508,25 @@ int ssme_pf_shard_plan(ssme_pf_handle h, const double* tsum_all, const double* t
         HIPCHK(hipGetLastError());
         const int Bl = h->B / h->shard_world;
         const bool sorted = h->cfg.resampler != SSME_RESAMP_MULTINOMIAL_IID;
+        int32_t* stage = reinterpret_cast<int32_t*>(h->pin + 2 + h->R);        // pinned
         for (int d = 0; d < h->shard_world; ++d) {
-            lo_hi[2 * d] = 0; lo_hi[2 * d + 1] = h->B - 1;
+            stage[2 * d] = 0; stage[2 * d + 1] = h->B - 1;
             if (sorted) {
-                HIPCHK(hipMemcpyAsync(lo_hi + 2 * d, h->l2_lo + (size_t)d * Bl, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(hipMemcpyAsync(lo_hi + 2 * d + 1, h->l2_hi + (size_t)(d + 1) * Bl - 1, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipMemcpyAsync(stage + 2 * d, h->l2_lo + (size_t)d * Bl, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipMemcpyAsync(stage + 2 * d + 1, h->l2_hi + (size_t)(d + 1) * Bl - 1, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
             }
         }
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(wait_stream_low_latency(h->stream));
+        for (int d = 0; d < 2 * h->shard_world; ++d) lo_hi[d] = stage[d];
         return SSME_OK;
     }
     hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(512), sizeof(double) * (h->Bpow2 < 2 ? 2 : h->Bpow2), h->stream, a,
                        h->shard_world, h->plan_dev);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(lo_hi, h->plan_dev, sizeof(int32_t) * 2 * h->shard_world, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    int32_t* stage = reinterpret_cast<int32_t*>(h->pin + 2 + h->R);            // pinned
+    HIPCHK(hipMemcpyAsync(stage, h->plan_dev, sizeof(int32_t) * 2 * h->shard_world, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(wait_stream_low_latency(h->stream));
+    for (int d = 0; d < 2 * h->shard_world; ++d) lo_hi[d] = stage[d];
     return SSME_OK;
 }
 

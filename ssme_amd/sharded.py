@@ -87,6 +87,63 @@ def exchange_tiles(local, my_first_tile, sends, recvs, rank, group=None, stage_t
     return window.to(local.device) if stage_through_host else window
 
 
+class HaloBuffer:
+    """This rank's tiles with room for neighbours' tiles on both sides: [margin | own tiles | margin] rows of W doubles.
+
+    The step kernels write the rank's output tiles straight into the middle and read their source window [lo, hi] from the
+    same buffer, so the rank's own tiles are never copied: only the halo tiles that other ranks own travel.  A window that
+    does not fit the margins (very unbalanced weights) falls back to `exchange_tiles` (a freshly assembled window)."""
+
+    def __init__(self, tiles, width, margin, device, dtype):
+        import torch
+        self.tiles, self.width, self.margin = tiles, width, margin
+        self.buf = torch.zeros((tiles + 2 * margin, width), dtype=dtype, device=device)
+
+    def own(self):
+        return self.buf[self.margin:self.margin + self.tiles]
+
+    def fits(self, lo, hi, tile0):
+        return tile0 - lo <= self.margin and hi - (tile0 + self.tiles - 1) <= self.margin
+
+    def rows(self, first, count, tile0):
+        """View of global tiles first .. first+count-1 (own or halo)."""
+        a = self.margin + (first - tile0)
+        return self.buf[a:a + count]
+
+
+def exchange_halos(bufs, tile0, plan, tiles_per_rank, rank, group=None, stage_through_host=False):
+    """One grouped exchange for several HaloBuffers that share a plan: every piece another rank owns is received straight
+    into the margin rows, every piece another rank needs is sent from the own rows.  Returns (win_tile0, win_tiles) or
+    None if the window does not fit the margins."""
+    import torch.distributed as dist
+    lo, hi = plan[rank]
+    if not all(b.fits(lo, hi, tile0) for b in bufs):
+        return None
+    sends, recvs = exchange_plan(plan, tiles_per_rank, rank)
+    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    ops, staged = [], []
+    for b in bufs:
+        for s, (first, cnt) in enumerate(recvs):
+            if cnt and s != rank:
+                dst = b.rows(first, cnt, tile0)
+                if stage_through_host:
+                    tmp = dst.cpu()
+                    staged.append((dst, tmp))
+                    ops.append(dist.P2POp(dist.irecv, tmp, peer(s), group))
+                else:
+                    ops.append(dist.P2POp(dist.irecv, dst, peer(s), group))
+        for d, (first, cnt) in enumerate(sends):
+            if cnt and d != rank:
+                src = b.rows(first, cnt, tile0)
+                ops.append(dist.P2POp(dist.isend, src.cpu() if stage_through_host else src, peer(d), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for dst, tmp in staged:
+        dst.copy_(tmp)
+    return lo, hi - lo + 1
+
+
 class ShardedParticleFilter:
     """Bootstrap filter with its N particles sharded over the ranks of a torch.distributed group."""
 
@@ -113,8 +170,11 @@ class ShardedParticleFilter:
         self._stream = torch.cuda.Stream(self.device)
         self._chk(capi.lib().ssme_pf_set_stream(self._h, C.c_void_p(self._stream.cuda_stream)))
         f64 = dict(dtype=torch.float64, device=self.device)
-        self.x = torch.zeros((self.Bl, TILE), **f64)            # this rank's particles after the last step
-        self.cdf = torch.zeros((self.Bl, TILE), **f64)          # tile-local integer cdf (integers < 2^53 in fp64)
+        # particles and tile-local integer cdf (integers < 2^53 in fp64) after the last step: ping-pong halo buffers
+        margin = min(self.B - self.Bl, max(2, self.Bl // 2)) if self.world > 1 else 0
+        self._hx = [HaloBuffer(self.Bl, TILE, margin, self.device, torch.float64) for _ in range(2)]
+        self._hc = [HaloBuffer(self.Bl, TILE, margin, self.device, torch.float64) for _ in range(2)]
+        self._cur = 0
         self.tiles_loc = torch.zeros((2, self.Bl), **f64)       # row 0: tile sums, row 1: tile maxima
         self.tiles_all = torch.zeros((2, self.B), **f64)
         self.anc = None
@@ -173,10 +233,11 @@ class ShardedParticleFilter:
         L = capi.lib()
         self._chk(L.ssme_pf_shard_prepare(self._h, capi.dptr(yv), capi.dptr(zv), T))
         ts, tm = self.tiles_all[0], self.tiles_all[1]
-        x_new, cdf_new = torch.empty_like(self.x), torch.empty_like(self.cdf)
         lo_hi = (C.c_int32 * (2 * self.world))()
         self.exchanged_tiles = 0
         for t in range(T):
+            hx, hc = self._hx[self._cur], self._hc[self._cur]            # sources: the last step's outputs (+ halos)
+            ox, oc = self._hx[self._cur ^ 1], self._hc[self._cur ^ 1]    # this step's outputs go to the other pair
             if t == 0:
                 xw = cw = None
                 win0 = 0
@@ -184,18 +245,22 @@ class ShardedParticleFilter:
                 self._gather_tiles()
                 self._chk(L.ssme_pf_shard_plan(self._h, self._ptr(ts), self._ptr(tm), t, lo_hi))
                 plan = [(lo_hi[2 * g], lo_hi[2 * g + 1]) for g in range(self.world)]
-                sends, recvs = exchange_plan(plan, self.Bl, self.rank)
-                self.exchanged_tiles += sum(c for s, (_, c) in enumerate(recvs) if s != self.rank)
-                cw = exchange_tiles(self.cdf, self.tile0, sends, recvs, self.rank, self.group, self.stage)
-                xw = exchange_tiles(self.x, self.tile0, sends, recvs, self.rank, self.group, self.stage)
-                win0 = plan[self.rank][0]
+                got = exchange_halos([hc, hx], self.tile0, plan, self.Bl, self.rank, self.group, self.stage)
+                if got is None:                                          # window wider than the margins: assemble it
+                    sends, recvs = exchange_plan(plan, self.Bl, self.rank)
+                    cw = exchange_tiles(hc.own(), self.tile0, sends, recvs, self.rank, self.group, self.stage)
+                    xw = exchange_tiles(hx.own(), self.tile0, sends, recvs, self.rank, self.group, self.stage)
+                    win0 = plan[self.rank][0]
+                else:
+                    win0, wt = got
+                    cw, xw = hc.rows(win0, wt, self.tile0), hx.rows(win0, wt, self.tile0)
+                lo_r, hi_r = plan[self.rank]
+                self.exchanged_tiles += max(0, min(hi_r + 1, self.tile0) - lo_r) + max(0, hi_r - max(lo_r - 1, self.tile0 + self.Bl - 1))
             self._chk(L.ssme_pf_shard_step(
                 self._h, t, None if xw is None else self._ptr(xw), None if cw is None else self._ptr(cw), win0,
-                self._ptr(ts), self._ptr(tm), self._ptr(x_new), self._ptr(cdf_new), self._ptr(self.tiles_loc[0]),
+                self._ptr(ts), self._ptr(tm), self._ptr(ox.own()), self._ptr(oc.own()), self._ptr(self.tiles_loc[0]),
                 self._ptr(self.tiles_loc[1]), None if self.anc is None else self._ptr(self.anc)))
-            # the windows must outlive the kernel that reads them: same stream, freed by the caching allocator in order
-            self.x, x_new = x_new, self.x
-            self.cdf, cdf_new = cdf_new, self.cdf
+            self._cur ^= 1
         self._gather_tiles()
         self._chk(L.ssme_pf_shard_finalize(self._h, T - 1, self._ptr(ts), self._ptr(tm)))
         self._T = T
@@ -209,10 +274,10 @@ class ShardedParticleFilter:
         return out[0]
 
     def local_particles(self):
-        return self.x.reshape(-1).cpu().numpy()
+        return self._hx[self._cur].own().reshape(-1).cpu().numpy()
 
     def local_cdf(self):
-        return self.cdf.reshape(-1).cpu().numpy()
+        return self._hc[self._cur].own().reshape(-1).cpu().numpy()
 
 
 class ShardedLiuWest:
