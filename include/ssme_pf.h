@@ -248,6 +248,9 @@ const char* ssme_lw_last_error(ssme_lw_handle h);
  * provides the first-stage (m, S) that mid turns into the log-sum-exp.  theta buffers are 4 planes: [4][tiles * 2048].  Bit-identical to ssme_lw_run_series. */
 int ssme_lw_shard_create(const ssme_lw_config* cfg, int32_t rank, int32_t world, ssme_lw_handle* out);
 int ssme_lw_set_stream(ssme_lw_handle h, void* hip_stream);
+/* theta OUTPUT buffers are 4 planes of `tiles` rows each (default B / world; larger when the caller keeps halo rows around
+ * its own tiles).  In the stage calls `win_tiles` is the same thing for the theta SOURCE window: rows per plane. */
+int ssme_lw_shard_set_plane_tiles(ssme_lw_handle h, int32_t tiles);
 int ssme_lw_shard_prepare(ssme_lw_handle h, const double* y, const double* z, int32_t T);
 /* t = 0 on this rank's tiles: prior draws, q1Samp, first weights */
 int ssme_lw_shard_init(ssme_lw_handle h, double* xB, double* thB, double* cdfB, double* tsumB, double* tmaxB);

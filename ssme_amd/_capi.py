@@ -31,7 +31,7 @@ EXPORTS = [
     "ssme_lw_create", "ssme_lw_destroy", "ssme_lw_reset", "ssme_lw_step", "ssme_lw_run_series", "ssme_lw_get_per_step",
     "ssme_lw_get_param_means", "ssme_lw_download_state", "ssme_lw_set_debug", "ssme_lw_last_elapsed_ms",
     "ssme_lw_last_error",
-    "ssme_lw_shard_create", "ssme_lw_set_stream", "ssme_lw_shard_prepare", "ssme_lw_shard_init", "ssme_lw_shard_plan",
+    "ssme_lw_shard_create", "ssme_lw_set_stream", "ssme_lw_shard_set_plane_tiles", "ssme_lw_shard_prepare", "ssme_lw_shard_init", "ssme_lw_shard_plan",
     "ssme_lw_shard_stage1", "ssme_lw_shard_mid", "ssme_lw_shard_stage2", "ssme_lw_shard_finalize", "ssme_lw_get_loglik",
 ]
 
@@ -124,6 +124,7 @@ def lib():
         vp = C.c_void_p
         L.ssme_lw_shard_create.argtypes = [C.POINTER(LwConfig), C.c_int32, C.c_int32, C.POINTER(H)]
         L.ssme_lw_set_stream.argtypes = [H, vp]
+        L.ssme_lw_shard_set_plane_tiles.argtypes = [H, C.c_int32]
         L.ssme_lw_shard_prepare.argtypes = [H, dp, dp, C.c_int32]
         L.ssme_lw_shard_init.argtypes = [H, vp, vp, vp, vp, vp]
         L.ssme_lw_shard_plan.argtypes = [H, C.c_int32, C.c_int32, vp, vp, C.POINTER(C.c_int32)]

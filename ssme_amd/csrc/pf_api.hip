@@ -1073,8 +1073,10 @@ struct ssme_lw_s {
     double *gamA, *pgamA, *gtotA, *gamB, *pgamB, *gtotB;
     uint32_t *anc, *kidx, *keybuf;
     int shard_rank, shard_world;     // particle-sharded filter (world = 0: unsharded)
+    int th_plane_tiles;              // sharded: rows (tiles) per theta plane of the caller's OUTPUT buffers (default B / world)
     hipStream_t own_stream;
     int32_t* plan_dev;
+    int32_t* plan_pin;               // pinned staging of the plan download
     int gamma_t0, gamma_rows;        // step API: the Gamma tables hold time indices gamma_t0 .. gamma_t0 + gamma_rows - 1
     int split_l2;                    // level-2 of both draws by k_level2_plan (more than 512 tiles)
     double *l2T[2], *l2R[2];         // [draw: 0 resampling (B), 1 k draw (A)][R][Bs]
@@ -1227,6 +1229,7 @@ int ssme_lw_destroy(ssme_lw_handle h) {
                     h->kidx, h->scal, h->keybuf, h->plan_dev, h->l2T[0], h->l2T[1], h->l2R[0], h->l2R[1], h->l2lo[0], h->l2lo[1],
                     h->l2hi[0], h->l2hi[1], h->l2s[0], h->l2s[1]};
     for (void* p : bufs) if (p) hipFree(p);
+    if (h->plan_pin) hipHostFree(h->plan_pin);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1284,6 +1287,8 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
             for (auto p : small) { LWCHK(hipMalloc(p, sizeof(double) * nb)); LWCHK(hipMemset(*p, 0, sizeof(double) * nb)); }
         } else {
             LWCHK(hipMalloc(&h->plan_dev, sizeof(int32_t) * 2 * h->shard_world));
+            LWCHK(hipHostMalloc(reinterpret_cast<void**>(&h->plan_pin), sizeof(int32_t) * 2 * h->shard_world, hipHostMallocDefault));
+            h->th_plane_tiles = h->B / h->shard_world;
         }
         LWCHK(hipMalloc(&h->mom, sizeof(double) * (size_t)h->R * h->B * 16));
         LWCHK(hipMalloc(&h->prop, sizeof(double) * (size_t)h->R * 16));
@@ -1330,6 +1335,14 @@ int ssme_lw_set_stream(ssme_lw_handle h, void* hip_stream) {
     return SSME_OK;
 }
 
+int ssme_lw_shard_set_plane_tiles(ssme_lw_handle h, int32_t tiles) {
+    if (!h || tiles < 1) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1) return SSME_ERR_STATE;
+    if (tiles < h->B / h->shard_world) return SSME_ERR_INVALID_ARG;
+    h->th_plane_tiles = tiles;
+    return SSME_OK;
+}
+
 int ssme_lw_shard_prepare(ssme_lw_handle h, const double* y, const double* z, int32_t T) {
     if (!h || !y) return SSME_ERR_INVALID_ARG;
     if (h->shard_world < 1) return SSME_ERR_STATE;
@@ -1353,7 +1366,7 @@ static LwArgs lw_shard_args(ssme_lw_handle h, int t) {
     a.t = t; a.yi = t; a.gi = t; a.finalize_prev = t > 1 || t == 1 ? 1 : 0;
     a.per_step = h->per_step;
     a.tile0 = h->shard_rank * Bl;
-    a.th_dst_stride = (int64_t)Bl * kTile;
+    a.th_dst_stride = (int64_t)h->th_plane_tiles * kTile;
     a.anc = nullptr; a.kidx = nullptr;
     return a;
 }
@@ -1380,10 +1393,11 @@ int ssme_lw_shard_plan(ssme_lw_handle h, int32_t which, int32_t t, const double*
         LWCHK(hipGetLastError());
         const int Bl = h->B / h->shard_world;
         for (int d = 0; d < h->shard_world; ++d) {
-            LWCHK(hipMemcpyAsync(lo_hi + 2 * d, h->l2lo[which] + (size_t)d * Bl, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-            LWCHK(hipMemcpyAsync(lo_hi + 2 * d + 1, h->l2hi[which] + (size_t)(d + 1) * Bl - 1, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            LWCHK(hipMemcpyAsync(h->plan_pin + 2 * d, h->l2lo[which] + (size_t)d * Bl, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            LWCHK(hipMemcpyAsync(h->plan_pin + 2 * d + 1, h->l2hi[which] + (size_t)(d + 1) * Bl - 1, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         }
-        LWCHK(hipStreamSynchronize(h->stream));
+        LWCHK(wait_stream_low_latency(h->stream));
+        for (int d = 0; d < 2 * h->shard_world; ++d) lo_hi[d] = h->plan_pin[d];
         return SSME_OK;
     }
     StepArgs a{};                                   // the fields k_shard_plan reads
@@ -1396,8 +1410,9 @@ int ssme_lw_shard_plan(ssme_lw_handle h, int32_t which, int32_t t, const double*
     hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(512), sizeof(double) * (h->Bpow2 < 2 ? 2 : h->Bpow2), h->stream, a,
                        h->shard_world, h->plan_dev);
     LWCHK(hipGetLastError());
-    LWCHK(hipMemcpyAsync(lo_hi, h->plan_dev, sizeof(int32_t) * 2 * h->shard_world, hipMemcpyDeviceToHost, h->stream));
-    LWCHK(hipStreamSynchronize(h->stream));
+    LWCHK(hipMemcpyAsync(h->plan_pin, h->plan_dev, sizeof(int32_t) * 2 * h->shard_world, hipMemcpyDeviceToHost, h->stream));
+    LWCHK(wait_stream_low_latency(h->stream));
+    for (int d = 0; d < 2 * h->shard_world; ++d) lo_hi[d] = h->plan_pin[d];
     return SSME_OK;
 }
 

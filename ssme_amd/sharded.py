@@ -94,10 +94,10 @@ class HaloBuffer:
     same buffer, so the rank's own tiles are never copied: only the halo tiles that other ranks own travel.  A window that
     does not fit the margins (very unbalanced weights) falls back to `exchange_tiles` (a freshly assembled window)."""
 
-    def __init__(self, tiles, width, margin, device, dtype):
+    def __init__(self, tiles, width, margin, device, dtype, storage=None):
         import torch
         self.tiles, self.width, self.margin = tiles, width, margin
-        self.buf = torch.zeros((tiles + 2 * margin, width), dtype=dtype, device=device)
+        self.buf = torch.zeros((tiles + 2 * margin, width), dtype=dtype, device=device) if storage is None else storage
 
     def own(self):
         return self.buf[self.margin:self.margin + self.tiles]
@@ -316,10 +316,16 @@ class ShardedLiuWest:
         self._chk(capi.lib().ssme_lw_set_stream(self._h, C.c_void_p(self._stream.cuda_stream)))
         f64 = dict(dtype=torch.float64, device=self.device)
         Bl = self.Bl
-        self.xB, self.cdfB = torch.zeros((Bl, TILE), **f64), torch.zeros((Bl, TILE), **f64)
-        self.thB = torch.zeros((4, Bl, TILE), **f64)
-        self.xr, self.lw1, self.cdfA = (torch.zeros((Bl, TILE), **f64) for _ in range(3))
-        self.thr = torch.zeros((4, Bl, TILE), **f64)
+        margin = min(self.B - Bl, max(2, Bl // 2)) if self.world > 1 else 0
+        self._rows = Bl + 2 * margin                                   # rows per theta plane, halos included
+        self._chk(capi.lib().ssme_lw_shard_set_plane_tiles(self._h, self._rows))
+        mk = lambda: HaloBuffer(Bl, TILE, margin, self.device, torch.float64)
+        # stage-2 outputs / stage-1 sources, and stage-1 outputs / stage-2 sources; theta: 4 planes in one tensor
+        self.xB, self.cdfB, self.xr, self.lw1, self.cdfA = mk(), mk(), mk(), mk(), mk()
+        self._thB4 = torch.zeros((4, self._rows, TILE), **f64)
+        self._thr4 = torch.zeros((4, self._rows, TILE), **f64)
+        self.thB = [HaloBuffer(Bl, TILE, margin, self.device, torch.float64, storage=self._thB4[d]) for d in range(4)]
+        self.thr = [HaloBuffer(Bl, TILE, margin, self.device, torch.float64, storage=self._thr4[d]) for d in range(4)]
         self.tilesB = torch.zeros((2, Bl), **f64)            # rows: tile sums, tile maxima (second-stage weights)
         self.tilesA = torch.zeros((2, Bl), **f64)
         self.mom = torch.zeros((Bl, 16), **f64)
@@ -357,17 +363,24 @@ class ShardedLiuWest:
         dist.all_gather(parts, src.contiguous(), group=self.group)
         return torch.cat(parts, dim=out_cat_dim).to(self.device)
 
-    def _windows(self, which, t, tiles_all, planes2d, planes4):
-        """plan + exchange: returns (win_tile0, win_tiles, [2-D windows], [4-plane window])."""
+    def _windows(self, which, t, tiles_all, halos2d, halos4):
+        """plan + exchange for one draw.  Returns (win_tile0, theta rows per source plane, [2-D source windows], theta source
+        window (pointer to plane 0)).  Own tiles stay where they are; only halo tiles travel."""
         import torch
         lo_hi = (C.c_int32 * (2 * self.world))()
         self._chk(capi.lib().ssme_lw_shard_plan(self._h, which, t, self._ptr(tiles_all[0]), self._ptr(tiles_all[1]), lo_hi))
         plan = [(lo_hi[2 * g], lo_hi[2 * g + 1]) for g in range(self.world)]
-        sends, recvs = exchange_plan(plan, self.Bl, self.rank)
-        self.exchanged_tiles += sum(c for s, (_, c) in enumerate(recvs) if s != self.rank)
-        wins = [exchange_tiles(p, self.tile0, sends, recvs, self.rank, self.group, self.stage) for p in planes2d]
-        w4 = torch.stack([exchange_tiles(planes4[d], self.tile0, sends, recvs, self.rank, self.group, self.stage) for d in range(4)])
-        return plan[self.rank][0], plan[self.rank][1] - plan[self.rank][0] + 1, wins, w4.contiguous()
+        lo_r, hi_r = plan[self.rank]
+        self.exchanged_tiles += max(0, min(hi_r + 1, self.tile0) - lo_r) + max(0, hi_r - max(lo_r - 1, self.tile0 + self.Bl - 1))
+        got = exchange_halos(halos2d + halos4, self.tile0, plan, self.Bl, self.rank, self.group, self.stage)
+        if got is not None:
+            w0, wt = got
+            return w0, self._rows, [hb.rows(w0, wt, self.tile0) for hb in halos2d], halos4[0].rows(w0, wt, self.tile0)
+        sends, recvs = exchange_plan(plan, self.Bl, self.rank)             # window wider than the margins: assemble it
+        wins = [exchange_tiles(hb.own(), self.tile0, sends, recvs, self.rank, self.group, self.stage) for hb in halos2d]
+        w4 = torch.stack([exchange_tiles(hb.own(), self.tile0, sends, recvs, self.rank, self.group, self.stage) for hb in halos4])
+        self._keep = w4                                                    # keep the assembled window alive until the launch
+        return lo_r, hi_r - lo_r + 1, wins, w4
 
     def run_series(self, y, z=None):
         import torch
@@ -382,20 +395,21 @@ class ShardedLiuWest:
         T = yv.size
         self._chk(L.ssme_lw_shard_prepare(self._h, capi.dptr(yv), capi.dptr(zv), T))
         self.exchanged_tiles = 0
-        self._chk(L.ssme_lw_shard_init(self._h, p(self.xB), p(self.thB), p(self.cdfB), p(self.tilesB[0]), p(self.tilesB[1])))
+        thB_own, thr_own = p(self.thB[0].own()), p(self.thr[0].own())       # plane 0 of the own rows; planes are _rows apart
+        self._chk(L.ssme_lw_shard_init(self._h, p(self.xB.own()), thB_own, p(self.cdfB.own()), p(self.tilesB[0]), p(self.tilesB[1])))
         for t in range(1, T):
             self.allB.copy_(self._gather(self.tilesB, 1))
-            w0, wt, (w_x, w_cdf), w_th = self._windows(0, t, self.allB, [self.xB, self.cdfB], self.thB)
-            self._chk(L.ssme_lw_shard_stage1(self._h, t, w0, wt, p(w_x), p(w_th), p(w_cdf), p(self.allB[0]), p(self.allB[1]),
-                                             p(self.xr), p(self.thr), p(self.lw1), p(self.cdfA), p(self.tilesA[0]),
+            w0, rows, (w_x, w_cdf), w_th = self._windows(0, t, self.allB, [self.xB, self.cdfB], self.thB)
+            self._chk(L.ssme_lw_shard_stage1(self._h, t, w0, rows, p(w_x), p(w_th), p(w_cdf), p(self.allB[0]), p(self.allB[1]),
+                                             p(self.xr.own()), thr_own, p(self.lw1.own()), p(self.cdfA.own()), p(self.tilesA[0]),
                                              p(self.tilesA[1]), p(self.mom), None))
             self.allA.copy_(self._gather(self.tilesA, 1))
             self.mom_all.copy_(self._gather(self.mom, 0))
             # the plan of the k draw first: with the split level-2 it also provides the (m, S) that mid turns into lse1
-            w0, wt, (w_x, w_lw1, w_cdf), w_th = self._windows(1, t, self.allA, [self.xr, self.lw1, self.cdfA], self.thr)
+            w0, rows, (w_x, w_lw1, w_cdf), w_th = self._windows(1, t, self.allA, [self.xr, self.lw1, self.cdfA], self.thr)
             self._chk(L.ssme_lw_shard_mid(self._h, t, p(self.allA[0]), p(self.allA[1]), p(self.mom_all)))
-            self._chk(L.ssme_lw_shard_stage2(self._h, t, w0, wt, p(w_x), p(w_th), p(w_lw1), p(w_cdf), p(self.allA[0]),
-                                             p(self.allA[1]), p(self.xB), p(self.thB), p(self.cdfB), p(self.tilesB[0]),
+            self._chk(L.ssme_lw_shard_stage2(self._h, t, w0, rows, p(w_x), p(w_th), p(w_lw1), p(w_cdf), p(self.allA[0]),
+                                             p(self.allA[1]), p(self.xB.own()), thB_own, p(self.cdfB.own()), p(self.tilesB[0]),
                                              p(self.tilesB[1]), None))
         self.allB.copy_(self._gather(self.tilesB, 1))
         self._chk(L.ssme_lw_shard_finalize(self._h, T - 1, p(self.allB[0]), p(self.allB[1])))
@@ -410,7 +424,7 @@ class ShardedLiuWest:
         return out[0]
 
     def local_particles(self):
-        return self.xB.reshape(-1).cpu().numpy()
+        return self.xB.own().reshape(-1).cpu().numpy()
 
     def local_theta(self):
-        return self.thB.reshape(4, -1).cpu().numpy()
+        return np.stack([hb.own().reshape(-1).cpu().numpy() for hb in self.thB])
