@@ -87,6 +87,21 @@ def exchange_tiles(local, my_first_tile, sends, recvs, rank, group=None, stage_t
     return window.to(local.device) if stage_through_host else window
 
 
+def gather_flat(local_flat, world, group=None, stage_through_host=False):
+    """all_gather of one contiguous 1-D tensor per rank -> [world, n] on the local tensor's device (one collective:
+    all_gather_into_tensor where the backend has it (nccl), the list form otherwise)."""
+    import torch
+    import torch.distributed as dist
+    src = local_flat.cpu() if stage_through_host else local_flat
+    out = torch.empty((world, src.numel()), dtype=src.dtype, device=src.device)
+    if stage_through_host:
+        parts = list(out.unbind(0))
+        dist.all_gather(parts, src.contiguous(), group=group)
+    else:
+        dist.all_gather_into_tensor(out, src.contiguous(), group=group)
+    return out.to(local_flat.device) if stage_through_host else out
+
+
 class HaloBuffer:
     """This rank's tiles with room for neighbours' tiles on both sides: [margin | own tiles | margin] rows of W doubles.
 
@@ -207,12 +222,9 @@ class ShardedParticleFilter:
     # ---- collectives --------------------------------------------------------------------------------------------
     def _gather_tiles(self):
         """tiles_all[:, g*Bl:(g+1)*Bl] = rank g's tiles_loc."""
-        import torch
-        import torch.distributed as dist
-        loc = self.tiles_loc.cpu() if self.stage else self.tiles_loc
-        parts = [torch.empty((2, self.Bl), dtype=loc.dtype, device=loc.device) for _ in range(self.world)]
-        dist.all_gather(parts, loc.contiguous(), group=self.group)
-        self.tiles_all.copy_(torch.cat(parts, dim=1), non_blocking=False)
+        G = gather_flat(self.tiles_loc.reshape(-1), self.world, self.group, self.stage)          # [world, 2 * Bl]
+        self.tiles_all[0].view(self.world, self.Bl).copy_(G[:, :self.Bl])
+        self.tiles_all[1].view(self.world, self.Bl).copy_(G[:, self.Bl:])
 
     def _ptr(self, t):
         return C.c_void_p(t.data_ptr())
@@ -327,8 +339,9 @@ class ShardedLiuWest:
         self.thB = [HaloBuffer(Bl, TILE, margin, self.device, torch.float64, storage=self._thB4[d]) for d in range(4)]
         self.thr = [HaloBuffer(Bl, TILE, margin, self.device, torch.float64, storage=self._thr4[d]) for d in range(4)]
         self.tilesB = torch.zeros((2, Bl), **f64)            # rows: tile sums, tile maxima (second-stage weights)
-        self.tilesA = torch.zeros((2, Bl), **f64)
-        self.mom = torch.zeros((Bl, 16), **f64)
+        self._locA = torch.zeros(18 * Bl, **f64)             # stage-1 outputs in one buffer: tile sums | tile maxima | 16 moments per tile
+        self.tilesA = self._locA[:2 * Bl].view(2, Bl)
+        self.mom = self._locA[2 * Bl:].view(Bl, 16)
         self.allB = torch.zeros((2, self.B), **f64)
         self.allA = torch.zeros((2, self.B), **f64)
         self.mom_all = torch.zeros((self.B, 16), **f64)
@@ -354,14 +367,17 @@ class ShardedLiuWest:
     def _ptr(t):
         return C.c_void_p(t.data_ptr())
 
-    def _gather(self, loc, out_cat_dim):
-        """all_gather of a small per-rank tensor; concatenated over ranks along out_cat_dim."""
-        import torch
-        import torch.distributed as dist
-        src = loc.cpu() if self.stage else loc
-        parts = [torch.empty_like(src) for _ in range(self.world)]
-        dist.all_gather(parts, src.contiguous(), group=self.group)
-        return torch.cat(parts, dim=out_cat_dim).to(self.device)
+    def _gather_B(self):
+        G = gather_flat(self.tilesB.reshape(-1), self.world, self.group, self.stage)               # [world, 2 Bl]
+        self.allB[0].view(self.world, self.Bl).copy_(G[:, :self.Bl])
+        self.allB[1].view(self.world, self.Bl).copy_(G[:, self.Bl:])
+
+    def _gather_A(self):
+        Bl = self.Bl
+        G = gather_flat(self._locA, self.world, self.group, self.stage)                             # [world, 18 Bl]: ONE collective
+        self.allA[0].view(self.world, Bl).copy_(G[:, :Bl])
+        self.allA[1].view(self.world, Bl).copy_(G[:, Bl:2 * Bl])
+        self.mom_all.view(self.world, Bl * 16).copy_(G[:, 2 * Bl:])
 
     def _windows(self, which, t, tiles_all, halos2d, halos4):
         """plan + exchange for one draw.  Returns (win_tile0, theta rows per source plane, [2-D source windows], theta source
@@ -398,20 +414,19 @@ class ShardedLiuWest:
         thB_own, thr_own = p(self.thB[0].own()), p(self.thr[0].own())       # plane 0 of the own rows; planes are _rows apart
         self._chk(L.ssme_lw_shard_init(self._h, p(self.xB.own()), thB_own, p(self.cdfB.own()), p(self.tilesB[0]), p(self.tilesB[1])))
         for t in range(1, T):
-            self.allB.copy_(self._gather(self.tilesB, 1))
+            self._gather_B()
             w0, rows, (w_x, w_cdf), w_th = self._windows(0, t, self.allB, [self.xB, self.cdfB], self.thB)
             self._chk(L.ssme_lw_shard_stage1(self._h, t, w0, rows, p(w_x), p(w_th), p(w_cdf), p(self.allB[0]), p(self.allB[1]),
                                              p(self.xr.own()), thr_own, p(self.lw1.own()), p(self.cdfA.own()), p(self.tilesA[0]),
                                              p(self.tilesA[1]), p(self.mom), None))
-            self.allA.copy_(self._gather(self.tilesA, 1))
-            self.mom_all.copy_(self._gather(self.mom, 0))
+            self._gather_A()
             # the plan of the k draw first: with the split level-2 it also provides the (m, S) that mid turns into lse1
             w0, rows, (w_x, w_lw1, w_cdf), w_th = self._windows(1, t, self.allA, [self.xr, self.lw1, self.cdfA], self.thr)
             self._chk(L.ssme_lw_shard_mid(self._h, t, p(self.allA[0]), p(self.allA[1]), p(self.mom_all)))
             self._chk(L.ssme_lw_shard_stage2(self._h, t, w0, rows, p(w_x), p(w_th), p(w_lw1), p(w_cdf), p(self.allA[0]),
                                              p(self.allA[1]), p(self.xB.own()), thB_own, p(self.cdfB.own()), p(self.tilesB[0]),
                                              p(self.tilesB[1]), None))
-        self.allB.copy_(self._gather(self.tilesB, 1))
+        self._gather_B()
         self._chk(L.ssme_lw_shard_finalize(self._h, T - 1, p(self.allB[0]), p(self.allB[1])))
         self._T = T
         out = np.empty(1)
