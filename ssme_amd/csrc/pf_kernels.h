@@ -6,7 +6,7 @@
 //   resampling targets (sorted uniforms by exponential spacings)          twin :105-139
 //   search of the previous step's integer weight cdf, tiles staged in LDS  twin :112-139
 //   gather ancestor state, fSamp, logGEv                                  example/univ_svol_bootstrap_filter.h:74-86
-//   tile max, q = rne(exp(logw - max_tile) 2^51), exact integer tile scan  twin :96-104
+//   tile max, q = rne(exp(logw - max_tile) 2^41), exact integer tile scan  twin :96-104
 // It replaces pf::BSFilter::filter (call site example/estimate_univ_svol.h:124).
 //
 // Particles are a structure of arrays in HBM: x[R][Npad] (fp64, ping-pong), cdf[R][Npad] (fixed point:
