@@ -1,5 +1,5 @@
 import os, sys, numpy as np
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ssme_amd as sa
 from oracle import oracle
