@@ -280,6 +280,56 @@ private:
     unsigned num_obs_ = 0;
 };
 
+// ---- Swarm over univariate-SVOL members (include/ssme/pswarm_filter.h:23-320: the variant without covariates) ---------
+// update(y) = filter(y, fs) on every member, plain averages over members; parameters in the model's ctor order of
+// svol_bs: samp_untrans_params() returns (phi, beta, sigma) (univ_svol_bootstrap_filter.h:34).
+template <std::size_t n_state_parts, std::size_t n_param_parts, typename float_t = double>
+class swarm_gpu {
+public:
+    using float_type = float_t;
+    using func = int;
+    explicit swarm_gpu(const std::vector<func>& fs, gpu_options o = gpu_options()) : fs_(fs), opt_(o) {}
+    virtual ~swarm_gpu() = default;
+    virtual std::vector<float_t> samp_untrans_params() = 0;      // phi, beta, sigma
+
+    template <typename Osv>
+    void update(const Osv& yt) {
+        if (!h_) finish_construction();
+        const double y = (double)yt(0);
+        std::vector<double> ll(n_param_parts), e(n_param_parts);
+        check(ssme_pf_step(h_.get(), &y, nullptr, ll.data()), h_.get());
+        double s = 0.0;
+        for (double v : ll) s += v;
+        log_cond_like_ = (float_t)(s / (double)n_param_parts);
+        expectations_.assign(fs_.size(), 0.0);
+        for (std::size_t i = 0; i < fs_.size(); ++i) {
+            check(ssme_pf_get_expectations(h_.get(), fs_[i], e.data()), h_.get());
+            double se = 0.0;
+            for (double v : e) se += v;
+            expectations_[i] = se / (double)n_param_parts;
+        }
+    }
+    float_t getLogCondLike() const { return log_cond_like_; }
+    std::vector<double> getExpectations() const { return expectations_; }
+
+private:
+    void finish_construction() {
+        std::vector<double> theta(n_param_parts * 3);
+        for (std::size_t i = 0; i < n_param_parts; ++i) {
+            const std::vector<float_t> p = samp_untrans_params();
+            if (p.size() != 3) throw std::invalid_argument("samp_untrans_params must return phi, beta, sigma");
+            theta[i * 3 + 0] = (double)p[1]; theta[i * 3 + 1] = (double)p[0]; theta[i * 3 + 2] = (double)p[2];   // C ABI order: beta, phi, sigma
+        }
+        h_ = handle(SSME_MODEL_SVOL, (int)n_state_parts, (int)n_param_parts, opt_.seed, opt_.resampler, opt_.resamp_sched, opt_.device, 0);
+        check(ssme_pf_set_params(h_.get(), theta.data(), 3, (int)n_param_parts), h_.get());
+    }
+    std::vector<func> fs_;
+    gpu_options opt_;
+    handle h_;
+    std::vector<double> expectations_;
+    float_t log_cond_like_ = 0;
+};
+
 // ---- headerless CSV -> rows of doubles (utils::read_data, include/ssme/utils.h:25-64) -------------------------------
 // Same tolerance as the reference: rows that fail to parse are skipped; an unreadable file yields an empty vector
 // (callers then throw length_error, estimate_univ_svol.h:112-113).

@@ -16,7 +16,7 @@ from . import _capi as capi
 from ._capi import (MODEL_LIN_GAUSS, MODEL_SVOL, MODEL_SVOL_LEVERAGE, RESAMP_MULTINOMIAL, RESAMP_MULTINOMIAL_IID,
                     RESAMP_STRATIFIED, RESAMP_SYSTEMATIC, SsmeError)
 
-__all__ = ["ParticleFilterBank", "svol_bs", "svol_leverage", "lin_gauss_bs", "log_like_eval", "svol_lw_1_par", "SwarmWithCovs", "svol_swarm_1",
+__all__ = ["ParticleFilterBank", "svol_bs", "svol_leverage", "lin_gauss_bs", "log_like_eval", "svol_lw_1_par", "SwarmWithCovs", "Swarm", "svol_swarm_1",
            "TR_NULL", "TR_TWICE_FISHER", "TR_LOGIT", "TR_LOG",
            "MODEL_SVOL", "MODEL_SVOL_LEVERAGE", "MODEL_LIN_GAUSS", "RESAMP_MULTINOMIAL", "RESAMP_SYSTEMATIC",
            "RESAMP_STRATIFIED", "RESAMP_MULTINOMIAL_IID", "SsmeError"]
@@ -273,6 +273,21 @@ class SwarmWithCovs:
         if self._bank is not None:
             self._bank.close()
             self._bank = None
+
+
+class Swarm(SwarmWithCovs):
+    """include/ssme/pswarm_filter.h:23-320: the swarm without covariates, over univariate-SVOL members.
+    samp_untrans_params() returns (beta, phi, sigma), the C ABI's order for MODEL_SVOL."""
+    _model = MODEL_SVOL
+
+    def update(self, y):
+        if self._bank is None:
+            self._finish_construction()
+        ll = self._bank.step(float(np.ravel(y)[0]), None)
+        self._member_lcl = ll
+        self._lcl = float(np.sum(ll) / ll.size)
+        self._exp = [float(np.sum(self._bank.expectations(f)) / ll.size) for f in self._fs]
+        self.num_obs += 1
 
 
 class svol_swarm_1(SwarmWithCovs):

@@ -27,6 +27,12 @@ struct test_swarm : ssme_gpu::swarm_with_covs_gpu<600, 5, double> {
     }
 };
 
+struct test_swarm_nocov : ssme_gpu::swarm_gpu<400, 3, double> {
+    using ssme_gpu::swarm_gpu<400, 3, double>::swarm_gpu;
+    int k = 0;
+    std::vector<double> samp_untrans_params() override { const double u = 0.2 + 0.3 * k++; return {0.9 + 0.05 * u, 0.8 + 0.4 * u, 0.2 + 0.1 * u}; }
+};
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::vector<vec1> data;
@@ -81,6 +87,11 @@ int main(int argc, char** argv) {
     std::printf("swarm %.17g\n", swll);
     std::printf("swarm42 %.17g\n", sw.getExpectations()[0]);
     std::printf("swarmx %.17g\n", sw.getExpectations()[1]);
+    // (9) swarm without covariates (pswarm_filter.h:23-320)
+    test_swarm_nocov sn({SSME_H_X}, o);
+    double snll = 0.0;
+    for (size_t row = 0; row < 4; ++row) { sn.update(data[row]); snll += sn.getLogCondLike(); }
+    std::printf("swarm_nocov %.17g\n", snll);
     // (4) error mapping
     try { std::vector<vec1> empty; ssme_gpu::log_like_eval_gpu(theta, empty, 100, 1, o); std::printf("no-throw\n"); }
     catch (const std::length_error&) { std::printf("length_error ok\n"); }

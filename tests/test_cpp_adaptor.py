@@ -55,6 +55,12 @@ def test_adaptor_matches_oracle(oracle, spy):
     assert abs(float(vals["swarm"]) - tot) < 1e-12
     assert abs(float(vals["swarm42"]) - 42.0) < 1e-4
     assert abs(float(vals["swarmx"]) - ex) < 1e-9
+    mem = []
+    for k in range(3):
+        u = 0.2 + 0.3 * k
+        mem.append(oracle.Filter(oracle.MODEL_SVOL, 400, [0.8 + 0.4 * u, 0.9 + 0.05 * u, 0.2 + 0.1 * u], 77, rep=k))   # beta, phi, sigma
+    tot = sum(sum(m.step(y[t]) for m in mem) / 3 for t in range(4))
+    assert abs(float(vals["swarm_nocov"]) - tot) < 1e-12
     n, first = vals["read_data"].split()
     assert int(n) == spy.size and float(first) == spy[0]
 
