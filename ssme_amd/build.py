@@ -7,8 +7,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libssme_pf.so")
 SOURCES = [os.path.join(CSRC, "pf_api.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("pf_kernels.h", "ssme_math.h")] + [
-    os.path.join(os.path.dirname(HERE), "include", "ssme_pf.h")]
+STAMP = SO + ".srchash"          # hash of every source + the flags the .so was built from (ships with the .so)
+
+
+def deps():
+    """Everything the library is compiled from: csrc/* and the C-ABI header."""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp"))) + [
+        os.path.join(os.path.dirname(HERE), "include", "ssme_pf.h")]
 
 # -ffp-contract=off: the libm-free math is a fixed IEEE operation sequence (explicit fma only)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma",
@@ -22,11 +28,24 @@ def hipcc():
     return "hipcc"
 
 
+def source_hash(extra=()):
+    import hashlib
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS + list(extra)).encode())
+    for d in deps():
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(SO):
+    """True unless the .so on disk was built from exactly these sources and flags (content hash, not mtimes:
+    a snapshot copied to another box keeps no useful timestamps)."""
+    if not os.path.exists(SO) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(SO)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False, extra=(), out=None):
@@ -59,6 +78,9 @@ def build(force=False, verbose=False, extra=(), out=None):
         scratch = st.get("ScratchSize [bytes/lane]", 0)
         if scratch != 0 and not (st.get("SGPRs Spill", 0) > 0 and scratch <= 128):
             raise RuntimeError(f"kernel {name} uses scratch memory: {st}")
+    if out is None and not extra:
+        with open(STAMP, "w") as f:
+            f.write(source_hash() + "\n")
     return out or SO
 
 

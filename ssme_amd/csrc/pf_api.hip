@@ -1505,6 +1505,7 @@ int ssme_lw_reset(ssme_lw_handle h) {
 
 int ssme_lw_set_debug(ssme_lw_handle h, int32_t flags) {
     if (!h) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0 && (flags & 1)) return SSME_ERR_STATE;   // index recording needs the handle's own buffers
     LWCHK(hipSetDevice(h->cfg.device));
     if ((flags & 1) && !h->anc) {
         LWCHK(hipMalloc(&h->anc, sizeof(uint32_t) * (size_t)h->R * h->Npad));
@@ -1519,6 +1520,7 @@ int ssme_lw_set_debug(ssme_lw_handle h, int32_t flags) {
 
 int ssme_lw_step(ssme_lw_handle h, const double* y, const double* z, double* out) {
     if (!h || !y) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;     // sharded handles own no particle buffers: ssme_lw_shard_* drives them
     LWCHK(hipSetDevice(h->cfg.device));
     const double z0 = z ? *z : 0.0;
     if (h->gcap < kStepGammaChunk) {
@@ -1548,6 +1550,7 @@ int ssme_lw_step(ssme_lw_handle h, const double* y, const double* z, double* out
 
 int ssme_lw_run_series(ssme_lw_handle h, const double* y, const double* z, int32_t T, double* loglik_out) {
     if (!h || !y) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;     // sharded handles own no particle buffers: ssme_lw_shard_* drives them
     if (T < 1) return SSME_ERR_LENGTH;
     LWCHK(hipSetDevice(h->cfg.device));
     int rc = lw_ensure_capacity(h, T);
@@ -1583,6 +1586,7 @@ int ssme_lw_get_per_step(ssme_lw_handle h, double* out, int32_t T) {
 
 int ssme_lw_get_param_means(ssme_lw_handle h, double* out) {
     if (!h || !out) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;     // sharded handles own no particle buffers: ssme_lw_shard_* drives them
     if (h->t < 1) return SSME_ERR_STATE;
     LWCHK(hipSetDevice(h->cfg.device));
     LwArgs a = lw_args(h);
@@ -1598,6 +1602,7 @@ int ssme_lw_get_param_means(ssme_lw_handle h, double* out) {
 int ssme_lw_download_state(ssme_lw_handle h, int32_t f, double* x, double* theta, uint32_t* kidx, uint32_t* anc, double* thetabar,
                            double* chol) {
     if (!h || f < 0 || f >= h->R) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;     // sharded handles own no particle buffers: ssme_lw_shard_* drives them
     LWCHK(hipSetDevice(h->cfg.device));
     const size_t off = (size_t)f * h->Npad;
     if (x) LWCHK(hipMemcpyAsync(x, h->xB + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));

@@ -112,12 +112,6 @@ struct StepArgs {
 // out of range, or whose row is masked off, receive `fill`.
 // ---------------------------------------------------------------------------------------
 template <int CTRL, int ROWMASK>
-__device__ __forceinline__ u64 dpp_u64(u64 v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROWMASK, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROWMASK, 0xF, false);
-    return ((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo;
-}
-template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_f64_neginf(double v) {    // fill = -inf
     const u64 b = d2bits(v);
     const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROWMASK, 0xF, false);
@@ -150,17 +144,6 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 
 // row_shr:n = 0x110+n ; row_bcast:15 = 0x142 ; row_bcast:31 = 0x143 ; wave_shr:1 = 0x138
-__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v) {
-    v += dpp_u64<0x111, 0xF>(v);
-    v += dpp_u64<0x112, 0xF>(v);
-    v += dpp_u64<0x114, 0xF>(v);
-    v += dpp_u64<0x118, 0xF>(v);
-    v += dpp_u64<0x142, 0xA>(v);
-    v += dpp_u64<0x143, 0xC>(v);
-    return v;
-}
-__device__ __forceinline__ u64 wave_shr1_u64(u64 v) { return dpp_u64<0x138, 0xF>(v); }
-
 __device__ __forceinline__ u64 readlane_u64(u64 v, int lane) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
@@ -192,46 +175,12 @@ __device__ __forceinline__ double block_max_nanprop(double m, bool nan, double* 
 }
 
 // ---------------------------------------------------------------------------------------
-// Exact inclusive scan of 2048 uint64 values by a block of NT threads (NT = 256, 512, 1024).
+// Exact inclusive scan of 2048 integer-valued doubles by a block of NT threads (NT = 256, 512, 1024); every partial
+// sum < 2^53, so each v_add_f64 is exact and the sums are associative: any wave/segment decomposition gives the same.
 // Thread tid holds NK = 1024/NT pairs: q[k][c] = value[(k*NT + tid)*2 + c].
 // incl[k][c] = sum of all values up to and including that position; total = sum of all.
-// lds_seg: 16 u64 private to this call (no trailing barrier).  One __syncthreads().
-// Integer addition is associative: any wave/segment decomposition gives the same sums.
+// lds_seg: 16 doubles private to this call (no trailing barrier).  One __syncthreads().
 // ---------------------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ void block_scan_u64(const u64 (&q)[1024 / NT][2], u64 (&incl)[1024 / NT][2], u64& total,
-                                               u64* lds_seg) {
-    constexpr int NK = 1024 / NT, WPR = NT / 64;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    u64 s0[NK], s1[NK], exc[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        s0[k] = q[k][0];
-        s1[k] = s0[k] + q[k][1];
-        const u64 inc = wave_incl_scan_u64(s1[k]);
-        exc[k] = wave_shr1_u64(inc);
-        if (lane == 63) lds_seg[k * WPR + wave] = inc;
-    }
-    __syncthreads();
-    // 16 segment totals -> inclusive prefixes, scanned inside every 16-lane row
-    u64 sv = lds_seg[lane & 15];
-    sv += dpp_u64<0x111, 0xF>(sv);
-    sv += dpp_u64<0x112, 0xF>(sv);
-    sv += dpp_u64<0x114, 0xF>(sv);
-    sv += dpp_u64<0x118, 0xF>(sv);
-    total = readlane_u64(sv, 15);
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int seg = k * WPR + wave;
-        const u64 pre = seg ? readlane_u64(sv, seg - 1) : 0ull;
-        const u64 base = pre + exc[k];
-        incl[k][0] = base + s0[k];
-        incl[k][1] = base + s1[k];
-    }
-}
-
-// The same for integer-valued doubles (every partial sum < 2^53, so each v_add_f64 is exact).
 template <int NT>
 __device__ __forceinline__ void block_scan_f64(const double (&q)[1024 / NT][2], double (&incl)[1024 / NT][2], double& total,
                                                double* lds_seg) {
@@ -353,15 +302,6 @@ __device__ __forceinline__ int count_less_pow2(int n, double target, F get) {
         if (get(pos + step - 1) < target) pos += step;
     // pos in [0, n-1]; the last element is not probed: callers clamp the count to n-1 anyway
     return pos;
-}
-
-// gallop: #{ j < 2048 : tile[j] < target } given that every index < lo already is (lo <= count)
-__device__ __forceinline__ int count_less_gallop(const double* tile, double target, int lo) {
-    int w = 1;
-    while (lo + w <= kTile && tile[lo + w - 1] < target) { lo += w; w <<= 1; }
-    for (w >>= 1; w >= 1; w >>= 1)
-        if (lo + w <= kTile && tile[lo + w - 1] < target) lo += w;
-    return lo < kTile - 1 ? lo : kTile - 1;
 }
 
 // Level-2 of one filter: global max m over the tile maxima (NaN propagating), rescaled integer
@@ -725,7 +665,6 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             __syncthreads();
             STAMP(a, 5);
             PRIO_AT(5);
-    PRIO_AT(5);
             // All 2*NK count-searches of a thread descend together, one level per iteration: the probes of a level are
             // independent LDS reads, so the phase costs log2(2048) = 11 dependent LDS round trips instead of one chain
             // per particle (this phase is bound by LDS latency, not by issue slots).

@@ -132,7 +132,10 @@ def exchange_halos(bufs, tile0, plan, tiles_per_rank, rank, group=None, stage_th
     None if the window does not fit the margins."""
     import torch.distributed as dist
     lo, hi = plan[rank]
-    if not all(b.fits(lo, hi, tile0) for b in bufs):
+    # The decision is GLOBAL: every rank holds the whole plan and evaluates every rank's window against the (identical)
+    # margins, so that all ranks take the same path and post the same grouping of sends/receives (a mixed grouping is
+    # benign on gloo but not something to rely on under RCCL).
+    if not all(b.fits(plan[g][0], plan[g][1], g * tiles_per_rank) for g in range(len(plan)) for b in bufs):
         return None
     sends, recvs = exchange_plan(plan, tiles_per_rank, rank)
     peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))

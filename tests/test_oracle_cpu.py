@@ -181,16 +181,43 @@ def test_kalman_anchor(oracle, resampler):
 
 
 def test_mode_a_vs_mode_b(oracle, spy):
-    """Reference-faithful mt19937 mode and kernel-matched Philox mode agree statistically."""
+    """Reference-faithful mt19937 mode (A) and kernel-matched Philox mode (B) have the same mean log-likelihood:
+    >= 200 seeds each, 3 SE, no additive slack, svol_bs at the shipped N = 500 on the first 300
+    rows of spy_returns.csv; both resamplers of the reference (discrete_distribution and the sorted-uniform one)."""
+    import stat_anchor as sa
     th = [1.0, 0.95, 0.25]
     y = spy[:300]
-    a = np.array([oracle.ref_run_series(oracle.MODEL_SVOL, th, 500, y, seed=s)[0] for s in range(24)])
-    b = np.array([oracle.Filter(oracle.MODEL_SVOL, 500, th, s).run_series(y)[0] for s in range(24)])
-    se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
-    assert abs(a.mean() - b.mean()) < 4 * se
-    af = np.array([oracle.ref_run_series(oracle.MODEL_SVOL, th, 500, y, seed=s, fast_resampler=True)[0]
-                   for s in range(24)])
-    assert abs(a.mean() - af.mean()) < 4 * np.sqrt(a.var(ddof=1) / 24 + af.var(ddof=1) / 24)
+    a = sa.mode_a_bootstrap(oracle, oracle.MODEL_SVOL, th, 500, y)
+    b = np.array(sa.pmap(lambda s: oracle.Filter(oracle.MODEL_SVOL, 500, th, 1000 + s).run_series(y)[0], range(sa.SEEDS)))
+    sa.assert_same_mean(a, b, "svol_bs mode A vs mode B")
+    af = sa.mode_a_bootstrap(oracle, oracle.MODEL_SVOL, th, 500, y, seed0=5000, fast_resampler=True)
+    sa.assert_same_mean(a, af, "svol_bs mn_resampler vs mn_resamp_fast1")
+
+
+def test_mode_a_vs_mode_b_leverage(oracle):
+    """The same anchor for svol_leverage (test/test_pswarm.cpp:80-134) with the covariate z_t = y_{t-1}."""
+    import stat_anchor as sa
+    th = [0.95, 0.0, 0.2, -0.3]
+    y, z = sa.sim_leverage(300, *th, seed=11)
+    a = sa.mode_a_bootstrap(oracle, oracle.MODEL_SVOL_LEVERAGE, th, 500, y, z)
+    b = np.array(sa.pmap(lambda s: oracle.Filter(oracle.MODEL_SVOL_LEVERAGE, 500, th, 1000 + s).run_series(y, z)[0],
+                         range(sa.SEEDS)))
+    sa.assert_same_mean(a, b, "svol_leverage mode A vs mode B")
+
+
+def test_mode_a_vs_mode_b_liu_west(oracle):
+    """The same anchor for the Liu-West filter: log-likelihood and the posterior means of all four parameters."""
+    import stat_anchor as sa
+    y, z = sa.sim_leverage(100, 0.95, 0.0, 0.05, -0.3, seed=9)
+    a = sa.mode_a_liu_west(oracle, 2000, y, z)
+
+    def one(s):
+        o = oracle.LWFilter(2000, 1000 + s)
+        for t in range(y.size):
+            o.step(y[t], z[t])
+        return (o.loglik,) + tuple(o.param_means())
+    b = np.array(sa.pmap(one, range(sa.SEEDS)))
+    sa.assert_same_mean(a, b, "Liu-West mode A vs mode B (loglik, phi, mu, sigma, rho)")
 
 
 def test_variance_scales_with_n(oracle, spy):

@@ -125,3 +125,48 @@ def test_exchange_tiles_gloo_world2():
     full = np.concatenate([np.arange(Bl * W, dtype=np.float64).reshape(Bl, W) + 1000.0 * r for r in range(2)])
     np.testing.assert_array_equal(got[0], full[0:5])
     np.testing.assert_array_equal(got[1], full[2:6])
+
+
+def _halo_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ssme_amd.sharded import HaloBuffer, exchange_halos
+    Bl, W, margin = 4, 8, 1
+    res = {}
+    # (a) both windows fit the margins; (b) rank 1's window reaches 2 tiles into rank 0 (over ITS margin only):
+    # the decision must be the same on both ranks (the grouping of sends/receives must not be mixed)
+    for name, plan in (("fits", [(0, 4), (3, 7)]), ("rank1_over", [(0, 4), (2, 7)])):
+        hb = HaloBuffer(Bl, W, margin, torch.device("cpu"), torch.float64)
+        hb.own().copy_(torch.arange(Bl * W, dtype=torch.float64).reshape(Bl, W) + 1000.0 * rank)
+        got = exchange_halos([hb], rank * Bl, plan, Bl, rank)
+        res[name] = (got, hb.buf.numpy().copy())
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_halos_decision_is_global_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [ctx.Process(target=_halo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Bl, W = 4, 8
+    full = np.concatenate([np.arange(Bl * W, dtype=np.float64).reshape(Bl, W) + 1000.0 * r for r in range(2)])
+    # fits: rank 0's window is tiles 0..4 (own 0..3 + right halo = tile 4), rank 1's 3..7 (left halo = tile 3)
+    assert got[0]["fits"][0] == (0, 5) and got[1]["fits"][0] == (3, 5)
+    np.testing.assert_array_equal(got[0]["fits"][1][1:6], full[0:5])
+    np.testing.assert_array_equal(got[1]["fits"][1][0:5], full[3:8])
+    # one rank over its margin => BOTH ranks report "does not fit" (and fall back to the assembled window together)
+    assert got[0]["rank1_over"][0] is None and got[1]["rank1_over"][0] is None

@@ -470,35 +470,33 @@ def test_liu_west_series_equals_steps_and_replicates(sa, oracle):
     g.close()
 
 
-def test_liu_west_recovers_parameters_like_reference_restatement(sa, oracle):
-    """Statistical: posterior means from the device filter agree with the mode-A (mt19937, reference-faithful)
-    restatement within Monte-Carlo error on a simulated leverage-SVOL series."""
-    rng = np.random.default_rng(9)
-    T, phi, mu, sig, rho = 200, 0.95, 0.0, 0.05, -0.3
-    x = np.zeros(T); y = np.zeros(T)
-    x[0] = mu + sig / np.sqrt(1 - phi * phi) * rng.normal()
-    y[0] = np.exp(x[0] / 2) * rng.normal()
-    for t in range(1, T):
-        x[t] = mu + phi * (x[t - 1] - mu) + rho * sig * y[t - 1] * np.exp(-x[t - 1] / 2) + sig * np.sqrt(1 - rho * rho) * rng.normal()
-        y[t] = np.exp(x[t] / 2) * rng.normal()
-    z = np.concatenate([[0.0], y[:-1]])
-    g = sa.svol_lw_1_par(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=20000, n_filters=4, seed=1)
-    ll = g.run_series(y, z)
-    pm = g.param_means()
-    ref = [oracle.lw_ref_run(20000, y, z, seed=s) for s in (1, 2, 3, 4)]
-    ll_ref = np.array([r[0] for r in ref]); pm_ref = np.array([r[2] for r in ref])
-    assert np.all(np.isfinite(ll))
-    assert abs(ll.mean() - ll_ref.mean()) < 4 * np.sqrt(ll.var() / 4 + ll_ref.var() / 4) + 0.5
-    assert np.all(np.abs(pm.mean(0) - pm_ref.mean(0)) < 4 * np.sqrt(pm.var(0) / 4 + pm_ref.var(0) / 4) + [0.01, 0.01, 0.005, 0.03])
-    g.close()
-
-
 def test_liu_west_rejects_bad_config(sa):
     from ssme_amd import SsmeError
     with pytest.raises(SsmeError):
         sa.svol_lw_1_par(1.5, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=100)      # delta outside (0,1]
     with pytest.raises(SsmeError):
         sa.svol_lw_1_par(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=0)
+
+
+def test_liu_west_sharded_handle_rejects_unsharded_entry_points(sa):
+    """A handle from ssme_lw_shard_create owns no particle buffers: the unsharded entry points must return
+    SSME_ERR_STATE instead of launching kernels through null pointers."""
+    import ctypes as C
+    from ssme_amd import _capi as capi
+    L = capi.lib()
+    cfg = capi.LwConfig(n_particles=4096, n_filters=1, seed=1, device=0, first_filter_id=0, delta=0.99)
+    cfg.transforms[:] = [2, 0, 3, 1]
+    cfg.prior_lo[:] = [0.8, -0.1, 0.01, -0.5]
+    cfg.prior_hi[:] = [0.99, 0.1, 0.1, -0.01]
+    h = C.c_void_p()
+    assert L.ssme_lw_shard_create(C.byref(cfg), 0, 1, C.byref(h)) == capi.OK
+    y = np.array([0.1, 0.2]); out = np.zeros(4)
+    assert L.ssme_lw_step(h, capi.dptr(y), capi.dptr(y), capi.dptr(out)) == capi.ERR_STATE
+    assert L.ssme_lw_run_series(h, capi.dptr(y), capi.dptr(y), 2, capi.dptr(out)) == capi.ERR_STATE
+    assert L.ssme_lw_get_param_means(h, capi.dptr(out)) == capi.ERR_STATE
+    assert L.ssme_lw_download_state(h, 0, capi.dptr(np.zeros(4096)), None, None, None, None, None) == capi.ERR_STATE
+    assert L.ssme_lw_set_debug(h, 1) == capi.ERR_STATE
+    assert L.ssme_lw_destroy(h) == capi.OK
 
 
 def test_set_seed_reuses_graph_and_matches_fresh_handle(sa, oracle, spy):

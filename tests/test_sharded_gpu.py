@@ -97,7 +97,9 @@ def _run_sharded_lw(tmp_path, world, n, T, seed, delta):
 
 
 @pytest.mark.parametrize("world,n,delta", [(2, 16384, 0.99), (4, 32768, 0.95), (2, 8192, 1.0),
-                                           (2, 2 * 300 * 2048, 0.99)])          # 600 tiles: split level-2
+                                           (2, 2 * 300 * 2048, 0.99),           # 600 tiles: split level-2
+                                           # BASELINE.json configs[4]'s per-GPU slice: 2^21 particles = 1024 tiles per rank
+                                           (2, 2 * 1024 * 2048, 0.99)])
 def test_sharded_liu_west_is_bit_identical_to_unsharded(tmp_path, spy, world, n, delta):
     """BASELINE.json configs[4] in small: Liu-West filter over G ranks == the unsharded filter (log-likelihoods, particles,
     transformed parameters), two window exchanges and one moment gather per step."""

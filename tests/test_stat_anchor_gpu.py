@@ -1,0 +1,73 @@
+"""GPU vs the reference-faithful restatement (oracle mode A: mt19937 + <random>, reference operation order) -- the only
+reference-facing evidence for filter outputs, at the strength SURVEY.md section 8d specifies: >= 200 seeds,
+|difference of mean log-likelihoods| <= 3 SE, no additive slack.  The 200 device filters are n_filters = 200 of ONE
+handle (one launch per step); the 200 mode-A filters run on the host cores in parallel threads.
+
+Filter outputs stay "parity unpinned" against the reference itself: its only fixtures for this path are
+test/test_pswarm.cpp:251-252 and test/test_liu_west.cpp:172,198-199 (loglike^2 > 0, E[42] = 42, uninitialised inputs)."""
+import numpy as np
+import pytest
+
+import stat_anchor as sa
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import ssme_amd
+    from ssme_amd import _capi
+    assert _capi.lib() is not None
+    return ssme_amd
+
+
+def test_svol_bs_device_vs_mode_a(dev, oracle, spy):
+    """svol_bs (example/univ_svol_bootstrap_filter.h:17-103), N = 500 as shipped (example/main.cpp:9), multinomial
+    resampling every step (estimate_univ_svol.h:119), first 300 rows of spy_returns.csv."""
+    th = [1.0, 0.95, 0.25]
+    y = spy[:300]
+    bank = dev.ParticleFilterBank(dev.MODEL_SVOL, 500, sa.SEEDS, seed=20260101)
+    bank.set_params(th)
+    g = bank.run_series(y)
+    bank.close()
+    a = sa.mode_a_bootstrap(oracle, oracle.MODEL_SVOL, th, 500, y)
+    sa.assert_same_mean(a, g, "svol_bs device vs mode A")
+
+
+def test_svol_bs_tiled_kernel_device_vs_mode_a(dev, oracle, spy):
+    """The same through the tiled step kernel with several tiles per filter (N = 5000: level-2 rescale + tile search)."""
+    th = [1.0, 0.95, 0.25]
+    y = spy[:100]
+    bank = dev.ParticleFilterBank(dev.MODEL_SVOL, 5000, sa.SEEDS, seed=7)
+    bank.set_params(th)
+    g = bank.run_series(y)
+    bank.close()
+    a = sa.mode_a_bootstrap(oracle, oracle.MODEL_SVOL, th, 5000, y)
+    sa.assert_same_mean(a, g, "svol_bs (N = 5000, tiled kernel) device vs mode A")
+
+
+def test_svol_leverage_device_vs_mode_a(dev, oracle):
+    """svol_leverage (test/test_pswarm.cpp:80-134) with z_t = y_{t-1}, on a series drawn from the model."""
+    th = [0.95, 0.0, 0.2, -0.3]
+    y, z = sa.sim_leverage(300, *th, seed=11)
+    bank = dev.ParticleFilterBank(dev.MODEL_SVOL_LEVERAGE, 500, sa.SEEDS, seed=99)
+    bank.set_params(th)
+    g = bank.run_series(y, z)
+    bank.close()
+    a = sa.mode_a_bootstrap(oracle, oracle.MODEL_SVOL_LEVERAGE, th, 500, y, z)
+    sa.assert_same_mean(a, g, "svol_leverage device vs mode A")
+
+
+@pytest.mark.parametrize("delta", [0.99, 0.95])
+def test_liu_west_device_vs_mode_a(dev, oracle, delta):
+    """Liu-West (liu_west_filter.h:971-1159, model test/test_liu_west.cpp:22-157): log-likelihood and the posterior
+    means of phi, mu, sigma, rho; 200 device filters in one handle against 200 mode-A seeds, 3 SE each, no slack."""
+    y, z = sa.sim_leverage(100, 0.95, 0.0, 0.05, -0.3, seed=9)
+    g = dev.svol_lw_1_par(delta, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=2000, n_filters=sa.SEEDS, seed=31)
+    ll = g.run_series(y, z)
+    pm = g.param_means()
+    g.close()
+    a = sa.mode_a_liu_west(oracle, 2000, y, z, delta=delta)
+    sa.assert_same_mean(a, np.column_stack([ll, pm]), f"Liu-West delta={delta} device vs mode A (loglik, phi, mu, sigma, rho)")
