@@ -10,16 +10,28 @@
 //       void filter(const osv&, const cvsv&, const std::vector<func>&); getExpectations(); getLogCondLike()
 //                                                                          include/ssme/pswarm_filter.h:380-388
 //   typedefs float_type, dynamic_matrix, func                              include/ssme/pswarm_filter.h:29,41,44
-// The classes are templated on the pack / vector types only through duck typing, so they compile with the
-// reference's Eigen-based param::pack and Eigen vectors as well as with plain stand-ins (tests/cpp).
-// Host std::function callbacks cannot run on the device: fs entries are SSME_H_* enums (include/ssme_pf.h).
-// Errors: std::invalid_argument / std::runtime_error, as the reference throws; NaN/-inf are values.
+// The classes are templated on the pack / vector / matrix types (duck typing), so they compile with the reference's
+// Eigen-based param::pack, Eigen vectors and Eigen dynamic matrices as well as with plain stand-ins (tests/cpp).
+// svol_leverage_gpu satisfies what the UNMODIFIED Swarm / SwarmWithCovs templates ask of ModType
+// (pswarm_filter.h:29-60,86-92,272-304,380-388): float_type / dynamic_matrix / func typedefs with func a
+// std::function returning a dynamic matrix, default ctor + copy-assign, filter(y, z, const std::vector<func>&),
+// std::vector<dynamic_matrix> getExpectations(), and -- through the optional `Base` template parameter -- inheritance
+// from pf::bases::pf_withcov_base<float_t,dimy,dimx,dimcov>, so that the static_assert at :352 holds as written.
+// Host std::function callbacks cannot run on the device.  Each h in fs is therefore PROBED on the host at six state
+// values: a function that is constant, x, x^2 or exp(x/2) there is served by the device functionals (SSME_H_*);
+// anything else is evaluated on the host over the downloaded particles and weights (ssme_pf_download_weights) --
+// correct for every h, fast for the common ones.  gpu_options::probe_functionals = false forces the host path.
+// Every model object draws its own random stream (the reference clock-seeds each object): the filter id defaults to a
+// process-wide counter.  Errors: std::invalid_argument / std::runtime_error, as the reference throws; NaN/-inf are values.
 #ifndef SSME_GPU_BSFILTER_GPU_HPP
 #define SSME_GPU_BSFILTER_GPU_HPP
 
+#include <atomic>
 #include <cmath>
 #include <cstddef>
+#include <functional>
 #include <fstream>
+#include <limits>
 #include <sstream>
 #include <cstdint>
 #include <memory>
@@ -62,23 +74,36 @@ struct gpu_options {
     int resampler = SSME_RESAMP_MULTINOMIAL;
     int resamp_sched = 1;
     int device = 0;
+    bool probe_functionals = true;   // recognise constant / x / x^2 / exp(x/2) functionals and run them on the device
 };
+
+// Filter id of a model object constructed without one: a process-wide counter, so that every object has its own random
+// stream under one seed (the reference seeds every sampler of every model object from the clock, liu_west_filter.h:75-76).
+constexpr unsigned auto_filter_id = 0xffffffffu;
+namespace detail {
+struct no_base {};
+inline unsigned resolve_filter_id(unsigned id) {
+    static std::atomic<unsigned> next{0};
+    return id == auto_filter_id ? next.fetch_add(1) : id;
+}
+}  // namespace detail
 
 // ---- svol_bs ---------------------------------------------------------------------------------------------
 template <std::size_t nparts, typename float_t = double>
 class svol_bs_gpu {
 public:
     using float_type = float_t;
-    svol_bs_gpu(const float_t& phi, const float_t& beta, const float_t& sigma, gpu_options o = gpu_options())
-        : h_(SSME_MODEL_SVOL, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device, 0) {
+    svol_bs_gpu(const float_t& phi, const float_t& beta, const float_t& sigma, gpu_options o = gpu_options(),
+                unsigned filter_id = auto_filter_id)
+        : h_(SSME_MODEL_SVOL, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device, detail::resolve_filter_id(filter_id)) {
         const double th[3] = {(double)beta, (double)phi, (double)sigma};
         check(ssme_pf_set_params(h_.get(), th, 3, 1), h_.get());
     }
     // ctor from a param::pack: order beta, phi, ss (univ_svol_bootstrap_filter.h:55-61)
     template <typename Pack>
-    explicit svol_bs_gpu(const Pack& pp, gpu_options o = gpu_options())
+    explicit svol_bs_gpu(const Pack& pp, gpu_options o = gpu_options(), unsigned filter_id = auto_filter_id)
         : svol_bs_gpu((float_t)pp.get_untrans_params(1, 1)(0), (float_t)pp.get_untrans_params(0, 0)(0),
-                      (float_t)std::sqrt((double)pp.get_untrans_params(2, 2)(0)), o) {}
+                      (float_t)std::sqrt((double)pp.get_untrans_params(2, 2)(0)), o, filter_id) {}
 
     template <typename Osv>
     void filter(const Osv& yt) {
@@ -95,38 +120,170 @@ private:
     float_t last_ = 0;
 };
 
-// ---- svol_leverage (BSFilterWC) ------------------------------------------------------------------------------
-template <std::size_t nparts, typename float_t = double, typename Mat = std::vector<std::vector<float_t>>>
-class svol_leverage_gpu {
+// ---- expectations of host-side functionals ---------------------------------------------------------------------
+// Shared by the swarm-member models below.  h: any callable Mat(const Ssv&) (the covariate, if any, already bound).
+namespace detail {
+template <typename float_t, typename Mat, typename Ssv>
+struct functional_engine {
+    // Which device functional reproduces h?  Probed at six states; exact agreement required (exp(x/2): 4 ulp).
+    // Returns SSME_H_* (and the factor to apply to the device value) or -1 = evaluate on the host.
+    template <typename H>
+    static int classify(const H& h, double* scale) {
+        static const double probes[6] = {-1.7, -0.3125, 0.0, 0.5625, 1.9, 3.25};
+        bool is_const = true, is_x = true, is_x2 = true, is_vol = true;
+        float_t c0 = 0;
+        for (int p = 0; p < 6; ++p) {
+            Ssv xv;
+            xv(0) = (float_t)probes[p];
+            const Mat m = h(xv);
+            if (m.rows() != 1 || m.cols() != 1) return -1;
+            const float_t v = m(0, 0), xx = xv(0);
+            if (p == 0) c0 = v;
+            is_const = is_const && (v == c0);
+            is_x = is_x && (v == xx);
+            is_x2 = is_x2 && (v == xx * xx);
+            const float_t e = (float_t)std::exp((float_t)0.5 * xx);
+            is_vol = is_vol && (std::fabs(v - e) <= 4 * std::numeric_limits<float_t>::epsilon() * e);
+        }
+        *scale = 1.0;
+        if (is_const) { *scale = (double)c0 / 42.0; return SSME_H_CONST42; }   // E[c] = c E[42] / 42 (a NaN filter stays NaN)
+        if (is_x) return SSME_H_X;
+        if (is_x2) return SSME_H_X2;
+        if (is_vol) return SSME_H_VOL;
+        return -1;
+    }
+    // sum_i h(x_i) w_i / sum_i w_i on the host, any matrix shape (twin liu_west_filter.h:1662-1683)
+    template <typename H>
+    static Mat host_expectation(const H& h, const std::vector<double>& x, const std::vector<double>& w) {
+        std::vector<double> acc;
+        long rows = 0, cols = 0;
+        double wsum = 0.0;
+        for (std::size_t i = 0; i < x.size(); ++i) {
+            Ssv xv;
+            xv(0) = (float_t)x[i];
+            const Mat hv = h(xv);
+            if (i == 0) { rows = (long)hv.rows(); cols = (long)hv.cols(); acc.assign((std::size_t)(rows * cols), 0.0); }
+            for (long r = 0; r < rows; ++r)
+                for (long c = 0; c < cols; ++c) acc[(std::size_t)(r * cols + c)] += (double)hv(r, c) * w[i];
+            wsum += w[i];
+        }
+        Mat m(rows, cols);
+        for (long r = 0; r < rows; ++r)
+            for (long c = 0; c < cols; ++c) m(r, c) = (float_t)(acc[(std::size_t)(r * cols + c)] / wsum);
+        return m;
+    }
+    // E[h_i] for every h of `hs` after the last step of single-filter handle `hd`: device functionals in one pass,
+    // everything else on the host over ONE download of (x, weights).
+    template <typename H>
+    static std::vector<Mat> expectations(ssme_pf_handle hd, const std::vector<H>& hs, std::size_t nparts, bool probe) {
+        std::vector<Mat> out;
+        if (hs.empty()) return out;
+        std::vector<int> kind(hs.size(), -1);
+        std::vector<double> scale(hs.size(), 1.0);
+        std::vector<int32_t> ids;
+        for (std::size_t i = 0; i < hs.size(); ++i) {
+            if (probe) kind[i] = classify(hs[i], &scale[i]);
+            if (kind[i] >= 0 && ids.size() == 4) kind[i] = -1;           // more than 4 device functionals: the rest on the host
+            if (kind[i] >= 0) ids.push_back(kind[i]);
+        }
+        std::vector<double> dev(ids.size());
+        if (!ids.empty()) check(ssme_pf_get_expectations_multi(hd, ids.data(), (int32_t)ids.size(), dev.data()), hd);
+        std::vector<double> x, w;
+        std::size_t d = 0;
+        for (std::size_t i = 0; i < hs.size(); ++i) {
+            if (kind[i] >= 0) {
+                Mat m(1, 1);
+                m(0, 0) = (float_t)(dev[d++] * scale[i]);
+                out.push_back(m);
+            } else {
+                if (w.empty()) {
+                    x.resize(nparts); w.resize(nparts);
+                    check(ssme_pf_download_weights(hd, 0, x.data(), w.data()), hd);
+                }
+                out.push_back(host_expectation(hs[i], x, w));
+            }
+        }
+        return out;
+    }
+};
+}  // namespace detail
+
+// ---- svol_leverage (BSFilterWC): a ModType for the unmodified SwarmWithCovs ------------------------------------------
+// Template parameters: Mat = the model's dynamic_matrix (Eigen::Matrix<float_t,-1,-1> in the reference), Osv / Ssv / Cvsv =
+// observation / state / covariate vectors (Eigen::Matrix<float_t,1,1>), Base = pf::bases::pf_withcov_base<float_t,1,1,1>
+// when the pf headers are present (its pure virtuals filter / getLogCondLike are overridden by the members below
+// [pf-recollection: pf_base.h]); detail::no_base otherwise.  Needs of the types: Mat(rows, cols), rows(), cols(),
+// operator()(i, j); vectors: default ctor, operator()(i).
+template <std::size_t nparts, typename float_t, typename Mat, typename Osv, typename Ssv, typename Cvsv,
+          typename Base = detail::no_base>
+class svol_leverage_gpu : public Base {
 public:
     using float_type = float_t;
     using dynamic_matrix = Mat;
-    using func = int;                 // SSME_H_* functional id instead of std::function
-    svol_leverage_gpu() = default;    // Swarm default-constructs its array of models (pswarm_filter.h:71)
+    using func = std::function<const Mat(const Ssv&, const Cvsv&)>;     // pf_withcov_base::func; what Swarm binds (:272-275)
+    svol_leverage_gpu() = default;    // Swarm default-constructs its array of models (pswarm_filter.h:71,367)
     svol_leverage_gpu(const float_t& phi, const float_t& mu, const float_t& sigma, const float_t& rho, unsigned /*dte*/ = 0,
-                      gpu_options o = gpu_options(), unsigned filter_id = 0)
-        : h_(SSME_MODEL_SVOL_LEVERAGE, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device, filter_id) {
+                      gpu_options o = gpu_options(), unsigned filter_id = auto_filter_id)
+        : h_(SSME_MODEL_SVOL_LEVERAGE, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device,
+             detail::resolve_filter_id(filter_id)), probe_(o.probe_functionals) {
         const double th[4] = {(double)phi, (double)mu, (double)sigma, (double)rho};
         check(ssme_pf_set_params(h_.get(), th, 4, 1), h_.get());
     }
-    template <typename Osv, typename Cvsv>
+    // BSFilterWC::filter(y_t, z_t, fs) as SwarmWithCovs::comp_func calls it (pswarm_filter.h:383)
     void filter(const Osv& yt, const Cvsv& zt, const std::vector<func>& fs = std::vector<func>()) {
         if (!h_) throw std::runtime_error("model not constructed");
         const double y = (double)yt(0), z = (double)zt(0);
         double out = 0.0;
         check(ssme_pf_step(h_.get(), &y, &z, &out), h_.get());
         last_ = (float_t)out;
-        expectations_.assign(fs.size(), 0.0);
-        for (std::size_t i = 0; i < fs.size(); ++i) check(ssme_pf_get_expectations(h_.get(), fs[i], &expectations_[i]), h_.get());
+        std::vector<std::function<const Mat(const Ssv&)>> hs;
+        for (const func& f : fs) hs.push_back([&f, &zt](const Ssv& xv) { return f(xv, zt); });
+        expectations_ = detail::functional_engine<float_t, Mat, Ssv>::expectations(h_.get(), hs, nparts, probe_);
     }
     float_t getLogCondLike() const { return last_; }
-    std::vector<double> getExpectations() const { return expectations_; }
+    std::vector<Mat> getExpectations() const { return expectations_; }   // E[h(x_t) | y_{1:t}], pre-resampling weights
     ssme_pf_handle native() const { return h_.get(); }
 
 private:
     handle h_;
+    bool probe_ = true;
     float_t last_ = 0;
-    std::vector<double> expectations_;
+    std::vector<Mat> expectations_;
+};
+
+// ---- svol_bs as a ModType for the unmodified Swarm (no covariates; pswarm_filter.h:23-320, comp_func :86-92) -----------
+// Base = pf::bases::pf_base<float_t,1,1> when pf is present.  Same model as svol_bs_gpu (ctor order phi, beta, sigma).
+template <std::size_t nparts, typename float_t, typename Mat, typename Osv, typename Ssv, typename Base = detail::no_base>
+class svol_bs_member_gpu : public Base {
+public:
+    using float_type = float_t;
+    using dynamic_matrix = Mat;
+    using func = std::function<const Mat(const Ssv&)>;                   // pf_base::func
+    svol_bs_member_gpu() = default;
+    svol_bs_member_gpu(const float_t& phi, const float_t& beta, const float_t& sigma, gpu_options o = gpu_options(),
+                       unsigned filter_id = auto_filter_id)
+        : h_(SSME_MODEL_SVOL, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device, detail::resolve_filter_id(filter_id)),
+          probe_(o.probe_functionals) {
+        const double th[3] = {(double)beta, (double)phi, (double)sigma};
+        check(ssme_pf_set_params(h_.get(), th, 3, 1), h_.get());
+    }
+    void filter(const Osv& yt, const std::vector<func>& fs = std::vector<func>()) {
+        if (!h_) throw std::runtime_error("model not constructed");
+        const double y = (double)yt(0);
+        double out = 0.0;
+        check(ssme_pf_step(h_.get(), &y, nullptr, &out), h_.get());
+        last_ = (float_t)out;
+        expectations_ = detail::functional_engine<float_t, Mat, Ssv>::expectations(h_.get(), fs, nparts, probe_);
+    }
+    float_t getLogCondLike() const { return last_; }
+    std::vector<Mat> getExpectations() const { return expectations_; }
+    ssme_pf_handle native() const { return h_.get(); }
+
+private:
+    handle h_;
+    bool probe_ = true;
+    float_t last_ = 0;
+    std::vector<Mat> expectations_;
 };
 
 // ---- log_like_eval with replicate batching -----------------------------------------------------------------
@@ -242,18 +399,8 @@ public:
     void update(const Osv& yt, const Csv& zt) {
         if (!h_) finish_construction();
         const double y = (double)yt(0), z = (double)zt(0);
-        std::vector<double> ll(n_param_parts), e(n_param_parts);
-        check(ssme_pf_step(h_.get(), &y, &z, ll.data()), h_.get());
-        double s = 0.0;
-        for (double v : ll) s += v;
-        log_cond_like_ = (float_t)(s / (double)n_param_parts);
-        expectations_.assign(fs_.size(), 0.0);
-        for (std::size_t i = 0; i < fs_.size(); ++i) {
-            check(ssme_pf_get_expectations(h_.get(), fs_[i], e.data()), h_.get());
-            double se = 0.0;
-            for (double v : e) se += v;
-            expectations_[i] = se / (double)n_param_parts;
-        }
+        check(ssme_pf_step(h_.get(), &y, &z, nullptr), h_.get());
+        aggregate();
         ++num_obs_;
     }
     float_t getLogCondLike() const { return log_cond_like_; }
@@ -261,6 +408,15 @@ public:
     const std::vector<double>& params() const { return theta_; }         // [n_param_parts][4]
 
 private:
+    // intra/inter_agg_func (pswarm_filter.h:96-160): plain means over the members, reduced on the device, one download
+    void aggregate() {
+        if (fs_.size() > 4) throw std::invalid_argument("at most 4 device functionals per swarm");
+        std::vector<int32_t> ids(fs_.begin(), fs_.end());
+        double lcl = 0.0;
+        expectations_.assign(fs_.size(), 0.0);
+        check(ssme_pf_swarm_aggregate(h_.get(), ids.data(), (int32_t)ids.size(), &lcl, expectations_.data()), h_.get());
+        log_cond_like_ = (float_t)lcl;
+    }
     void finish_construction() {                                  // pswarm_filter.h:280-304
         theta_.resize(n_param_parts * 4);
         for (std::size_t i = 0; i < n_param_parts; ++i) {
@@ -296,23 +452,22 @@ public:
     void update(const Osv& yt) {
         if (!h_) finish_construction();
         const double y = (double)yt(0);
-        std::vector<double> ll(n_param_parts), e(n_param_parts);
-        check(ssme_pf_step(h_.get(), &y, nullptr, ll.data()), h_.get());
-        double s = 0.0;
-        for (double v : ll) s += v;
-        log_cond_like_ = (float_t)(s / (double)n_param_parts);
-        expectations_.assign(fs_.size(), 0.0);
-        for (std::size_t i = 0; i < fs_.size(); ++i) {
-            check(ssme_pf_get_expectations(h_.get(), fs_[i], e.data()), h_.get());
-            double se = 0.0;
-            for (double v : e) se += v;
-            expectations_[i] = se / (double)n_param_parts;
-        }
+        check(ssme_pf_step(h_.get(), &y, nullptr, nullptr), h_.get());
+        aggregate();
     }
     float_t getLogCondLike() const { return log_cond_like_; }
     std::vector<double> getExpectations() const { return expectations_; }
 
 private:
+    // intra/inter_agg_func (pswarm_filter.h:96-160): plain means over the members, reduced on the device, one download
+    void aggregate() {
+        if (fs_.size() > 4) throw std::invalid_argument("at most 4 device functionals per swarm");
+        std::vector<int32_t> ids(fs_.begin(), fs_.end());
+        double lcl = 0.0;
+        expectations_.assign(fs_.size(), 0.0);
+        check(ssme_pf_swarm_aggregate(h_.get(), ids.data(), (int32_t)ids.size(), &lcl, expectations_.data()), h_.get());
+        log_cond_like_ = (float_t)lcl;
+    }
     void finish_construction() {
         std::vector<double> theta(n_param_parts * 3);
         for (std::size_t i = 0; i < n_param_parts; ++i) {

@@ -112,6 +112,18 @@ int ssme_pf_get_loglik(ssme_pf_handle h, double* out);
 /* E[h(x_t) | y_{1:t}] with the pre-resampling weights of the last step
  * (getExpectations(); twin liu_west_filter.h:1662-1683).  out: R values. */
 int ssme_pf_get_expectations(ssme_pf_handle h, int32_t functional, double* out);
+/* The same for n <= 4 built-in functionals at once (filter(y, z, fs) takes a VECTOR of functions, pswarm_filter.h:87):
+ * one pass over the particles, one download.  out[i*R + r] = E[h_i] of filter r. */
+int ssme_pf_get_expectations_multi(ssme_pf_handle h, const int32_t* functionals, int32_t n, double* out);
+/* Swarm::update's aggregation over the R member filters of this handle (pswarm_filter.h:96-160,233-235: uniform
+ * weights, i.e. plain means), reduced on the device: mean of the last step's log conditional likelihoods and mean of each
+ * requested expectation (n may be 0).  One download of n + 1 doubles. */
+int ssme_pf_swarm_aggregate(ssme_pf_handle h, const int32_t* functionals, int32_t n, double* mean_logcondlike /*1*/,
+                            double* mean_expectations /*n*/);
+/* Arbitrary host-side h (the reference's filt_func is a std::function, pswarm_filter.h:44,87-89): particles x (N,
+ * nullable) and weights w (N) of one filter after the last step, w_j = exp(logw_j - max logw) in the 2^-41 fixed point
+ * the resampler and ssme_pf_get_expectations use; the caller forms sum h(x_j) w_j / sum w_j.  Needs no debug mode. */
+int ssme_pf_download_weights(ssme_pf_handle h, int32_t filter, double* x, double* w);
 
 /* Replicate aggregation of thread_pool.h:263-268: log-mean-exp of the R log-likelihoods. */
 int ssme_pf_log_mean_exp(ssme_pf_handle h, double* out);

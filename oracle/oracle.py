@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libssme_oracle.so")
+_SO_O3 = os.path.join(_HERE, "libssme_oracle_o3.so")          # -O3 build, timed by bench.py's cpu_baseline only
 
 MODEL_SVOL, MODEL_SVOL_LEVERAGE, MODEL_LIN_GAUSS = 0, 1, 2
 RESAMP_MULTINOMIAL, RESAMP_SYSTEMATIC, RESAMP_STRATIFIED, RESAMP_MULTINOMIAL_IID = 0, 1, 2, 3
@@ -20,7 +21,7 @@ TILE = 2048
 
 def build(force=False):
     src = os.path.join(_HERE, "ssme_oracle.cpp")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    if force or any(not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src) for so in (_SO, _SO_O3)):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -230,14 +231,31 @@ class Filter:
         return lib().orc_pf_expectation(self._h, kind)
 
 
-def ref_run_series(model, theta, n, y, z=None, seed=1, use_float=False, fast_resampler=False):
-    """Mode A: mt19937 / <random> reference-faithful filter. Returns (loglik, per-step)."""
+_lib_o3 = None
+
+
+def _baseline_lib():
+    global _lib_o3
+    if _lib_o3 is None:
+        build()
+        L = C.CDLL(_SO_O3)
+        dp = C.POINTER(C.c_double)
+        L.orc_ref_run_series.restype = C.c_double
+        L.orc_ref_run_series.argtypes = [C.c_int, dp, C.c_int, dp, dp, C.c_int, C.c_uint32, C.c_int, C.c_int, dp]
+        _lib_o3 = L
+    return _lib_o3
+
+
+def ref_run_series(model, theta, n, y, z=None, seed=1, use_float=False, fast_resampler=False, o3=False):
+    """Mode A: mt19937 / <random> reference-faithful filter. Returns (loglik, per-step).
+    o3: run the -O3 build (bench.py's cpu_baseline; same source, the reference example's optimisation level)."""
     th = np.ascontiguousarray(theta, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64)
     z = None if z is None else np.ascontiguousarray(z, dtype=np.float64)
     per = np.empty(y.size)
-    ll = lib().orc_ref_run_series(model, _dp(th), n, _dp(y), _dp(z), y.size, seed, int(use_float),
-                                  int(fast_resampler), _dp(per))
+    L = _baseline_lib() if o3 else lib()
+    ll = L.orc_ref_run_series(model, _dp(th), n, _dp(y), _dp(z), y.size, seed, int(use_float),
+                              int(fast_resampler), _dp(per))
     return ll, per
 
 

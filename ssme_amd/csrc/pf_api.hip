@@ -47,6 +47,8 @@ struct ssme_pf_s {
     double* tsum[2];
     double* tmax[2];
     double *logw, *ybuf, *zbuf, *per_step, *scratchR;
+    double *exp_part, *exp_out;  // expectations: [R][Bs][4] per-tile numerators; [5][R] per-filter values + [5] means over filters
+    double* wscratch;            // [Npad] weights of one filter (host-side functionals), allocated on first use
     double *gam, *pgam, *gtot;   // Gamma tables of the multinomial resampler, gcap time rows
     uint32_t* anc;
     uint32_t* keybuf;        // [2] Philox key = seed (lo, hi)
@@ -414,9 +416,11 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
         HIPCHK(hipMalloc(&h->scal, sizeof(FilterScalars) * h->R));
         HIPCHK(hipMalloc(&h->mc, sizeof(ModelConst) * h->R));
         HIPCHK(hipMalloc(&h->scratchR, sizeof(double) * h->R));
+        HIPCHK(hipMalloc(&h->exp_part, sizeof(double) * (size_t)h->R * h->Bs * kMaxFunctionals));
+        HIPCHK(hipMalloc(&h->exp_out, sizeof(double) * ((size_t)(kMaxFunctionals + 1) * h->R + kMaxFunctionals + 1)));
         HIPCHK(hipMalloc(&h->keybuf, sizeof(uint32_t) * 2));
         HIPCHK(hipMalloc(&h->yz_step, sizeof(double) * 2));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pin), sizeof(double) * (2 + (size_t)h->R + 64), hipHostMallocDefault));   // + 128 ints for the shard plan
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pin), sizeof(double) * (2 + (size_t)h->R + 64 + 8), hipHostMallocDefault));   // + 128 ints for the shard plan + 8 swarm aggregates
         int rc2 = upload_key(h);
         if (rc2 != SSME_OK) return rc2;
         if (h->shard_world > 0) return ensure_series_capacity(h, 1);
@@ -436,7 +440,7 @@ int ssme_pf_destroy(ssme_pf_handle h) {
     h->stream = h->own_stream;
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     void* bufs[] = {h->x[0], h->x[1], h->cdf[0], h->cdf[1], h->tsum[0], h->tsum[1], h->tmax[0], h->tmax[1], h->logw,
-                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_lo, h->l2_hi, h->yz_step};
+                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_lo, h->l2_hi, h->yz_step, h->exp_part, h->exp_out, h->wscratch};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->pin) hipHostFree(h->pin);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -776,15 +780,81 @@ int ssme_pf_log_mean_exp(ssme_pf_handle h, double* out) {
     return SSME_OK;
 }
 
-int ssme_pf_get_expectations(ssme_pf_handle h, int32_t functional, double* out) {
-    if (!h || !out || functional < 0 || functional > SSME_H_CONST42) return SSME_ERR_INVALID_ARG;
+// per-filter expectations of n built-in functionals into exp_out rows 0..n-1 (device); three small launches, no sync
+static int enqueue_expectations(ssme_pf_handle h, const int32_t* functionals, int32_t n) {
+    if (n < 1 || n > kMaxFunctionals) return SSME_ERR_INVALID_ARG;
+    FunctionalIds fs{};
+    fs.n = n;
+    for (int i = 0; i < n; ++i) {
+        if (functionals[i] < 0 || functionals[i] > SSME_H_CONST42) return SSME_ERR_INVALID_ARG;
+        fs.id[i] = functionals[i];
+    }
+    hipLaunchKernelGGL(k_expect_partials, dim3(h->B, h->R), dim3(kThreads), 0, h->stream, h->x[h->cur], h->cdf[h->cur], h->N,
+                       h->Npad, h->Bs, fs, h->exp_part);
+    hipLaunchKernelGGL(k_expect_final, dim3(h->R), dim3(kThreads), 0, h->stream, h->exp_part, h->tsum[h->cur], h->tmax[h->cur],
+                       h->B, h->Bs, h->R, fs, h->exp_out);
+    HIPCHK(hipGetLastError());
+    return SSME_OK;
+}
+
+int ssme_pf_get_expectations_multi(ssme_pf_handle h, const int32_t* functionals, int32_t n, double* out) {
+    if (!h || !out || !functionals) return SSME_ERR_INVALID_ARG;
     if (h->shard_world > 0) return SSME_ERR_STATE;
     if (h->t < 1) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(k_expectation, dim3(h->R), dim3(kThreads), 0, h->stream, h->x[h->cur], h->cdf[h->cur],
-                       h->tmax[h->cur], h->N, h->Npad, h->B, h->Bs, functional, h->scratchR);
+    int rc = enqueue_expectations(h, functionals, n);
+    if (rc != SSME_OK) return rc;
+    HIPCHK(hipMemcpyAsync(out, h->exp_out, sizeof(double) * (size_t)n * h->R, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SSME_OK;
+}
+
+int ssme_pf_get_expectations(ssme_pf_handle h, int32_t functional, double* out) {
+    return ssme_pf_get_expectations_multi(h, &functional, 1, out);
+}
+
+// Swarm::update's aggregation (pswarm_filter.h:96-160,233-235): the plain means over the R member filters of the last
+// step's log conditional likelihoods and of the expectations, reduced ON THE DEVICE; one download of n + 1 doubles.
+int ssme_pf_swarm_aggregate(ssme_pf_handle h, const int32_t* functionals, int32_t n, double* mean_logcondlike,
+                            double* mean_expectations) {
+    if (!h || !mean_logcondlike || n < 0 || n > kMaxFunctionals || (n > 0 && (!functionals || !mean_expectations)))
+        return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;
+    if (h->t < 1) return SSME_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (n > 0) {
+        int rc = enqueue_expectations(h, functionals, n);
+        if (rc != SSME_OK) return rc;
+    }
+    double* ll_row = h->exp_out + (size_t)kMaxFunctionals * h->R;            // row 4: the members' log conditional likelihoods
+    double* means = h->exp_out + (size_t)(kMaxFunctionals + 1) * h->R;       // [5]
+    hipLaunchKernelGGL(k_collect_last_ll, dim3((h->R + 255) / 256), dim3(256), 0, h->stream, (const FilterScalars*)h->scal, ll_row, h->R);
+    if (n > 0) hipLaunchKernelGGL(k_rows_mean, dim3(n), dim3(kThreads), 0, h->stream, (const double*)h->exp_out, h->R, means);
+    hipLaunchKernelGGL(k_rows_mean, dim3(1), dim3(kThreads), 0, h->stream, (const double*)ll_row, h->R, means + kMaxFunctionals);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, h->scratchR, sizeof(double) * h->R, hipMemcpyDeviceToHost, h->stream));
+    double* pin = h->pin + 2 + h->R + 64;
+    HIPCHK(hipMemcpyAsync(pin, means, sizeof(double) * (kMaxFunctionals + 1), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(wait_stream_low_latency(h->stream));
+    *mean_logcondlike = pin[kMaxFunctionals];
+    for (int i = 0; i < n; ++i) mean_expectations[i] = pin[i];
+    return SSME_OK;
+}
+
+// Particles and normalisable weights of one filter after the last step, for functionals that cannot run on the device
+// (arbitrary std::function h, pswarm_filter.h:44): w_j = exp(logw_j - max logw) up to the 2^-41 fixed point -- the same
+// weights the device expectations and the resampler use.  No debug mode needed (the weights are rebuilt from the cdf).
+int ssme_pf_download_weights(ssme_pf_handle h, int32_t f, double* x, double* w) {
+    if (!h || f < 0 || f >= h->R || !w) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;
+    if (h->t < 1) return SSME_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (!h->wscratch) HIPCHK(hipMalloc(&h->wscratch, sizeof(double) * (size_t)h->Npad));
+    const size_t off = (size_t)f * h->Npad;
+    hipLaunchKernelGGL(k_weights, dim3(h->B), dim3(kThreads), 0, h->stream, (const double*)(h->cdf[h->cur] + off),
+                       (const double*)(h->tmax[h->cur] + (size_t)f * h->Bs), h->N, h->B, h->wscratch);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(w, h->wscratch, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (x) HIPCHK(hipMemcpyAsync(x, h->x[h->cur] + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SSME_OK;
 }

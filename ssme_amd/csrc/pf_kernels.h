@@ -1041,38 +1041,113 @@ __global__ __launch_bounds__(kThreads) void k_gamma_prefix_rows(const double* ga
 }
 
 // ---------------------------------------------------------------------------------------
-// Weighted expectation of a built-in functional with the last step's weights
-// (getExpectations(); twin liu_west_filter.h:1662-1683).  grid = (R), block = 256.
-// Weights are the fixed-point weights the resampler uses: w_j = q_j * exp(m_tile - m),
-// q_j = cdf_j - cdf_{j-1}.  Partial sums: per-thread strided, wave tree, 4 waves in order.
+// Weighted expectations of built-in functionals with the last step's (pre-resampling) weights
+// (getExpectations(); twin liu_west_filter.h:1662-1683; callers pswarm_filter.h:87-89,383-385).
+// The weights are the fixed-point weights the resampler uses: w_j = q_j exp(m_tile - m), q_j = cdf_j - cdf_{j-1}.
+//   k_expect_partials  grid (B tiles, R): per tile sum_j h_f(x_j) q_j for ALL requested functionals at once (the tile's
+//                      denominator sum_j q_j is its exact integer tile sum A_b, already in memory); every CU takes part
+//   k_expect_final     grid (R): E_f = sum_b num_{b,f} e^{m_b - m} / sum_b A_b e^{m_b - m}
+//   k_expect_mean      grid (1): the swarm aggregate, the plain mean over the R members (pswarm_filter.h:103,136)
+// Summation trees are fixed (per-thread strided, wave xor tree, waves in order), so results are reproducible.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_expectation(const double* x, const double* cdf, const double* tmax, int N, int Npad,
-                                                          int B, int Bs, int functional, double* out) {
-    __shared__ double lds_n[4], lds_d[4];
+constexpr int kMaxFunctionals = 4;
+struct FunctionalIds { int32_t n; int32_t id[kMaxFunctionals]; };
+
+__device__ __forceinline__ double builtin_h(int functional, double xv) {
+    return functional == 0 ? xv : functional == 1 ? xv * xv : functional == 2 ? dexp(0.5 * xv) : 42.0;
+}
+__device__ __forceinline__ double wave_sum_xor(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, kWave);
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void k_expect_partials(const double* x, const double* cdf, int N, int Npad, int Bs,
+                                                              FunctionalIds fs, double* part /*[R][Bs][kMaxFunctionals]*/) {
+    __shared__ double lds[kMaxFunctionals][4];
+    const int tid = threadIdx.x, b = blockIdx.x, r = blockIdx.y;
+    const double* xr = x + (size_t)r * Npad + (size_t)b * kTile;
+    const double* cr = cdf + (size_t)r * Npad + (size_t)b * kTile;
+    const int nvalid = (N - b * kTile) < kTile ? (N - b * kTile) : kTile;
+    double num[kMaxFunctionals] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < kTile / kThreads; ++k) {
+        const int j = k * kThreads + tid;
+        if (j < nvalid) {
+            const double q = cr[j] - (j ? cr[j - 1] : 0.0);
+            const double xv = xr[j];
+#pragma unroll
+            for (int f = 0; f < kMaxFunctionals; ++f)
+                if (f < fs.n) num[f] = num[f] + builtin_h(fs.id[f], xv) * q;
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < kMaxFunctionals; ++f) {
+        num[f] = wave_sum_xor(num[f]);
+        if ((tid & 63) == 0) lds[f][tid >> 6] = num[f];
+    }
+    __syncthreads();
+    if (tid < kMaxFunctionals)
+        part[((size_t)r * Bs + b) * kMaxFunctionals + tid] = ((lds[tid][0] + lds[tid][1]) + lds[tid][2]) + lds[tid][3];
+}
+
+__global__ __launch_bounds__(kThreads) void k_expect_final(const double* part, const double* tsum, const double* tmax, int B, int Bs,
+                                                           int R, FunctionalIds fs, double* out /*[n][R]*/) {
+    __shared__ double lds[kMaxFunctionals + 1][4];
     __shared__ double lds_m[16];
     const int tid = threadIdx.x, r = blockIdx.x;
     double mx = -dinf();
     bool nan = false;
     for (int j = tid; j < B; j += kThreads) { const double v = tmax[(size_t)r * Bs + j]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
     const double m = block_max_nanprop<kThreads>(mx, nan, lds_m);
-    double num = 0.0, den = 0.0;
-    for (int i = tid; i < N; i += kThreads) {
-        const double c1 = cdf[(size_t)r * Npad + i];
-        const double c0 = (i & (kTile - 1)) ? cdf[(size_t)r * Npad + i - 1] : 0.0;
-        const double w = (c1 - c0) * dexp(tmax[(size_t)r * Bs + i / kTile] - m);
-        const double xv = x[(size_t)r * Npad + i];
-        const double hv = functional == 0 ? xv : functional == 1 ? xv * xv : functional == 2 ? dexp(0.5 * xv) : 42.0;
-        num = num + hv * w;
-        den = den + w;
+    double acc[kMaxFunctionals + 1] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int j = tid; j < B; j += kThreads) {
+        const double sc = dexp(tmax[(size_t)r * Bs + j] - m);
+#pragma unroll
+        for (int f = 0; f < kMaxFunctionals; ++f)
+            if (f < fs.n) acc[f] = acc[f] + part[((size_t)r * Bs + j) * kMaxFunctionals + f] * sc;
+        acc[kMaxFunctionals] = acc[kMaxFunctionals] + tsum[(size_t)r * Bs + j] * sc;
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { num = num + __shfl_xor(num, d, kWave); den = den + __shfl_xor(den, d, kWave); }
-    if ((tid & 63) == 0) { lds_n[tid >> 6] = num; lds_d[tid >> 6] = den; }
+    for (int f = 0; f <= kMaxFunctionals; ++f) {
+        acc[f] = wave_sum_xor(acc[f]);
+        if ((tid & 63) == 0) lds[f][tid >> 6] = acc[f];
+    }
     __syncthreads();
-    if (tid == 0) {
-        const double n4 = ((lds_n[0] + lds_n[1]) + lds_n[2]) + lds_n[3];
-        const double d4 = ((lds_d[0] + lds_d[1]) + lds_d[2]) + lds_d[3];
-        out[r] = n4 / d4;
+    if (tid < fs.n) {
+        const double n4 = ((lds[tid][0] + lds[tid][1]) + lds[tid][2]) + lds[tid][3];
+        const double d4 = ((lds[kMaxFunctionals][0] + lds[kMaxFunctionals][1]) + lds[kMaxFunctionals][2]) + lds[kMaxFunctionals][3];
+        out[(size_t)tid * R + r] = (m != m) ? dnan() : n4 / d4;
+    }
+}
+
+// mean over the R rows of each of n_rows series: in [n_rows][R] -> out [n_rows]   (swarm aggregation on the device)
+__global__ __launch_bounds__(kThreads) void k_rows_mean(const double* in, int R, double* out) {
+    __shared__ double lds[4];
+    const int tid = threadIdx.x, f = blockIdx.x;
+    double s = 0.0;
+    for (int r = tid; r < R; r += kThreads) s = s + in[(size_t)f * R + r];
+    s = wave_sum_xor(s);
+    if ((tid & 63) == 0) lds[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) out[f] = (((lds[0] + lds[1]) + lds[2]) + lds[3]) / (double)R;
+}
+
+// Normalisable weights of one filter for host-side functionals (arbitrary std::function h: pswarm_filter.h:44,87-89):
+// w_j = q_j exp(m_tile - m) 2^-41  (= exp(logw_j - max logw) to 2^-41).  grid (B), block 256.
+__global__ __launch_bounds__(kThreads) void k_weights(const double* cdf, const double* tmax, int N, int B, double* w) {
+    __shared__ double lds_m[16];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    double mx = -dinf();
+    bool nan = false;
+    for (int j = tid; j < B; j += kThreads) { const double v = tmax[j]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
+    const double m = block_max_nanprop<kThreads>(mx, nan, lds_m);
+    const double sc = (m != m) ? dnan() : dexp_scaled(tmax[b] - m, -kTileShift);
+    const double* cr = cdf + (size_t)b * kTile;
+#pragma unroll
+    for (int k = 0; k < kTile / kThreads; ++k) {
+        const int j = k * kThreads + tid;
+        if (b * kTile + j < N) w[(size_t)b * kTile + j] = (cr[j] - (j ? cr[j - 1] : 0.0)) * sc;
     }
 }
 

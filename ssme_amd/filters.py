@@ -116,6 +116,28 @@ class ParticleFilterBank:
         self._chk(capi.lib().ssme_pf_get_expectations(self._h, functional, capi.dptr(out)))
         return out
 
+    def expectations_multi(self, functionals):
+        """E[h_i] of every filter for up to 4 built-in functionals in one pass: [n, R]."""
+        fs = np.ascontiguousarray(functionals, dtype=np.int32)
+        out = np.empty((fs.size, self.r))
+        self._chk(capi.lib().ssme_pf_get_expectations_multi(self._h, fs.ctypes.data_as(C.POINTER(C.c_int32)), fs.size,
+                                                            capi.dptr(out)))
+        return out
+
+    def swarm_aggregate(self, functionals=()):
+        """(mean over filters of the last log conditional likelihoods, [mean expectations]) reduced on the device."""
+        fs = np.ascontiguousarray(functionals, dtype=np.int32)
+        ll, ex = np.empty(1), np.empty(max(fs.size, 1))
+        self._chk(capi.lib().ssme_pf_swarm_aggregate(self._h, fs.ctypes.data_as(C.POINTER(C.c_int32)), fs.size,
+                                                     capi.dptr(ll), capi.dptr(ex)))
+        return float(ll[0]), ex[:fs.size].tolist()
+
+    def weights(self, f=0):
+        """(x, w) of filter f after the last step for host-side functionals: w = exp(logw - max logw)."""
+        x, w = np.empty(self.n), np.empty(self.n)
+        self._chk(capi.lib().ssme_pf_download_weights(self._h, f, capi.dptr(x), capi.dptr(w)))
+        return x, w
+
     def state(self, f=0, ancestors=False, logw=True):
         """Parity/debug view of filter f after the last step (cdf and tile sums are exact uint64)."""
         n = self.n
@@ -166,8 +188,21 @@ class _SingleFilter:
         return self._last
 
     def getExpectations(self):
-        """fs given to filter() are SSME_H_* enums (std::function cannot run on device)."""
-        return [float(self._bank.expectations(f)[0]) for f in self._fs]
+        """fs given to filter(): SSME_H_* ids run on the device in one pass; anything callable (the reference's
+        std::function h, pswarm_filter.h:44) is evaluated on the host over the downloaded (x, weights)."""
+        ids = [f for f in self._fs if not callable(f)]
+        dev = iter(self._bank.expectations_multi(ids)[:, 0].tolist()) if ids else iter(())
+        xw = None
+        out = []
+        for f in self._fs:
+            if callable(f):
+                if xw is None:
+                    xw = self._bank.weights(0)
+                hv = np.array([np.asarray(f(xi), dtype=np.float64) for xi in xw[0]])
+                out.append(np.tensordot(xw[1], hv, axes=(0, 0)) / xw[1].sum())
+            else:
+                out.append(float(next(dev)))
+        return out
 
     @property
     def bank(self):
@@ -257,10 +292,8 @@ class SwarmWithCovs:
     def update(self, y, z=0.0):
         if self._bank is None:
             self._finish_construction()
-        ll = self._bank.step(float(np.ravel(y)[0]), float(np.ravel(z)[0]))
-        self._member_lcl = ll
-        self._lcl = float(np.sum(ll) / ll.size)
-        self._exp = [float(np.sum(self._bank.expectations(f)) / ll.size) for f in self._fs]
+        self._member_lcl = self._bank.step(float(np.ravel(y)[0]), float(np.ravel(z)[0]))
+        self._lcl, self._exp = self._bank.swarm_aggregate(self._fs)      # means over members, reduced on the device
         self.num_obs += 1
 
     def getLogCondLike(self):
@@ -283,10 +316,8 @@ class Swarm(SwarmWithCovs):
     def update(self, y):
         if self._bank is None:
             self._finish_construction()
-        ll = self._bank.step(float(np.ravel(y)[0]), None)
-        self._member_lcl = ll
-        self._lcl = float(np.sum(ll) / ll.size)
-        self._exp = [float(np.sum(self._bank.expectations(f)) / ll.size) for f in self._fs]
+        self._member_lcl = self._bank.step(float(np.ravel(y)[0]), None)
+        self._lcl, self._exp = self._bank.swarm_aggregate(self._fs)
         self.num_obs += 1
 
 

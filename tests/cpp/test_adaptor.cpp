@@ -7,17 +7,44 @@
 #include <vector>
 
 #include "../../include/ssme_gpu/bsfilter_gpu.hpp"
+#include "swarm_shape.hpp"
 
-struct vec1 {                          // stand-in for Eigen::Matrix<double,1,1>
-    double v;
-    double operator()(int) const { return v; }
-};
+using vec1 = shape::vec1<double>;      // stand-in for Eigen::Matrix<double,1,1>
+using Mat = shape::dynmat<double>;     // stand-in for Eigen::Matrix<double,Dynamic,Dynamic>
 struct pack3 {                         // stand-in for param::pack<double,3>::get_untrans_params(i,i)
     double p[3];
     vec1 get_untrans_params(unsigned a, unsigned) const { return vec1{p[a]}; }
 };
 
-// svol_swarm_1 of test/test_pswarm.cpp:146-208 with a deterministic stand-in for its uniform prior samplers
+// ---- the model types handed to the (structurally restated) UNMODIFIED swarm templates ----
+using lev_mod = ssme_gpu::svol_leverage_gpu<600, double, Mat, vec1, vec1, vec1, shape::pf_withcov_base_like<double>>;
+using bs_mod = ssme_gpu::svol_bs_member_gpu<400, double, Mat, vec1, vec1, shape::pf_base_like<double>>;
+
+// svol_swarm_1 of test/test_pswarm.cpp:146-208 on the swarm template's own terms: samp_untrans_params +
+// instantiate_mod overrides, filter functions given as std::function (lambda) objects
+struct unmodified_swarm : shape::swarm_with_covs_shape<lev_mod, 3, 5> {
+    using base = shape::swarm_with_covs_shape<lev_mod, 3, 5>;
+    using base::base;
+    int k = 0;
+    ssme_gpu::gpu_options opt;
+    psv samp_untrans_params() override {
+        const double u = 0.1 + 0.2 * k;
+        psv p;
+        p(0) = 0.8 + 0.19 * u; p(1) = -0.1 + 0.2 * u; p(2) = 0.01 + 0.09 * u; p(3) = -0.5 + 0.49 * u;
+        return p;
+    }
+    lev_mod instantiate_mod(const psv& th) override { return lev_mod(th(0), th(1), th(2), th(3), 10, opt, (unsigned)k++); }
+};
+struct unmodified_swarm_nocov : shape::swarm_shape<bs_mod, 1, 3> {
+    using base = shape::swarm_shape<bs_mod, 1, 3>;
+    using base::base;
+    int k = 0;
+    ssme_gpu::gpu_options opt;
+    psv samp_untrans_params() override { const double u = 0.2 + 0.3 * k; psv p; p(0) = 0.9 + 0.05 * u; p(1) = 0.8 + 0.4 * u; p(2) = 0.2 + 0.1 * u; return p; }
+    bs_mod instantiate_mod(const psv& th) override { return bs_mod(th(0), th(1), th(2), opt, (unsigned)k++); }
+};
+
+// the batched fast path: all members in one handle
 struct test_swarm : ssme_gpu::swarm_with_covs_gpu<600, 5, double> {
     using ssme_gpu::swarm_with_covs_gpu<600, 5, double>::swarm_with_covs_gpu;
     int k = 0;
@@ -43,7 +70,7 @@ int main(int argc, char** argv) {
     o.seed = 77;
     // (1) the log_like_eval loop with the model object (estimate_univ_svol.h:119-127)
     pack3 theta{{1.0, 0.95, 0.0625}};                    // beta, phi, ss
-    ssme_gpu::svol_bs_gpu<500, double> mod(theta, o);
+    ssme_gpu::svol_bs_gpu<500, double> mod(theta, o, 0);
     double logLike = 0.0;
     for (size_t row = 0; row < data.size(); ++row) {
         mod.filter(data[row]);
@@ -53,15 +80,31 @@ int main(int argc, char** argv) {
     // (2) replicate-batched evaluation
     std::printf("log_like_eval_gpu %.17g\n", ssme_gpu::log_like_eval_gpu(theta, data, 500, 4, o));
     // (3) covariate model as Swarm::comp_func calls it (pswarm_filter.h:380-388)
-    ssme_gpu::svol_leverage_gpu<1000> lev(0.9, 0.0, 1.0, -0.1, 0, o, 3), lev2;
+    using lev1000 = ssme_gpu::svol_leverage_gpu<1000, double, Mat, vec1, vec1, vec1>;
+    lev1000 lev(0.9, 0.0, 1.0, -0.1, 0, o, 3), lev2;
     lev2 = lev;                                          // copy-assignable, default-constructible
+    // the reference test's constant lambda (test/test_pswarm.cpp:239-243), the state itself, and a function no device
+    // functional covers (2x2 matrix-valued, uses the covariate): host path over the downloaded (x, weights)
+    std::vector<lev1000::func> hs;
+    hs.push_back([](const vec1&, const vec1&) -> const Mat { vec1 ans; ans(0) = 42.0; return ans; });
+    hs.push_back([](const vec1& xt, const vec1&) -> const Mat { Mat m(1, 1); m(0, 0) = xt(0); return m; });
+    hs.push_back([](const vec1& xt, const vec1& zt) -> const Mat {
+        Mat m(2, 2); m(0, 0) = xt(0); m(0, 1) = xt(0) * xt(0); m(1, 0) = zt(0); m(1, 1) = std::sin(xt(0)); return m; });
     double ll = 0.0;
     for (size_t row = 0; row < 8; ++row) {
-        lev2.filter(data[row], vec1{row ? data[row - 1].v : 0.0}, {SSME_H_CONST42, SSME_H_X});
+        lev2.filter(data[row], vec1{row ? data[row - 1].v : 0.0}, hs);
         ll += lev2.getLogCondLike();
     }
     std::printf("svol_leverage %.17g\n", ll);
-    std::printf("expect42 %.17g\n", lev2.getExpectations()[0]);
+    {
+        const std::vector<Mat> e = lev2.getExpectations();
+        std::printf("expect42 %.17g\n", e[0](0, 0));
+        std::printf("expectx %.17g\n", e[1](0, 0));
+        std::printf("host_x %.17g\nhost_x2 %.17g\nhost_z %.17g\nhost_sin %.17g\n", e[2](0, 0), e[2](0, 1), e[2](1, 0), e[2](1, 1));
+        double x2dev = 0.0;
+        ssme_gpu::check(ssme_pf_get_expectations(lev2.native(), SSME_H_X2, &x2dev));
+        std::printf("dev_x2 %.17g\n", x2dev);
+    }
     // (5) persistent evaluator (one handle, fresh stream per call) == a fresh model with that seed
     ssme_gpu::svol_log_like_evaluator ev(data, 500, 4, o);
     ev(theta, 5);                                        // some other stream first
@@ -92,6 +135,34 @@ int main(int argc, char** argv) {
     double snll = 0.0;
     for (size_t row = 0; row < 4; ++row) { sn.update(data[row]); snll += sn.getLogCondLike(); }
     std::printf("swarm_nocov %.17g\n", snll);
+    // (10) the UNMODIFIED swarm templates' requirements on ModType (swarm_shape.hpp restates pswarm_filter.h:29-60,86-92,
+    //      272-304,380-388): typedefs, static_assert on the pf base, std::bind into filt_func, vector<DynMat> assignment
+    {
+        using sw_t = unmodified_swarm;
+        std::vector<sw_t::state_cov_parm_func> fs;
+        fs.push_back([](const vec1&, const vec1&, const shape::vec4<double>&) -> const Mat { vec1 ans; ans(0) = 42.0; return ans; });
+        fs.push_back([](const vec1& xt, const vec1&, const shape::vec4<double>&) -> const Mat { vec1 ans; ans(0) = xt(0); return ans; });
+        fs.push_back([](const vec1& xt, const vec1&, const shape::vec4<double>& pt) -> const Mat {   // uses the member's parameters
+            vec1 ans; ans(0) = pt(1) + xt(0); return ans; });
+        sw_t usw(fs);
+        usw.opt = o;
+        double ull = 0.0;
+        for (size_t row = 0; row < 5; ++row) {
+            usw.update(data[row], vec1{row ? data[row - 1].v : 0.0});
+            ull += usw.getLogCondLike();
+        }
+        std::printf("uswarm %.17g\n", ull);
+        std::printf("uswarm42 %.17g\n", usw.getExpectations()[0](0, 0));
+        std::printf("uswarmx %.17g\n", usw.getExpectations()[1](0, 0));
+        std::printf("uswarmmux %.17g\n", usw.getExpectations()[2](0, 0));
+        std::vector<unmodified_swarm_nocov::state_parm_func> gs;
+        gs.push_back([](const vec1& xt, const shape::vec4<double>&) -> const Mat { vec1 ans; ans(0) = xt(0); return ans; });
+        unmodified_swarm_nocov un(gs);
+        un.opt = o;
+        double unll = 0.0;
+        for (size_t row = 0; row < 4; ++row) { un.update(data[row]); unll += un.getLogCondLike(); }
+        std::printf("uswarm_nocov %.17g\n", unll);
+    }
     // (4) error mapping
     try { std::vector<vec1> empty; ssme_gpu::log_like_eval_gpu(theta, empty, 100, 1, o); std::printf("no-throw\n"); }
     catch (const std::length_error&) { std::printf("length_error ok\n"); }

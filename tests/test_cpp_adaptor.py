@@ -37,6 +37,14 @@ def test_adaptor_matches_oracle(oracle, spy):
     z = np.concatenate([[0.0], y[:-1]])
     assert float(vals["svol_leverage"]) == sum(ol.step(y[t], z[t]) for t in range(8))
     assert abs(float(vals["expect42"]) - 42.0) < 1e-4
+    # probed functionals (device) and the host path over the downloaded (x, weights) agree with the oracle / each other
+    assert abs(float(vals["expectx"]) - ol.expectation(0)) <= 1e-12 * abs(ol.expectation(0))
+    assert abs(float(vals["host_x"]) - float(vals["expectx"])) <= 1e-12 * abs(float(vals["expectx"]))
+    assert abs(float(vals["host_x2"]) - float(vals["dev_x2"])) <= 1e-12 * abs(float(vals["dev_x2"]))
+    assert float(vals["host_z"]) == z[7] and abs(float(vals["host_sin"])) <= 1.0
+    so = ol.state()
+    wo = np.exp(so["logw"] - so["logw"].max())
+    assert abs(float(vals["host_sin"]) - (np.sin(so["x"]) * wo).sum() / wo.sum()) < 1e-9
     assert vals["length_error"].strip() == "ok"
     assert abs(float(vals["evaluator"]) - oracle.log_mean_exp(np.array(lls))) < 1e-12
     lw = oracle.LWFilter(800, 77)
@@ -61,6 +69,13 @@ def test_adaptor_matches_oracle(oracle, spy):
         mem.append(oracle.Filter(oracle.MODEL_SVOL, 400, [0.8 + 0.4 * u, 0.9 + 0.05 * u, 0.2 + 0.1 * u], 77, rep=k))   # beta, phi, sigma
     tot = sum(sum(m.step(y[t]) for m in mem) / 3 for t in range(4))
     assert abs(float(vals["swarm_nocov"]) - tot) < 1e-12
+    # (10) the unmodified swarm templates (structural stand-in): one handle per member, filter ids 0..4, same members as (8)
+    assert abs(float(vals["uswarm"]) - float(vals["swarm"])) < 1e-12
+    assert abs(float(vals["uswarm42"]) - 42.0) < 1e-4
+    assert abs(float(vals["uswarmx"]) - float(vals["swarmx"])) < 1e-9
+    mus = [-0.1 + 0.2 * (0.1 + 0.2 * k) for k in range(5)]
+    assert abs(float(vals["uswarmmux"]) - (float(vals["swarmx"]) + sum(mus) / 5)) < 1e-9        # E[mu_i + x] per member
+    assert abs(float(vals["uswarm_nocov"]) - float(vals["swarm_nocov"])) < 1e-12
     n, first = vals["read_data"].split()
     assert int(n) == spy.size and float(first) == spy[0]
 

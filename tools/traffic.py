@@ -35,13 +35,17 @@ def driver():
     bank.close()
 
 
-def collect(outdir):
+def collect(outdir, env=None, cwd=None, quiet=False):
+    """Two PMC passes, one counter each (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2: they cannot share a pass).
+    The program after `--` is the python interpreter itself (no env/bash hop under the profiler)."""
     os.makedirs(outdir, exist_ok=True)
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(outdir, ctr), "--",
                sys.executable, os.path.abspath(__file__), "driver"]
-        print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd, stdout=open(os.path.join(outdir, ctr + ".log"), "w"), stderr=subprocess.STDOUT)
+        if not quiet:
+            print(" ".join(cmd), flush=True)
+        with open(os.path.join(outdir, ctr + ".log"), "w") as log:
+            subprocess.check_call(cmd, stdout=log, stderr=subprocess.STDOUT, env=env, cwd=cwd, timeout=600)
 
 
 def mean_counter(outdir, ctr, kernel_substr, skip_first=0):
@@ -54,7 +58,7 @@ def mean_counter(outdir, ctr, kernel_substr, skip_first=0):
     return sum(vals) / len(vals), len(vals)
 
 
-def summarize(outdir, outjson):
+def summarize(outdir, outjson, quiet=False):
     res = {}
     cal_bytes = CAL_N * 8.0
     f_cal, _ = mean_counter(outdir, "FETCH_SIZE", "k_calib_copy")
@@ -70,8 +74,11 @@ def summarize(outdir, outjson):
                             "read_bytes": f_k * 1024 * f_fac, "write_bytes": w_k * 1024 * w_fac}
     res["filter_step_bytes_per_launch"] = res["k_filter_step"]["read_bytes"] + res["k_filter_step"]["write_bytes"]
     res["algorithmic_bytes_per_launch"] = 32.0 * (1 << 20)
-    json.dump(res, open(outjson, "w"), indent=1)
-    print(json.dumps(res, indent=1))
+    if outjson:
+        json.dump(res, open(outjson, "w"), indent=1)
+    if not quiet:
+        print(json.dumps(res, indent=1))
+    return res
 
 
 if __name__ == "__main__":
