@@ -60,7 +60,7 @@ def lib():
         L = C.CDLL(_SO)
         dp, u32p = C.POINTER(C.c_double), C.POINTER(C.c_uint32)
         L.orc_philox4x32_10.argtypes = [u32p, u32p, u32p]
-        for f in (L.orc_exp, L.orc_log):
+        for f in (L.orc_exp, L.orc_log, L.orc_log_u):
             f.argtypes = [dp, dp, C.c_long]
         L.orc_sincos2pi.argtypes = [dp, dp, dp, C.c_long]
         L.orc_normals.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, dp]
@@ -139,6 +139,11 @@ def exp(x):
 
 def log(x):
     return _map1(lib().orc_log, x)
+
+
+def log_u(x):
+    """The table-based logarithm of the bootstrap filter's uniform draws (absolute error < 2^-51)."""
+    return _map1(lib().orc_log_u, x)
 
 
 def sincos2pi(u):

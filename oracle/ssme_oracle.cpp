@@ -154,6 +154,35 @@ double o_log(double x) {
     return dk * LN2_HI - ((hfsq - std::fma(s, hfsq + R, dk * LN2_LO)) - f);
 }
 
+// log of a uniform strictly inside (0,1): table + degree-6 series, no division (mirror of ssme_math.h: dlog_u).
+// The bootstrap filter's hot-loop draws (exponential spacings, Box-Muller radius) use it; absolute error < 2^-51.
+#include "ssme_log_table.h"
+struct LogTabEntry { double c, l; };
+static const LogTabEntry LOG_TABLE[SSME_LOG_TABLE_SIZE] = {SSME_LOG_TABLE_ROWS};
+double o_log_u(double x) {
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const uint64_t ux = double_to_bits(x);
+    const uint32_t hx = (uint32_t)(ux >> 32);
+    const int k = (int)(hx >> 20) - 1023;
+    const LogTabEntry e = LOG_TABLE[(hx >> 13) & 127u];
+    const double m = bits_to_double((ux & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    const double r = std::fma(m, e.c, -1.0);
+    double q = std::fma(r, -1.6666666666666666e-01, 2.0000000000000001e-01);
+    q = std::fma(q, r, -2.5000000000000000e-01);
+    q = std::fma(q, r, 3.3333333333333331e-01);
+    q = std::fma(q, r, -5.0000000000000000e-01);
+    const double p = std::fma(r * r, q, r);
+    const double dk = (double)k;
+    return std::fma(dk, LN2_HI, e.l) + std::fma(dk, LN2_LO, p);
+}
+// uniforms strictly inside (0,1) on a 2^-40 / 2^-32 midpoint grid; [0,1) on a 2^-24 grid (Box-Muller angle)
+inline double u01_mid40(uint32_t a, uint32_t b) {
+    const uint64_t man = ((uint64_t)a << 20) | ((uint64_t)(b >> 24) << 12) | 0x800ull;
+    return 2.0 - bits_to_double(0x3ff0000000000000ull | man);
+}
+inline double u01_lo24(uint32_t b) { return bits_to_double(0x3ff0000000000000ull | ((uint64_t)(b & 0x00ffffffu) << 28)) - 1.0; }
+inline double u01_mid32(uint32_t a) { return 2.0 - bits_to_double(0x3ff0000000000000ull | ((uint64_t)a << 20) | 0x80000ull); }
+
 // sin(2*pi*u), cos(2*pi*u) for u in [0,1)
 void o_sincos2pi(double u, double* sn, double* cs) {
     const double SH = 6755399441055744.0;
@@ -325,6 +354,10 @@ struct Filter {
     std::vector<uint32_t> anc;
     double m, prev, loglik, last_ll;
     uint64_t Sint;
+    // Bootstrap filter (k_filter_step): ONE Philox call per particle pair and time step, counter (pair, t, filter,
+    // STREAM_PROP): words 0-1 -> Box-Muller (radius uniform 40 bits, angle 24 bits), words 2-3 -> the pair's two
+    // exponential spacings (32 bits each); logs by o_log_u.  false: the Liu-West filter's streams (52-bit uniforms, o_log).
+    bool bootstrap_draws = false;
 
     void init(int model_, int N_, int resamp_, int rs_, uint64_t seed, uint32_t rep_, const double* th) {
         model = model_; N = N_; resamp = resamp_; rs = rs_ < 1 ? 1 : rs_;
@@ -343,10 +376,25 @@ struct Filter {
     double normal(int i, int tt) const {
         const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, STREAM_PROP};
         uint32_t o[4]; philox4x32_10(ctr, key, o);
+        if (bootstrap_draws) {
+            const double rad = std::sqrt(-2.0 * o_log_u(u01_mid40(o[0], o[1])));
+            double sn, cs; o_sincos2pi(u01_lo24(o[1]), &sn, &cs);
+            return (i & 1) ? rad * sn : rad * cs;
+        }
         const double u1 = u01_oc(o[0], o[1]), u2 = u01_co(o[2], o[3]);
         const double rad = std::sqrt(-2.0 * o_log(u1));
         double sn, cs; o_sincos2pi(u2, &sn, &cs);
         return (i & 1) ? rad * sn : rad * cs;
+    }
+    // exponential spacing E_i of the multinomial resampler at time tt
+    double spacing(int i, int tt, int stream) const {
+        if (bootstrap_draws) {
+            const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, STREAM_PROP};
+            uint32_t o[4]; philox4x32_10(ctr, key, o);
+            return -o_log_u(u01_mid32(o[2 + (i & 1)]));
+        }
+        uint32_t wa, wb; resamp_words(i, tt, &wa, &wb, stream);
+        return -o_log(u01_oc(wa, wb));
     }
     void resamp_words(int i, int tt, uint32_t* a, uint32_t* b, int stream = STREAM_RESAMP) const {
         const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, (uint32_t)stream};
@@ -407,8 +455,7 @@ struct Filter {
                 std::vector<uint64_t> locE(nb);
                 uint64_t s = 0;
                 for (int j = 0; j < nb; ++j) {
-                    uint32_t wa, wb; resamp_words(b * TILE + j, tt, &wa, &wb, s_spacing);
-                    const double E = -o_log(u01_oc(wa, wb));
+                    const double E = spacing(b * TILE + j, tt, s_spacing);
                     s += (uint64_t)std::rint(E * 34359738368.0 /* 2^35 */);
                     locE[j] = s;
                 }
@@ -925,9 +972,10 @@ void orc_exp(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) 
 void orc_log(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_log(x[i]); }
 void orc_sincos2pi(const double* u, double* s, double* c, long n) { for (long i = 0; i < n; ++i) o_sincos2pi(u[i], s + i, c + i); }
 void orc_normals(uint64_t seed, uint32_t rep, int t, int n, double* out) {
-    Filter f; double th[3] = {1.0, 0.5, 0.1}; f.init(MODEL_SVOL, n, 0, 1, seed, rep, th);
+    Filter f; double th[3] = {1.0, 0.5, 0.1}; f.bootstrap_draws = true; f.init(MODEL_SVOL, n, 0, 1, seed, rep, th);
     for (int i = 0; i < n; ++i) out[i] = f.normal(i, t);
 }
+void orc_log_u(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_log_u(x[i]); }
 void orc_exp_scaled(const double* x, int sc, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_exp_scaled(x[i], sc); }
 // Gamma(shape) draws for tiles b = 0..n-1 at time t (Marsaglia-Tsang, counter driven)
 void orc_gamma(uint64_t seed, uint32_t rep, int t, double shape, int n, double* out) {
@@ -940,7 +988,7 @@ void orc_rescale(const uint64_t* A, const double* dm, int sc, uint64_t* out, lon
 void orc_quantize(const double* x, int sc, uint64_t* q, long n) { for (long i = 0; i < n; ++i) q[i] = rne_u64(o_exp_scaled(x[i], sc)); }
 
 void* orc_pf_create(int model, int N, int resamp, int rs, uint64_t seed, uint32_t rep, const double* theta) {
-    Filter* f = new Filter(); f->init(model, N, resamp, rs, seed, rep, theta); return f;
+    Filter* f = new Filter(); f->bootstrap_draws = true; f->init(model, N, resamp, rs, seed, rep, theta); return f;
 }
 void orc_pf_destroy(void* h) { delete (Filter*)h; }
 void orc_pf_reset(void* h) { ((Filter*)h)->reset(); }

@@ -962,6 +962,7 @@ __global__ void k_test_math(int fn, const double* in, double* out, long n) {
         case 2: dsincos2pi(x, &s, &c); r = s; break;
         case 3: dsincos2pi(x, &s, &c); r = c; break;
         case 4: r = dsqrt(x); break;
+        case 6: r = dlog_u(x, kLogTable); break;
         default: r = dlog_pn(x); break;
     }
     out[i] = r;

@@ -271,6 +271,32 @@ __device__ __forceinline__ void normal_pair_angle(double rad, double u2, double*
     *z1 = rad * sn;
 }
 
+// ---- bootstrap filter: ONE Philox call per particle pair and time step -------------------------------------------------
+// The thread that propagates pair p at time t also draws that pair's two exponential spacings of the multinomial resampler,
+// so one counter (pair, t, filter, STREAM_PROP) feeds both: words 0-1 -> Box-Muller (radius uniform: 40 bits, strictly inside
+// (0,1), i.e. |z| < 7.45; angle: the low 24 bits of word 1), words 2-3 -> E_0, E_1 = -log(u), u on the 2^-32 midpoint grid
+// (the spacings are quantised to 2^-35 right away).  Logs by dlog_u (table in LDS, no division).  DESIGN.md section 4.1.
+__device__ __forceinline__ u32x4 pair_words(uint32_t pair, uint32_t t, uint32_t rep, uint32_t k0, uint32_t k1) {
+    return philox4x32_10(pair, t, rep, STREAM_PROP, k0, k1);
+}
+__device__ __forceinline__ void pair_spacings(const u32x4& o, const LogTabEntry* tab, double* e0, double* e1) {
+    *e0 = -dlog_u(u01_mid32(o.v2), tab);
+    *e1 = -dlog_u(u01_mid32(o.v3), tab);
+}
+__device__ __forceinline__ void pair_normals(uint32_t w0, uint32_t w1, const LogTabEntry* tab, double* z0, double* z1) {
+    const double rad = dsqrt(-2.0 * dlog_u(u01_mid40(w0, w1), tab));
+    double sn, cs;
+    dsincos2pi(u01_lo24(w1), &sn, &cs);
+    *z0 = rad * cs;
+    *z1 = rad * sn;
+}
+// the table of dlog_u, in device memory; every workgroup copies it into LDS (128 x 16 bytes) before its first draw
+static __device__ const LogTabEntry kLogTable[SSME_LOG_TABLE_SIZE] = {SSME_LOG_TABLE_ROWS};
+template <int NT>
+__device__ __forceinline__ void load_log_table(LogTabEntry* lds_tab) {
+    for (int i = threadIdx.x; i < SSME_LOG_TABLE_SIZE; i += NT) lds_tab[i] = kLogTable[i];
+}
+
 // Gamma(shape) draw, Marsaglia & Tsang (2000), attempts driven by the Philox counter
 __device__ __forceinline__ double gamma_draw(uint32_t b, uint32_t t, uint32_t rep, uint32_t k0, uint32_t k1, double shape,
                                              uint32_t stream_base = STREAM_GAMMA) {
@@ -442,8 +468,10 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     __shared__ int lds_cnt[2];
     __shared__ double lds_d1[16];
     __shared__ double lds_d2[16];
+    __shared__ __attribute__((aligned(16))) LogTabEntry lds_ltab[SSME_LOG_TABLE_SIZE];
 
     const int tid = threadIdx.x;
+    load_log_table<NT>(lds_ltab);        // visible after the first barrier below (every path has one before its first draw)
     // (filter, tile) of this workgroup: the launch's tiles in filter-major order, a contiguous range per XCD
     const int gtile = xcd_tile_of_block((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
     const int r = gtile / (int)gridDim.x, bloc = gtile - r * (int)gridDim.x;
@@ -581,20 +609,25 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     // --- exponential spacings of the multinomial resampler (liu_west_filter.h:105-139), exact tile scan;
     //     this arithmetic hides the latency of the tile loads ---
     double le[NK][2], se = 1.0;
-    if (multinomial) {
-        double qe[NK][2];
+    uint32_t nw0[NK], nw1[NK];            // words 0-1 of each pair's Philox output: the propagation normals (below)
+    if (!resampled) __syncthreads();      // the log table is in LDS (the resampling path has passed a barrier already)
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
+    for (int k = 0; k < NK; ++k) {
+        const u32x4 o = pair_words((uint32_t)(b * (kTile / 2) + k * NT + tid), (uint32_t)a.t, rep, key0, key1);
+        nw0[k] = o.v0; nw1[k] = o.v1;
+        if (multinomial) {
             const int i0 = i_first + (k * NT + tid) * 2;
             double e0, e1;
             if (ABL(a, 1)) { e0 = 1.0 + 1e-6 * (double)(i0 & 1023); e1 = 1.0; }
-            else {
-                const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, key0, key1);
-                e0 = -dlog_pn(u01_oc(o.v0, o.v1)); e1 = -dlog_pn(u01_oc(o.v2, o.v3));
-            }
-            qe[k][0] = (i0 < a.N) ? __builtin_rint(e0 * 34359738368.0 /* 2^35 */) : 0.0;
-            qe[k][1] = (i0 + 1 < a.N) ? __builtin_rint(e1 * 34359738368.0) : 0.0;
+            else pair_spacings(o, lds_ltab, &e0, &e1);
+            le[k][0] = (i0 < a.N) ? __builtin_rint(e0 * 34359738368.0 /* 2^35 */) : 0.0;
+            le[k][1] = (i0 + 1 < a.N) ? __builtin_rint(e1 * 34359738368.0) : 0.0;
         }
+    }
+    if (multinomial) {
+        double qe[NK][2];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { qe[k][0] = le[k][0]; qe[k][1] = le[k][1]; }
         block_scan_f64<NT>(qe, le, se, lds_seg_a);
     }
     STAMP(a, 4);
@@ -740,9 +773,8 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     double zn[NK][2];
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const uint32_t pair = (uint32_t)(b * (kTile / 2) + k * NT + tid);
-        if (ABL(a, 0)) { zn[k][0] = 0.25 + 1e-9 * (double)pair; zn[k][1] = -0.25; }
-        else normal_pair(pair, (uint32_t)a.t, rep, key0, key1, &zn[k][0], &zn[k][1]);
+        if (ABL(a, 0)) { zn[k][0] = 0.25 + 1e-9 * (double)nw0[k]; zn[k][1] = -0.25; }
+        else pair_normals(nw0[k], nw1[k], lds_ltab, &zn[k][0], &zn[k][1]);
     }
     STAMP(a, 7);
     PRIO_AT(7);

@@ -80,8 +80,11 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
     __shared__ double lds_seg_a[16];
     __shared__ double lds_seg_c[16];
     __shared__ double lds_d2[16];
+    __shared__ __attribute__((aligned(16))) LogTabEntry lds_ltab[SSME_LOG_TABLE_SIZE];
 
     const int tid = threadIdx.x;
+    load_log_table<NT>(lds_ltab);
+    __syncthreads();
     const int r = blockIdx.x;
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const uint32_t key0 = a.keyp[0], key1 = a.keyp[1];
@@ -136,23 +139,26 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
 
         // --- standard normals of this step: independent of the resampling chain, issued next to the spacings so that the
         //     two instruction streams interleave ---
+        // one Philox call per pair feeds the normals (words 0-1) and the pair's two spacings (words 2-3): pair_words
         double zn[NK][2];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) normal_pair((uint32_t)(k * NT + tid), (uint32_t)t, rep, key0, key1, &zn[k][0], &zn[k][1]);
-
-        // --- exponential spacings (multinomial), exact scan ---
         double le[NK][2], se = 1.0;
-        if (multinomial) {
+        {
             double qe[NK][2];
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                const int i0 = (k * NT + tid) * 2;
-                const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)t, rep, STREAM_RESAMP, key0, key1);
-                const double e0 = -dlog_pn(u01_oc(o.v0, o.v1)), e1 = -dlog_pn(u01_oc(o.v2, o.v3));
-                qe[k][0] = (i0 < a.N) ? __builtin_rint(e0 * 34359738368.0 /* 2^35 */) : 0.0;
-                qe[k][1] = (i0 + 1 < a.N) ? __builtin_rint(e1 * 34359738368.0) : 0.0;
+                const u32x4 o = pair_words((uint32_t)(k * NT + tid), (uint32_t)t, rep, key0, key1);
+                pair_normals(o.v0, o.v1, lds_ltab, &zn[k][0], &zn[k][1]);
+                qe[k][0] = 0.0; qe[k][1] = 0.0;
+                if (multinomial) {
+                    const int i0 = (k * NT + tid) * 2;
+                    double e0, e1;
+                    pair_spacings(o, lds_ltab, &e0, &e1);
+                    qe[k][0] = (i0 < a.N) ? __builtin_rint(e0 * 34359738368.0 /* 2^35 */) : 0.0;
+                    qe[k][1] = (i0 + 1 < a.N) ? __builtin_rint(e1 * 34359738368.0) : 0.0;
+                }
             }
-            block_scan_f64_g<NT, NK>(qe, le, se, lds_seg_a);
+            // --- exponential spacings (multinomial), exact scan ---
+            if (multinomial) block_scan_f64_g<NT, NK>(qe, le, se, lds_seg_a);
         }
 
         double xin[NK][2], lw_old[NK][2];

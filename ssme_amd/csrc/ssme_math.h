@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ssme_log_table.h"
+
 #define SSME_HD __host__ __device__ __forceinline__
 
 namespace ssme {
@@ -146,6 +148,42 @@ SSME_HD double dlog(double x) {
     if (x < 0.0) res = dnan();
     if (x != x) res = x;
     return res;
+}
+
+// ---- log of a uniform: table + short series, no division ------------------------------------------------------------
+// The draws of the bootstrap filter's hot loop (exponential spacings, Box-Muller radius) take -log(u) of uniforms that lie
+// strictly inside (0,1).  fdlibm's log spends half its instructions on the IEEE division s = f/(2+f); this one takes
+// c_i ~ 1/m and l_i = -log(c_i) from a 128-entry table indexed by the top 7 mantissa bits, so that r = fma(m, c_i, -1)
+// has |r| < 2^-8 and log(x) = k ln2 + l_i + log1p(r) with log1p a degree-6 series (truncation < 2^-58).
+// ABSOLUTE error < 2^-51 for any positive normal x (the relative error is unbounded next to x = 1, which the callers
+// never need: u <= 1 - 2^-41).  Same operation sequence in oracle/ssme_oracle.cpp.
+struct LogTabEntry { double c, l; };
+SSME_HD double dlog_u(double x, const LogTabEntry* tab) {
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const uint64_t ux = d2bits(x);
+    const uint32_t hx = (uint32_t)(ux >> 32);
+    const int k = (int)(hx >> 20) - 1023;
+    const LogTabEntry e = tab[(hx >> 13) & 127u];
+    const double m = bits2d((ux & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    const double r = dfma(m, e.c, -1.0);
+    double q = dfma_c(r, -1.6666666666666666e-01, 2.0000000000000001e-01);
+    q = dfma_c(q, r, -2.5000000000000000e-01);
+    q = dfma_c(q, r, 3.3333333333333331e-01);
+    q = dfma_c(q, r, -5.0000000000000000e-01);
+    const double p = dfma(r * r, q, r);
+    const double dk = (double)k;
+    return dfma(dk, LN2_HI, e.l) + dfma(dk, LN2_LO, p);
+}
+// uniforms strictly inside (0,1): midpoints of a 2^-40 / 2^-32 grid, and [0,1) on a 2^-24 grid (Box-Muller angle)
+SSME_HD double u01_mid40(uint32_t a, uint32_t b) {          // a: 32 bits, top 8 bits of b
+    const uint64_t man = ((uint64_t)a << 20) | ((uint64_t)(b >> 24) << 12) | 0x800ull;
+    return 2.0 - bits2d(0x3ff0000000000000ull | man);
+}
+SSME_HD double u01_lo24(uint32_t b) {                       // low 24 bits of b
+    return bits2d(0x3ff0000000000000ull | ((uint64_t)(b & 0x00ffffffu) << 28)) - 1.0;
+}
+SSME_HD double u01_mid32(uint32_t a) {
+    return 2.0 - bits2d(0x3ff0000000000000ull | ((uint64_t)a << 20) | 0x80000ull);
 }
 
 // ---- sin(2 pi u), cos(2 pi u), u in [0,1) -----------------------------------------------

@@ -46,6 +46,18 @@ def test_math_accuracy(oracle):
         assert abs(tc - mpmath.mpf(float(cv))) <= mpmath.mpf(float(np.spacing(abs(float(tc)))))
 
 
+def test_log_of_uniform_accuracy(oracle):
+    """The table-based log of the hot-loop draws: strictly negative on (0,1), absolute error < 2^-51 where |log| < 1
+    and <= 2 ulp of the result elsewhere (its relative error next to x = 1 is NOT bounded: never needed, u <= 1 - 2^-41)."""
+    rng = np.random.default_rng(3)
+    u = np.concatenate([rng.uniform(0, 1, 400000), (rng.integers(0, 2 ** 32, 100000) + 0.5) * 2.0 ** -32,
+                        1 - (rng.integers(0, 2 ** 20, 100000) + 0.5) * 2.0 ** -40, np.exp(rng.uniform(-40, 0, 100000))])
+    got, ref = oracle.log_u(u), np.log(u)
+    assert np.all(got < 0)
+    err = np.abs(got - ref)
+    assert np.all(err <= np.maximum(2.0 ** -51, 2 * np.spacing(np.abs(ref))))
+
+
 def test_math_special_values(oracle):
     with np.errstate(all="ignore"):
         x = np.array([-745.2, -745.0, -720.0, 709.7, 709.9, 0.0, np.inf, -np.inf])

@@ -66,6 +66,9 @@ def test_device_math_bit_exact(sa, oracle):
         assert_bits_equal(_dev_math(1, u), oracle.log(u), "log")
         un = u[(u > 2.3e-308) & np.isfinite(u)]
         assert_bits_equal(_dev_math(5, un), oracle.log(un), "log (normal-only core)")
+        uu = np.concatenate([rng.uniform(0, 1, 400000), (np.arange(0, 4096) + 0.5) * 2.0 ** -32, 1 - (np.arange(0, 4096) + 0.5) * 2.0 ** -40,
+                             np.exp(rng.uniform(-40, 0, 100000))])
+        assert_bits_equal(_dev_math(6, uu), oracle.log_u(uu), "log of a uniform (table, no division)")
         v = np.concatenate([rng.uniform(0, 1, 400000), np.arange(0, 4096) * 2.0 ** -53, 1 - np.arange(1, 4097) * 2.0 ** -53,
                             [0.0, 0.125, 0.25, 0.5, 0.75, 0.875]])
         s, c = oracle.sincos2pi(v)
