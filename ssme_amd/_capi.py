@@ -64,6 +64,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        if not os.environ.get("SSME_PF_LIB"):
+            # never load a library built from other sources than the ones on disk (content hash, ssme_amd/build.py):
+            # a stale .so silently tests / benches yesterday's kernels
+            from . import build as _build
+            if _build.needs_build():
+                _build.build()
         if not os.path.exists(SO_PATH):
             raise OSError(f"{SO_PATH} not built: run `python -m ssme_amd.build` (hipcc --offload-arch=gfx950); "
                           "there is no CPU fallback")
