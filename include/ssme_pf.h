@@ -75,6 +75,12 @@ typedef struct ssme_pf_config {
     int32_t  device;           /* HIP device ordinal                                         */
     uint32_t first_filter_id;  /* global id of filter 0 of this handle; enters the Philox
                                   counter, so sharding R over GPUs keeps every stream        */
+    int32_t  tile_particles;   /* particles per tile: 0 = by N (2048 for N <= 2048 and N > 2^18,
+                                  512 in between, so that mid-size filters spread over the
+                                  chip), or 2048 / 512.  Part of the arithmetic specification:
+                                  weights are fixed point relative to their tile's maximum and
+                                  the resampler draws one Gamma variate per tile */
+    int32_t  reserved;         /* 0 */
 } ssme_pf_config;
 
 /* Allocates device state for R filters of N particles.  Replaces construction of the
@@ -135,8 +141,10 @@ int ssme_pf_log_mean_exp(ssme_pf_handle h, double* out);
  * ancestors: N indices used by the last step (requires set_debug(flags & 1)). */
 int ssme_pf_download_state(ssme_pf_handle h, int32_t filter, double* x, double* logw, uint64_t* cdf,
                            uint32_t* ancestors);
+/* The tile decomposition in use: particles per tile (2048 or 512) and tiles per filter. */
+int ssme_pf_get_layout(ssme_pf_handle h, int32_t* tile_particles, int32_t* n_tiles);
 /* max_logw: max log-weight of the last step; sum_q: exact integer sum of the rescaled tile sums;
- * tile_sums / tile_max: one integer weight sum and one max log-weight per 2048-particle tile;
+ * tile_sums / tile_max: one integer weight sum and one max log-weight per tile;
  * rshift: the fixed-point exponent rg = 52 - ceil(log2(Npad)) of sum_q. */
 int ssme_pf_download_scalars(ssme_pf_handle h, int32_t filter, double* max_logw, uint64_t* sum_q,
                              uint64_t* tile_sums, double* tile_max, int32_t* rshift);

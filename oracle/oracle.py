@@ -71,7 +71,7 @@ def lib():
         L.orc_pf_sum_int.restype = C.c_uint64
         L.orc_pf_sum_int.argtypes = [C.c_void_p]
         L.orc_pf_create.restype = C.c_void_p
-        L.orc_pf_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, dp]
+        L.orc_pf_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, dp, C.c_int]
         L.orc_pf_destroy.argtypes = [C.c_void_p]
         L.orc_pf_reset.argtypes = [C.c_void_p]
         L.orc_pf_step.restype = C.c_double
@@ -191,14 +191,20 @@ def quantize(x, sc):
     return q
 
 
-class Filter:
-    """Kernel-matched oracle filter (mode B), one replicate."""
+def default_tile(n):
+    """The device's rule when the caller does not choose a tile size (pf_api.hip: default_tile)."""
+    return 512 if 2048 < n <= (1 << 18) else 2048
 
-    def __init__(self, model, n, theta, seed, rep=0, resampler=RESAMP_MULTINOMIAL, resamp_sched=1):
+
+class Filter:
+    """Kernel-matched oracle filter (mode B), one replicate.  tile: particles per tile (None: the device's default by N)."""
+
+    def __init__(self, model, n, theta, seed, rep=0, resampler=RESAMP_MULTINOMIAL, resamp_sched=1, tile=None):
         th = np.ascontiguousarray(theta, dtype=np.float64)
         self.n = int(n)
-        self.nt = (self.n + TILE - 1) // TILE
-        self._h = lib().orc_pf_create(model, n, resampler, resamp_sched, seed, rep, _dp(th))
+        self.tile = default_tile(self.n) if tile is None else int(tile)
+        self.nt = (self.n + self.tile - 1) // self.tile
+        self._h = lib().orc_pf_create(model, n, resampler, resamp_sched, seed, rep, _dp(th), self.tile)
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -358,12 +358,16 @@ struct Filter {
     // STREAM_PROP): words 0-1 -> Box-Muller (radius uniform 40 bits, angle 24 bits), words 2-3 -> the pair's two
     // exponential spacings (32 bits each); logs by o_log_u.  false: the Liu-West filter's streams (52-bit uniforms, o_log).
     bool bootstrap_draws = false;
+    // particles per tile (2048 or 512): weights are fixed point relative to their TILE's maximum and the multinomial
+    // resampler draws one Gamma variate per tile, so the tile size is part of the specification.  The device's rule when
+    // the caller does not choose (pf_api.hip: default_tile): 2048 for N <= 2048 and N > 2^18, 512 in between.
+    int tile = 2048;
 
     void init(int model_, int N_, int resamp_, int rs_, uint64_t seed, uint32_t rep_, const double* th) {
         model = model_; N = N_; resamp = resamp_; rs = rs_ < 1 ? 1 : rs_;
         key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32); rep = rep_;
         mc = derive(model, th);
-        B = (N + TILE - 1) / TILE; Npad = B * TILE;
+        B = (N + tile - 1) / tile; Npad = B * tile;
         rshift = 52 - ceil_log2(Npad);
         x.assign(Npad, 0.0); xprev.assign(Npad, 0.0); logw.assign(Npad, 0.0); loc.assign(Npad, 0);
         A.assign(B, 0); Ap.assign(B, 0); Tincl.assign(B, 0); mb.assign(B, 0.0);
@@ -442,7 +446,7 @@ struct Filter {
             std::vector<double> gam(B), pgam(B);
             double run = 0.0;
             for (int b = 0; b < B; ++b) {
-                const int nb = std::min(TILE, N - b * TILE);
+                const int nb = std::min(tile, N - b * tile);
                 gam[b] = gamma_draw(b, tt, (double)nb, s_gamma);
                 pgam[b] = run;
                 run = run + gam[b];
@@ -451,11 +455,11 @@ struct Filter {
             const double G = run + (-o_log(u01_oc(o[0], o[1])));
             const double scale = Sd / G;
             for (int b = 0; b < B; ++b) {
-                const int nb = std::min(TILE, N - b * TILE);
+                const int nb = std::min(tile, N - b * tile);
                 std::vector<uint64_t> locE(nb);
                 uint64_t s = 0;
                 for (int j = 0; j < nb; ++j) {
-                    const double E = spacing(b * TILE + j, tt, s_spacing);
+                    const double E = spacing(b * tile + j, tt, s_spacing);
                     s += (uint64_t)std::rint(E * 34359738368.0 /* 2^35 */);
                     locE[j] = s;
                 }
@@ -463,7 +467,7 @@ struct Filter {
                 for (int j = 0; j < nb; ++j) {
                     const double t1 = ratio * (double)locE[j];
                     const double t2 = pgam[b] + t1;
-                    tau[b * TILE + j] = tau_to_u64(t2 * scale);
+                    tau[b * tile + j] = tau_to_u64(t2 * scale);
                 }
             }
         } else if (resamp == RESAMP_SYSTEMATIC) {
@@ -486,10 +490,10 @@ struct Filter {
         const uint64_t d = tau - (Tincl[b] - Ap[b]);                     // unsigned, as on the device
         const double ratio = (double)A[b] / (double)Ap[b];
         const uint64_t tl = tau_to_u64((double)d * ratio);
-        const uint64_t* tile = &loc[(size_t)b * TILE];
-        int j = (int)(std::lower_bound(tile, tile + TILE, tl) - tile);   // #{loc_j < tl}
-        if (j > TILE - 1) j = TILE - 1;
-        return std::min(b * TILE + j, N - 1);
+        const uint64_t* tl_cdf = &loc[(size_t)b * tile];
+        int j = (int)(std::lower_bound(tl_cdf, tl_cdf + tile, tl) - tl_cdf);   // #{loc_j < tl}
+        if (j > tile - 1) j = tile - 1;
+        return std::min(b * tile + j, N - 1);
     }
 
     // logw[0..N) -> per-tile maxima, tile-local exact cdf, rescaled tile sums, their prefixes; returns S' 2^-rg
@@ -497,15 +501,15 @@ struct Filter {
         // per-tile NaN-propagating max, tile-local exact cdf
         for (int b = 0; b < B; ++b) {
             double mx = NEG_INF; bool nan = false;
-            for (int j = 0; j < TILE; ++j) {
-                const int i = b * TILE + j;
+            for (int j = 0; j < tile; ++j) {
+                const int i = b * tile + j;
                 if (i >= N) break;
                 if (logw[i] != logw[i]) nan = true; else if (logw[i] > mx) mx = logw[i];
             }
             mb[b] = nan ? std::numeric_limits<double>::quiet_NaN() : mx;
             uint64_t s = 0;
-            for (int j = 0; j < TILE; ++j) {
-                const int i = b * TILE + j;
+            for (int j = 0; j < tile; ++j) {
+                const int i = b * tile + j;
                 if (i < N) s += rne_u64(o_exp_scaled(logw[i] - mb[b], TILE_SHIFT));
                 loc[i] = s;
             }
@@ -987,8 +991,8 @@ void orc_gamma(uint64_t seed, uint32_t rep, int t, double shape, int n, double* 
 void orc_rescale(const uint64_t* A, const double* dm, int sc, uint64_t* out, long n) { for (long i = 0; i < n; ++i) out[i] = rint_to_u64((double)A[i] * o_exp_scaled(dm[i], sc)); }
 void orc_quantize(const double* x, int sc, uint64_t* q, long n) { for (long i = 0; i < n; ++i) q[i] = rne_u64(o_exp_scaled(x[i], sc)); }
 
-void* orc_pf_create(int model, int N, int resamp, int rs, uint64_t seed, uint32_t rep, const double* theta) {
-    Filter* f = new Filter(); f->bootstrap_draws = true; f->init(model, N, resamp, rs, seed, rep, theta); return f;
+void* orc_pf_create(int model, int N, int resamp, int rs, uint64_t seed, uint32_t rep, const double* theta, int tile) {
+    Filter* f = new Filter(); f->bootstrap_draws = true; f->tile = tile; f->init(model, N, resamp, rs, seed, rep, theta); return f;
 }
 void orc_pf_destroy(void* h) { delete (Filter*)h; }
 void orc_pf_reset(void* h) { ((Filter*)h)->reset(); }

@@ -21,7 +21,7 @@ H_X, H_X2, H_VOL, H_CONST42 = 0, 1, 2, 3
 EXPORTS = [
     "ssme_pf_create", "ssme_pf_destroy", "ssme_pf_set_params", "ssme_pf_reset", "ssme_pf_set_seed", "ssme_pf_set_small_series", "ssme_pf_shard_create", "ssme_pf_set_stream",
     "ssme_pf_shard_prepare", "ssme_pf_shard_plan", "ssme_pf_shard_step", "ssme_pf_shard_finalize", "ssme_pf_step",
-    "ssme_pf_run_series", "ssme_pf_get_per_step", "ssme_pf_get_loglik", "ssme_pf_get_expectations", "ssme_pf_get_expectations_multi", "ssme_pf_swarm_aggregate", "ssme_pf_download_weights",
+    "ssme_pf_run_series", "ssme_pf_get_per_step", "ssme_pf_get_loglik", "ssme_pf_get_expectations", "ssme_pf_get_expectations_multi", "ssme_pf_swarm_aggregate", "ssme_pf_download_weights", "ssme_pf_get_layout",
     "ssme_pf_log_mean_exp", "ssme_pf_download_state", "ssme_pf_download_scalars", "ssme_pf_set_debug",
     "ssme_pf_set_graph_mode", "ssme_pf_set_tuning", "ssme_pf_last_elapsed_ms", "ssme_pf_profile_series", "ssme_pf_test_math",
     "ssme_pf_test_philox", "ssme_pf_test_quantize", "ssme_pf_test_rescale", "ssme_pf_test_block_scan",
@@ -40,7 +40,7 @@ class Config(C.Structure):
     _fields_ = [
         ("model", C.c_int32), ("n_particles", C.c_int32), ("n_filters", C.c_int32), ("dtype", C.c_int32),
         ("resampler", C.c_int32), ("resamp_sched", C.c_int32), ("seed", C.c_uint64), ("device", C.c_int32),
-        ("first_filter_id", C.c_uint32),
+        ("first_filter_id", C.c_uint32), ("tile_particles", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -97,6 +97,7 @@ def lib():
         L.ssme_pf_get_expectations_multi.argtypes = [H, i32p, C.c_int32, dp]
         L.ssme_pf_swarm_aggregate.argtypes = [H, i32p, C.c_int32, dp, dp]
         L.ssme_pf_download_weights.argtypes = [H, C.c_int32, dp, dp]
+        L.ssme_pf_get_layout.argtypes = [H, i32p, i32p]
         L.ssme_pf_download_state.argtypes = [H, C.c_int32, dp, dp, u64p, u32p]
         L.ssme_pf_download_scalars.argtypes = [H, C.c_int32, dp, u64p, u64p, dp, i32p]
         L.ssme_pf_set_debug.argtypes = [H, C.c_int32]

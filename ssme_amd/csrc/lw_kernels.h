@@ -179,7 +179,7 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
         qe[k][0] = (i0 < N) ? __builtin_rint(e0 * 34359738368.0) : 0.0;
         qe[k][1] = (i0 + 1 < N) ? __builtin_rint(e1 * 34359738368.0) : 0.0;
     }
-    block_scan_f64<NT>(qe, le, se, L.seg_a);
+    block_scan_f64<NT, NK>(qe, le, se, L.seg_a);
     const double ratio = gam / se;
     double tau[NK][2];
 #pragma unroll
@@ -287,7 +287,7 @@ __device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int N, in
         q[k][0] = (i0 < N) ? __builtin_rint(dexp_scaled(lg[k][0] - mb, kTileShift)) : 0.0;
         q[k][1] = (i0 + 1 < N) ? __builtin_rint(dexp_scaled(lg[k][1] - mb, kTileShift)) : 0.0;
     }
-    block_scan_f64<NT>(q, inc, total, lds_seg);
+    block_scan_f64<NT, NK>(q, inc, total, lds_seg);
 #pragma unroll
     for (int k = 0; k < NK; ++k)
         *reinterpret_cast<double2*>(cdf_row + (i_first - tile0 * kTile) + (k * NT + tid) * 2) = make_double2(inc[k][0], inc[k][1]);

@@ -6,6 +6,7 @@
 #include "lw_kernels.h"
 #include "pf_small.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,7 @@ using namespace ssme;
 struct ssme_pf_s {
     ssme_pf_config cfg;
     int N, R, Npad, B, Bs, Bpow2, rshift;
+    int tile;                // particles per tile: 2048 or 512 (cfg.tile_particles, or by N: default_tile)
     size_t lds_bytes;
     int t;                   // next time index
     bool params_set;
@@ -135,6 +137,7 @@ static StepArgs step_args(ssme_pf_handle h) {
     a.scal = h->scal; a.mc = h->mc; a.y = h->ybuf; a.z = nullptr; a.per_step = nullptr;
     a.gam = h->gam; a.pgam = h->pgam; a.gtot = h->gtot;
     a.N = h->N; a.Npad = h->Npad; a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = h->R;
+    a.tile = h->tile;
     a.Tcap = h->tcap;
     a.resampler = h->cfg.resampler; a.resamp_sched = h->cfg.resamp_sched;
     a.keyp = h->keybuf; a.first_filter = h->cfg.first_filter_id;
@@ -165,49 +168,77 @@ static StepArgs step_args(ssme_pf_handle h) {
     return a;
 }
 
-template <int MODEL, int NT>
-static hipError_t set_lds1(size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_step<MODEL, NT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+// Tile size by N when the caller does not choose (part of the arithmetic specification: the oracle applies the same rule).
+// One tile for N <= 2048 (the whole-series kernel), 512-particle tiles up to 2^18 particles so that a mid-size filter
+// spreads over the chip (N = 2^16: 128 workgroups instead of 32), 2048-particle tiles above.
+static int default_tile(int n_particles) { return (n_particles > kTile && n_particles <= (1 << 18)) ? kTileSmall : kTile; }
+
+// One launcher per instantiation of the step kernel.  The dynamic-LDS ceiling of a kernel is process-wide state: it is
+// only ever raised (a handle with few tiles must not lower what a handle with many tiles was granted).
+static thread_local int g_grant_only = 0;      // 1: launch_k only raises the LDS ceiling (handle creation), 2: ... of the hot variant
+template <int MODEL, int NT, bool BIG, int TILE, int RS>
+static void launch_k(ssme_pf_handle h, const StepArgs& a, dim3 grid, size_t lds) {
+    static std::atomic<size_t> granted{0};
+    auto kern = &k_filter_step<MODEL, NT, BIG, TILE, RS>;
+    if (lds > granted.load(std::memory_order_relaxed)) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        granted.store(lds, std::memory_order_relaxed);
+    }
+    if (g_grant_only) return;
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, h->stream, a);
 }
-template <int MODEL>
-static hipError_t set_lds_big(size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter_step<MODEL, 512, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-template <int MODEL>
-static hipError_t set_lds(size_t bytes) {
-    hipError_t e = set_lds1<MODEL, 256>(bytes);
-    if (e == hipSuccess) e = set_lds1<MODEL, 512>(bytes);
-    if (e == hipSuccess) e = set_lds1<MODEL, 1024>(bytes);
-    return e;
+
+// RS: the reference's configuration (multinomial, resampling every step, t > 0, no debug outputs) has its own instantiation
+static bool hot_config(ssme_pf_handle h, const StepArgs& a) {
+    if (g_grant_only) return g_grant_only == 2;
+    return h->cfg.resampler == SSME_RESAMP_MULTINOMIAL && h->cfg.resamp_sched == 1 && a.t > 0 && !a.anc && !a.logw;
 }
 
 template <int MODEL>
-static void launch_step_m(ssme_pf_handle h, const StepArgs& a) {
-    dim3 grid(h->B, h->R);
+static void launch_step_grid(ssme_pf_handle h, const StepArgs& a, dim3 grid) {
+    const bool hot = hot_config(h, a);
+    if (h->tile == kTileSmall) {
+        if (h->split_l2) { if (hot) launch_k<MODEL, 256, true, kTileSmall, 0>(h, a, grid, h->lds_bytes_big); else launch_k<MODEL, 256, true, kTileSmall, -1>(h, a, grid, h->lds_bytes_big); }
+        else if (hot) launch_k<MODEL, 256, false, kTileSmall, 0>(h, a, grid, h->lds_bytes);
+        else launch_k<MODEL, 256, false, kTileSmall, -1>(h, a, grid, h->lds_bytes);
+        return;
+    }
     if (h->split_l2) {
-        hipLaunchKernelGGL((k_filter_step<MODEL, 512, true>), grid, dim3(512), h->lds_bytes_big, h->stream, a);
+        if (hot) launch_k<MODEL, 512, true, kTile, 0>(h, a, grid, h->lds_bytes_big);
+        else launch_k<MODEL, 512, true, kTile, -1>(h, a, grid, h->lds_bytes_big);
         return;
     }
     switch (h->nt) {
-        case 256: hipLaunchKernelGGL((k_filter_step<MODEL, 256>), grid, dim3(256), h->lds_bytes, h->stream, a); break;
-        case 512: hipLaunchKernelGGL((k_filter_step<MODEL, 512>), grid, dim3(512), h->lds_bytes, h->stream, a); break;
-        default: hipLaunchKernelGGL((k_filter_step<MODEL, 1024>), grid, dim3(1024), h->lds_bytes, h->stream, a); break;
+        case 256: launch_k<MODEL, 256, false, kTile, -1>(h, a, grid, h->lds_bytes); break;
+        case 512: if (hot) launch_k<MODEL, 512, false, kTile, 0>(h, a, grid, h->lds_bytes); else launch_k<MODEL, 512, false, kTile, -1>(h, a, grid, h->lds_bytes); break;
+        default: launch_k<MODEL, 1024, false, kTile, -1>(h, a, grid, h->lds_bytes); break;
     }
 }
-static void launch_step(ssme_pf_handle h, const StepArgs& a) {
+static void launch_step_on(ssme_pf_handle h, const StepArgs& a, dim3 grid) {
     switch (h->cfg.model) {
-        case SSME_MODEL_SVOL: launch_step_m<MODEL_SVOL>(h, a); break;
-        case SSME_MODEL_SVOL_LEVERAGE: launch_step_m<MODEL_SVOL_LEVERAGE>(h, a); break;
-        default: launch_step_m<MODEL_LIN_GAUSS>(h, a); break;
+        case SSME_MODEL_SVOL: launch_step_grid<MODEL_SVOL>(h, a, grid); break;
+        case SSME_MODEL_SVOL_LEVERAGE: launch_step_grid<MODEL_SVOL_LEVERAGE>(h, a, grid); break;
+        default: launch_step_grid<MODEL_LIN_GAUSS>(h, a, grid); break;
     }
+}
+static void launch_step(ssme_pf_handle h, const StepArgs& a) { launch_step_on(h, a, dim3(h->B, h->R)); }
+// every instantiation this handle can launch gets its LDS ceiling now (not inside a stream capture)
+static void grant_step_lds(ssme_pf_handle h) {
+    const int nt0 = h->nt, sp0 = h->split_l2;
+    StepArgs a{};
+    for (int hot = 1; hot <= 2; ++hot)
+        for (int sp = 0; sp < 2; ++sp)
+            for (int nt : {256, 512, 1024}) {
+                g_grant_only = hot; h->split_l2 = sp; h->nt = nt;
+                launch_step_on(h, a, dim3(1, 1));
+            }
+    g_grant_only = 0; h->nt = nt0; h->split_l2 = sp0;
 }
 // Gamma tables for time indices t0 .. t0+nT-1 into table rows 0 .. nT-1
 static void launch_gamma(ssme_pf_handle h, int t0, int nT) {
     if (h->cfg.resampler != SSME_RESAMP_MULTINOMIAL) return;
     hipLaunchKernelGGL(k_gamma_draw, dim3((h->B + kThreads - 1) / kThreads, nT, h->R), dim3(kThreads), 0, h->stream,
-                       h->gam, h->N, h->B, h->R, t0, (const uint32_t*)h->keybuf, h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA);
+                       h->gam, h->N, h->B, h->R, t0, (const uint32_t*)h->keybuf, h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA, h->tile);
     if (h->B <= 64)
         hipLaunchKernelGGL(k_gamma_prefix_rows, dim3((nT * h->R + kThreads - 1) / kThreads), dim3(kThreads), 0, h->stream,
                            h->gam, h->pgam, h->gtot, h->B, h->R, nT, t0, (const uint32_t*)h->keybuf, h->cfg.first_filter_id,
@@ -336,7 +367,7 @@ static int do_reset(ssme_pf_handle h) {
 
 extern "C" {
 
-int ssme_pf_version(void) { return 200; }
+int ssme_pf_version(void) { return 300; }
 
 const char* ssme_pf_strerror(int s) {
     switch (s) {
@@ -359,23 +390,26 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     if (cfg->resampler < 0 || cfg->resampler > SSME_RESAMP_MULTINOMIAL_IID) return SSME_ERR_INVALID_ARG;
     if (cfg->resamp_sched < 1) return SSME_ERR_INVALID_ARG;
     if (cfg->dtype != SSME_F64) return SSME_ERR_UNSUPPORTED;
-    const int B = (cfg->n_particles + kTile - 1) / kTile;
-    if (B > kMaxTilesSplit) return SSME_ERR_UNSUPPORTED;   // N <= 2^25 per filter
+    if (cfg->tile_particles != 0 && cfg->tile_particles != kTile && cfg->tile_particles != kTileSmall) return SSME_ERR_INVALID_ARG;
+    const int tile = shard_world > 0 ? kTile : (cfg->tile_particles ? cfg->tile_particles : default_tile(cfg->n_particles));
+    const int B = (cfg->n_particles + tile - 1) / tile;
+    if (B > kMaxTilesSplit) return SSME_ERR_UNSUPPORTED;   // at most 16384 tiles per filter (N <= 2^25 with 2048-particle tiles)
     ssme_pf_handle h = new (std::nothrow) ssme_pf_s();
     if (!h) return SSME_ERR_INVALID_ARG;
     h->cfg = *cfg;
     h->shard_rank = shard_rank; h->shard_world = shard_world;
-    h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * kTile;
+    h->tile = tile;
+    h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * tile;
     h->Bs = (B + 1) & ~1; h->Bpow2 = next_pow2(B);
     h->rshift = 52 - ceil_log2(h->Npad);
     h->split_l2 = B > kSplitLevel2Above ? 1 : 0;
     // in-kernel level-2 keeps T' and A/A' of all tiles in LDS (possible up to 2048 tiles, whichever policy is the default)
-    h->lds_bytes = sizeof(double) * (2 * (size_t)(B > kMaxTilesPerFilter ? 2 : (h->Bpow2 < 2 ? 2 : h->Bpow2)) + (size_t)kStageTiles * kTile);
-    h->lds_bytes_big = sizeof(double) * (4 + (size_t)kStageTiles * kTile);
+    h->lds_bytes = sizeof(double) * (2 * (size_t)(B > kMaxTilesPerFilter ? 2 : (h->Bpow2 < 2 ? 2 : h->Bpow2)) + (size_t)kStageTiles * tile);
+    h->lds_bytes_big = sizeof(double) * (4 + (size_t)kStageTiles * tile);
     h->lds_bytes_plan = sizeof(double) * (size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2);
     h->graph_mode = 1;
     h->small_series = 1;
-    h->nt = 512;
+    h->nt = tile == kTileSmall ? 256 : 512;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) { delete h; return SSME_ERR_HIP; }
     {
@@ -399,12 +433,8 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
             HIPCHK(hipMemset(h->tsum[i], 0, sizeof(double) * nb));
             HIPCHK(hipMemset(h->tmax[i], 0, sizeof(double) * nb));
         }
-        HIPCHK(set_lds<MODEL_SVOL>(h->lds_bytes));
-        HIPCHK(set_lds<MODEL_SVOL_LEVERAGE>(h->lds_bytes));
-        HIPCHK(set_lds<MODEL_LIN_GAUSS>(h->lds_bytes));
-        HIPCHK(set_lds_big<MODEL_SVOL>(h->lds_bytes_big));
-        HIPCHK(set_lds_big<MODEL_SVOL_LEVERAGE>(h->lds_bytes_big));
-        HIPCHK(set_lds_big<MODEL_LIN_GAUSS>(h->lds_bytes_big));
+        grant_step_lds(h);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level2_plan), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lds_bytes_plan));
         HIPCHK(hipMalloc(&h->l2_T, sizeof(double) * (size_t)h->R * h->Bs));
@@ -549,18 +579,7 @@ int ssme_pf_shard_step(ssme_pf_handle h, int32_t t, const double* x_win, const d
     a.finalize_prev = t > 0 ? 1 : 0;
     const int Bl = h->B / h->shard_world;
     a.tile0 = h->shard_rank * Bl;
-    const dim3 grid(Bl, 1);
-    if (h->split_l2) {
-        switch (h->cfg.model) {
-            case SSME_MODEL_SVOL: hipLaunchKernelGGL((k_filter_step<MODEL_SVOL, 512, true>), grid, dim3(512), h->lds_bytes_big, h->stream, a); break;
-            case SSME_MODEL_SVOL_LEVERAGE: hipLaunchKernelGGL((k_filter_step<MODEL_SVOL_LEVERAGE, 512, true>), grid, dim3(512), h->lds_bytes_big, h->stream, a); break;
-            default: hipLaunchKernelGGL((k_filter_step<MODEL_LIN_GAUSS, 512, true>), grid, dim3(512), h->lds_bytes_big, h->stream, a); break;
-        }
-    } else switch (h->cfg.model) {
-        case SSME_MODEL_SVOL: hipLaunchKernelGGL((k_filter_step<MODEL_SVOL, 512>), grid, dim3(512), h->lds_bytes, h->stream, a); break;
-        case SSME_MODEL_SVOL_LEVERAGE: hipLaunchKernelGGL((k_filter_step<MODEL_SVOL_LEVERAGE, 512>), grid, dim3(512), h->lds_bytes, h->stream, a); break;
-        default: hipLaunchKernelGGL((k_filter_step<MODEL_LIN_GAUSS, 512>), grid, dim3(512), h->lds_bytes, h->stream, a); break;
-    }
+    launch_step_on(h, a, dim3(Bl, 1));
     HIPCHK(hipGetLastError());
     h->t = t + 1;
     return SSME_OK;
@@ -635,6 +654,7 @@ int ssme_pf_set_debug(ssme_pf_handle h, int32_t flags) {
 int ssme_pf_set_tuning(ssme_pf_handle h, int32_t threads_per_tile) {
     if (!h) return SSME_ERR_INVALID_ARG;
     if (threads_per_tile != 256 && threads_per_tile != 512 && threads_per_tile != 1024) return SSME_ERR_INVALID_ARG;
+    if (h->tile == kTileSmall && threads_per_tile != 256) return SSME_ERR_UNSUPPORTED;     // 512-particle tiles run 256 threads
     h->nt = threads_per_tile;
     return SSME_OK;
 }
@@ -708,7 +728,7 @@ int ssme_pf_run_series(ssme_pf_handle h, const double* y, const double* z, int32
     if (rc != SSME_OK) return rc;
     const bool has_z = z != nullptr;
     const int lw = logw_needed(h) ? 1 : 0;
-    if (h->B == 1 && h->small_series) {
+    if (h->B == 1 && h->tile == kTile && h->small_series) {
         HIPCHK(hipEventRecord(h->ev0, h->stream));
         enqueue_series_small(h, T, has_z);
         HIPCHK(hipEventRecord(h->ev1, h->stream));
@@ -790,7 +810,7 @@ static int enqueue_expectations(ssme_pf_handle h, const int32_t* functionals, in
         fs.id[i] = functionals[i];
     }
     hipLaunchKernelGGL(k_expect_partials, dim3(h->B, h->R), dim3(kThreads), 0, h->stream, h->x[h->cur], h->cdf[h->cur], h->N,
-                       h->Npad, h->Bs, fs, h->exp_part);
+                       h->Npad, h->Bs, h->tile, fs, h->exp_part);
     hipLaunchKernelGGL(k_expect_final, dim3(h->R), dim3(kThreads), 0, h->stream, h->exp_part, h->tsum[h->cur], h->tmax[h->cur],
                        h->B, h->Bs, h->R, fs, h->exp_out);
     HIPCHK(hipGetLastError());
@@ -851,7 +871,7 @@ int ssme_pf_download_weights(ssme_pf_handle h, int32_t f, double* x, double* w) 
     if (!h->wscratch) HIPCHK(hipMalloc(&h->wscratch, sizeof(double) * (size_t)h->Npad));
     const size_t off = (size_t)f * h->Npad;
     hipLaunchKernelGGL(k_weights, dim3(h->B), dim3(kThreads), 0, h->stream, (const double*)(h->cdf[h->cur] + off),
-                       (const double*)(h->tmax[h->cur] + (size_t)f * h->Bs), h->N, h->B, h->wscratch);
+                       (const double*)(h->tmax[h->cur] + (size_t)f * h->Bs), h->N, h->B, h->tile, h->wscratch);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(w, h->wscratch, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
     if (x) HIPCHK(hipMemcpyAsync(x, h->x[h->cur] + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
@@ -898,6 +918,13 @@ int ssme_pf_download_scalars(ssme_pf_handle h, int32_t f, double* max_logw, uint
     if (max_logw) *max_logw = sc.m;
     if (sum_q) *sum_q = (sc.S == sc.S && sc.S > 0.0) ? (uint64_t)sc.S : 0;
     if (rshift) *rshift = h->rshift;
+    return SSME_OK;
+}
+
+int ssme_pf_get_layout(ssme_pf_handle h, int32_t* tile_particles, int32_t* n_tiles) {
+    if (!h) return SSME_ERR_INVALID_ARG;
+    if (tile_particles) *tile_particles = h->tile;
+    if (n_tiles) *n_tiles = h->B;
     return SSME_OK;
 }
 
@@ -986,7 +1013,7 @@ __global__ __launch_bounds__(NT) void k_test_block_scan(const u64* in, u64* incl
     const int tid = threadIdx.x;
     double q[NK][2], inc[NK][2], tot;
     for (int k = 0; k < NK; ++k) { q[k][0] = (double)in[(k * NT + tid) * 2]; q[k][1] = (double)in[(k * NT + tid) * 2 + 1]; }
-    block_scan_f64<NT>(q, inc, tot, lds_seg);
+    block_scan_f64<NT, 1024 / NT>(q, inc, tot, lds_seg);
     for (int k = 0; k < NK; ++k) { incl[(k * NT + tid) * 2] = (u64)inc[k][0]; incl[(k * NT + tid) * 2 + 1] = (u64)inc[k][1]; }
     if (tid == 0) *total = (u64)tot;
 }
@@ -1228,10 +1255,10 @@ static void lw_launch_gamma(ssme_lw_handle h, int t0, int nT) {
                                 h->cfg.first_filter_id, extra);
     };
     hipLaunchKernelGGL(k_gamma_draw, g1, dim3(kThreads), 0, h->stream, h->gamB, h->N, h->B, h->R, t0, kp,
-                       h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA);
+                       h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA, kTile);
     prefix(h->gamB, h->pgamB, h->gtotB, (uint32_t)STREAM_RESAMP_EXTRA);
     hipLaunchKernelGGL(k_gamma_draw, g1, dim3(kThreads), 0, h->stream, h->gamA, h->N, h->B, h->R, t0, kp,
-                       h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA_K);
+                       h->cfg.first_filter_id, (uint32_t)STREAM_GAMMA_K, kTile);
     prefix(h->gamA, h->pgamA, h->gtotA, (uint32_t)STREAM_LW_K_EXTRA);
 }
 
@@ -1240,7 +1267,7 @@ static void lw_launch_plan(ssme_lw_handle h, int draw, int t, int gi, const doub
     a.tsum_in = tsum; a.tmax_in = tmax;
     a.l2_T = h->l2T[draw]; a.l2_R = h->l2R[draw]; a.l2_lo = h->l2lo[draw]; a.l2_hi = h->l2hi[draw];
     a.scal = h->l2s[draw];
-    a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = h->R; a.N = h->N;
+    a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = h->R; a.N = h->N; a.tile = kTile;
     a.resampler = RESAMP_MULTINOMIAL; a.resamp_sched = 1;
     a.t = t; a.gi = gi; a.finalize_prev = 0;
     a.pgam = draw ? h->pgamA : h->pgamB; a.gtot = draw ? h->gtotA : h->gtotB;
@@ -1473,7 +1500,7 @@ int ssme_lw_shard_plan(ssme_lw_handle h, int32_t which, int32_t t, const double*
     }
     StepArgs a{};                                   // the fields k_shard_plan reads
     a.tsum_in = tsum_all; a.tmax_in = tmax_all;
-    a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = 1; a.N = h->N;
+    a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = 1; a.N = h->N; a.tile = kTile;
     a.resampler = RESAMP_MULTINOMIAL; a.resamp_sched = 1;
     a.t = t; a.gi = t;
     a.pgam = which ? h->pgamA : h->pgamB; a.gtot = which ? h->gtotA : h->gtotB;

@@ -29,7 +29,8 @@ typedef unsigned long long u64;
 constexpr int kThreads = 256;            // helper kernels; KA/KR are templated on their block size
 constexpr int kWave = 64;
 constexpr int kRow = 512;
-constexpr int kTile = 2048;
+constexpr int kTile = 2048;                // large tile: N <= 2048 (one-tile series kernel), N > 2^18, Liu-West, sharded filters
+constexpr int kTileSmall = 512;            // small tile: 2048 < N <= 2^18, so that a mid-size filter spreads over the chip (N = 2^16: 128 workgroups)
 constexpr int kMaxTilesPerFilter = 2048;   // in-kernel level-2 (one entry per thread at NT = 512 .. four at 512 threads)
 constexpr int kSplitLevel2Above = 512;     // measured: with more than one tile sum per thread the split level-2 wins (N = 3 2^20: 81 -> 49 us)
 constexpr int kMaxTilesSplit = 16384;      // split level-2 (k_level2_plan + k_filter_step<.., true>): N <= 2^25
@@ -88,6 +89,7 @@ struct StepArgs {
     const double* pgam;        // [nT][R][B] exclusive prefixes of gam
     const double* gtot;        // [nT][R]    sum(gam) + E_{N+1}
     int32_t N, Npad, B, Bs, Bpow2, rshift, R;
+    int32_t tile;              // particles per tile (2048 or 512): part of the arithmetic specification
     int32_t t, yi, gi, Tcap;   // t: time index (RNG counter, schedule); yi / gi: rows of y / gamma tables
     int32_t resampler, resamp_sched;
     int32_t finalize_prev;     // account log p(y_{t-1}|.) of the previous step
@@ -175,16 +177,16 @@ __device__ __forceinline__ double block_max_nanprop(double m, bool nan, double* 
 }
 
 // ---------------------------------------------------------------------------------------
-// Exact inclusive scan of 2048 integer-valued doubles by a block of NT threads (NT = 256, 512, 1024); every partial
-// sum < 2^53, so each v_add_f64 is exact and the sums are associative: any wave/segment decomposition gives the same.
-// Thread tid holds NK = 1024/NT pairs: q[k][c] = value[(k*NT + tid)*2 + c].
+// Exact inclusive scan of P = 2*NT*NK integer-valued doubles by a block of NT threads; every partial sum < 2^53, so each
+// v_add_f64 is exact and the sums are associative: any wave/segment decomposition gives the same.
+// Thread tid holds NK pairs: q[k][c] = value[(k*NT + tid)*2 + c].
 // incl[k][c] = sum of all values up to and including that position; total = sum of all.
 // lds_seg: 16 doubles private to this call (no trailing barrier).  One __syncthreads().
 // ---------------------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ void block_scan_f64(const double (&q)[1024 / NT][2], double (&incl)[1024 / NT][2], double& total,
-                                               double* lds_seg) {
-    constexpr int NK = 1024 / NT, WPR = NT / 64;
+template <int NT, int NK>
+__device__ __forceinline__ void block_scan_f64(const double (&q)[NK][2], double (&incl)[NK][2], double& total, double* lds_seg) {
+    constexpr int WPR = NT / 64, NSEG = NK * WPR;
+    static_assert(NSEG <= 16, "segment totals are scanned inside one 16-lane row");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double s0[NK], s1[NK], exc[NK];
@@ -197,7 +199,7 @@ __device__ __forceinline__ void block_scan_f64(const double (&q)[1024 / NT][2], 
         if (lane == 63) lds_seg[k * WPR + wave] = inc;
     }
     __syncthreads();
-    double sv = lds_seg[lane & 15];
+    double sv = (lane & 15) < NSEG ? lds_seg[lane & 15] : 0.0;
     sv = sv + dpp_f64_zero<0x111, 0xF>(sv);
     sv = sv + dpp_f64_zero<0x112, 0xF>(sv);
     sv = sv + dpp_f64_zero<0x114, 0xF>(sv);
@@ -448,20 +450,25 @@ __device__ __forceinline__ void prio_at(int mode, int idx) {
 
 // ---------------------------------------------------------------------------------------
 // k_filter_step: one bootstrap-filter step for every tile of every filter.
-// grid = (B tiles, R filters), block = NT (256/512/1024: NK = 1024/NT particle pairs per thread),
-// dynamic LDS = (2*max(Bpow2,2) + 3*2048) * 8 bytes.
+// grid = (B tiles, R filters), block = NT threads, NK = TILE/(2 NT) particle pairs per thread (TILE = 2048: NT = 256/512/1024;
+// TILE = 512: NT = 256), dynamic LDS = (2*max(Bpow2,2) + 3*TILE) * 8 bytes.
+// RS >= 0 compiles the reference's configuration in (resampler RS, resampling every step, t > 0, no debug outputs): the
+// uniform branches of the general kernel disappear and the compiler schedules across what they separated; RS = -1 is
+// the general kernel (any resampler / schedule / t = 0 / ancestor and log-weight recording).  Same arithmetic, same bits.
 // Phase order is chosen so that arithmetic hides memory latency: the cdf tiles are requested,
 // then the Box-Muller radii are computed while they arrive; the ancestor states are requested,
 // then the Box-Muller angles are computed while they arrive.
 // ---------------------------------------------------------------------------------------
-template <int MODEL, int NT, bool BIG = false>
+template <int MODEL, int NT, bool BIG = false, int TILE = kTile, int RS = -1>
 __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
-    constexpr int NK = 1024 / NT;
+    constexpr int NK = TILE / 2 / NT;
+    constexpr bool HOT = RS >= 0;
+    static_assert(NK >= 1 && NK * NT * 2 == TILE, "tile = 2 NT NK particles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nT2 = (BIG || a.Bpow2 < 2) ? 2 : a.Bpow2;      // BIG: level-2 comes from k_level2_plan, no tables in LDS
     double* lds_T = reinterpret_cast<double*>(smem);             // [Bpow2] inclusive prefixes of A'
     double* lds_R = lds_T + nT2;                                 // [Bpow2] A_b / A'_b
-    double* lds_stage = lds_T + 2 * nT2;                         // [3][2048] staged cdf tiles, 16-byte aligned
+    double* lds_stage = lds_T + 2 * nT2;                         // [3][TILE] staged cdf tiles, 16-byte aligned
     __shared__ double lds_seg_a[16];
     __shared__ double lds_seg_l2[64];
     __shared__ double lds_seg_c[16];
@@ -476,18 +483,22 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     const int gtile = xcd_tile_of_block((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
     const int r = gtile / (int)gridDim.x, bloc = gtile - r * (int)gridDim.x;
     const int b = bloc + a.tile0;                       // global tile id (tile0 = 0 unless the filter is sharded over GPUs)
-    const int out0 = a.tile0 * kTile, win0 = a.win_tile0 * kTile;
+    const int out0 = a.tile0 * TILE, win0 = a.win_tile0 * TILE;
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const uint32_t key0 = a.keyp[0], key1 = a.keyp[1];
     const size_t rowoff = (size_t)r * a.Npad;
     const ModelConst mc = a.mc[r];
     const double y = a.y[a.yi];
     const double zcov = a.z ? a.z[a.yi] : 0.0;
-    const bool resampled = (a.t > 0) && (a.t % a.resamp_sched == 0);
-    const bool need_l2 = (a.t > 0) && (resampled || (!BIG && bloc == 0 && a.finalize_prev));
-    const bool sorted = a.resampler != RESAMP_MULTINOMIAL_IID;
-    const int i_first = b * kTile;
-    const int nvalid = (a.N - i_first) < kTile ? (a.N - i_first) : kTile;    // valid outputs in this tile (>= 1)
+    const int rsm = HOT ? RS : a.resampler;
+    const bool first_step = !HOT && a.t == 0;
+    const bool resampled = HOT ? true : ((a.t > 0) && (a.t % a.resamp_sched == 0));
+    const bool need_l2 = HOT ? true : ((a.t > 0) && (resampled || (!BIG && bloc == 0 && a.finalize_prev)));
+    const bool sorted = rsm != RESAMP_MULTINOMIAL_IID;
+    uint32_t* const anc_p = HOT ? nullptr : a.anc;
+    double* const logw_p = HOT ? nullptr : a.logw;
+    const int i_first = b * TILE;
+    const int nvalid = (a.N - i_first) < TILE ? (a.N - i_first) : TILE;    // valid outputs in this tile (>= 1)
 
     STAMP(a, 0);
     PRIO_AT(0);
@@ -499,7 +510,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     const double* l2R = a.l2_R + (size_t)r * a.Bs;
     if (tid == 0) { lds_cnt[0] = 0; lds_cnt[1] = 0; }
     double gam = 0.0, pgam = 0.0, pgam_next = 0.0, G = 1.0;
-    const bool multinomial = resampled && a.resampler == RESAMP_MULTINOMIAL;
+    const bool multinomial = resampled && rsm == RESAMP_MULTINOMIAL;
     if (multinomial) {
         const size_t gidx = ((size_t)a.gi * a.R + r) * a.B + b;
         gam = a.gam[gidx]; pgam = a.pgam[gidx]; G = a.gtot[(size_t)a.gi * a.R + r];
@@ -515,11 +526,11 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         // split level-2: S', T', A/A' and this tile's source range were computed once per filter by k_level2_plan
         S = a.scal[r].S;
         double t_lo, t_hi;
-        if (a.resampler == RESAMP_SYSTEMATIC) {
+        if (rsm == RESAMP_SYSTEMATIC) {
             const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, key0, key1);
             u0 = u01_co(ox.v0, ox.v1);
         }
-        tile_target_bounds(a.resampler, S, a.N, i_first, nvalid, pgam, pgam_next, G, u0, t_scale, t_lo, t_hi);
+        tile_target_bounds(rsm, S, a.N, i_first, nvalid, pgam, pgam_next, G, u0, t_scale, t_lo, t_hi);
     }
     if (need_l2 && !BIG) {
         double Ap[NE], Tinc[NE];
@@ -532,11 +543,11 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         STAMP(a, 14);
         // bounds [t_lo, t_hi] of this tile's targets, known to every thread without the spacings
         double t_lo = 0.0, t_hi = dinf();
-        if (a.resampler == RESAMP_SYSTEMATIC) {
+        if (rsm == RESAMP_SYSTEMATIC) {
             const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, key0, key1);
             u0 = u01_co(ox.v0, ox.v1);
         }
-        tile_target_bounds(a.resampler, S, a.N, i_first, nvalid, pgam, pgam_next, G, u0, t_scale, t_lo, t_hi);
+        tile_target_bounds(rsm, S, a.N, i_first, nvalid, pgam, pgam_next, G, u0, t_scale, t_lo, t_hi);
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             if (e * NT < a.Bpow2) {
@@ -590,16 +601,16 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             span = __builtin_amdgcn_readfirstlane(hi) - bb_min + 1;
         }
         if (span <= kStageTiles) {
-            const double* src = cdf_r + (size_t)(bb_min - a.win_tile0) * kTile + tid * 2;
+            const double* src = cdf_r + (size_t)(bb_min - a.win_tile0) * TILE + tid * 2;
 #pragma unroll
             for (int k = 0; k < NK; ++k) stg0[k] = *reinterpret_cast<const double2*>(src + k * NT * 2);
             if (span >= 2) {
 #pragma unroll
-                for (int k = 0; k < NK; ++k) stg1[k] = *reinterpret_cast<const double2*>(src + kTile + k * NT * 2);
+                for (int k = 0; k < NK; ++k) stg1[k] = *reinterpret_cast<const double2*>(src + TILE + k * NT * 2);
             }
             if (span >= 3) {
 #pragma unroll
-                for (int k = 0; k < NK; ++k) stg2[k] = *reinterpret_cast<const double2*>(src + 2 * kTile + k * NT * 2);
+                for (int k = 0; k < NK; ++k) stg2[k] = *reinterpret_cast<const double2*>(src + 2 * TILE + k * NT * 2);
             }
         }
     }
@@ -613,7 +624,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     if (!resampled) __syncthreads();      // the log table is in LDS (the resampling path has passed a barrier already)
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const u32x4 o = pair_words((uint32_t)(b * (kTile / 2) + k * NT + tid), (uint32_t)a.t, rep, key0, key1);
+        const u32x4 o = pair_words((uint32_t)(b * (TILE / 2) + k * NT + tid), (uint32_t)a.t, rep, key0, key1);
         nw0[k] = o.v0; nw1[k] = o.v1;
         if (multinomial) {
             const int i0 = i_first + (k * NT + tid) * 2;
@@ -628,13 +639,13 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         double qe[NK][2];
 #pragma unroll
         for (int k = 0; k < NK; ++k) { qe[k][0] = le[k][0]; qe[k][1] = le[k][1]; }
-        block_scan_f64<NT>(qe, le, se, lds_seg_a);
+        block_scan_f64<NT, NK>(qe, le, se, lds_seg_a);
     }
     STAMP(a, 4);
     PRIO_AT(4);
 
     double xin[NK][2], lw_old[NK][2];
-    if (a.t == 0) {
+    if (first_step) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) { xin[k][0] = 0.0; xin[k][1] = 0.0; lw_old[k][0] = 0.0; lw_old[k][1] = 0.0; }
     } else if (!resampled) {
@@ -642,7 +653,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         for (int k = 0; k < NK; ++k) {
             const size_t idx = rowoff + (size_t)(i_first - out0) + (k * NT + tid) * 2;
             const double2 xv = *reinterpret_cast<const double2*>(a.x_in + idx);
-            const double2 lv = *reinterpret_cast<const double2*>(a.logw + idx);
+            const double2 lv = *reinterpret_cast<const double2*>(logw_p + idx);
             xin[k][0] = xv.x; xin[k][1] = xv.y; lw_old[k][0] = lv.x; lw_old[k][1] = lv.y;
         }
     } else {
@@ -652,20 +663,20 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int i0 = i_first + (k * NT + tid) * 2;
-            if (a.resampler == RESAMP_MULTINOMIAL) {
+            if (rsm == RESAMP_MULTINOMIAL) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const double t1 = ratio * le[k][c];
                     const double t2 = pgam + t1;
                     tau[k][c] = __builtin_ceil(t2 * t_scale);
                 }
-            } else if (a.resampler == RESAMP_SYSTEMATIC) {
+            } else if (rsm == RESAMP_SYSTEMATIC) {
                 tau[k][0] = __builtin_ceil(((double)i0 + u0) * t_scale);
                 tau[k][1] = __builtin_ceil(((double)(i0 + 1) + u0) * t_scale);
             } else {
                 const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, STREAM_RESAMP, key0, key1);
                 const double v0 = u01_co(o.v0, o.v1), v1 = u01_co(o.v2, o.v3);
-                if (a.resampler == RESAMP_STRATIFIED) {
+                if (rsm == RESAMP_STRATIFIED) {
                     tau[k][0] = __builtin_ceil(((double)i0 + v0) * t_scale);
                     tau[k][1] = __builtin_ceil(((double)(i0 + 1) + v1) * t_scale);
                 } else {
@@ -683,11 +694,11 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                 for (int k = 0; k < NK; ++k) *reinterpret_cast<double2*>(dst + k * NT * 2) = stg0[k];
                 if (span >= 2) {
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) *reinterpret_cast<double2*>(dst + kTile + k * NT * 2) = stg1[k];
+                    for (int k = 0; k < NK; ++k) *reinterpret_cast<double2*>(dst + TILE + k * NT * 2) = stg1[k];
                 }
                 if (span >= 3) {
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) *reinterpret_cast<double2*>(dst + 2 * kTile + k * NT * 2) = stg2[k];
+                    for (int k = 0; k < NK; ++k) *reinterpret_cast<double2*>(dst + 2 * TILE + k * NT * 2) = stg2[k];
                 }
             }
             const int b1 = bb_min + 1 < a.B ? bb_min + 1 : a.B - 1, b2 = bb_min + 2 < a.B ? bb_min + 2 : a.B - 1;
@@ -713,7 +724,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                     const double Pb = sel == 0 ? Pm : (sel == 1 ? T0 : T1);
                     const double Rb = sel == 0 ? R0 : (sel == 1 ? R1 : R2);
                     tloc[k][c] = __builtin_ceil((target - Pb) * Rb);
-                    base[k][c] = sel * kTile;
+                    base[k][c] = sel * TILE;
                     pos[k][c] = 0;
                 }
             }
@@ -722,7 +733,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                 for (int k = 0; k < NK; ++k) { pos[k][0] = (int)(d2bits(tloc[k][0]) >> 20) & 2047; pos[k][1] = (int)(d2bits(tloc[k][1]) >> 20) & 2047; }
             } else {
 #pragma unroll
-                for (int step = kTile >> 1; step >= 1; step >>= 1) {
+                for (int step = TILE >> 1; step >= 1; step >>= 1) {
 #pragma unroll
                     for (int k = 0; k < NK; ++k) {
 #pragma unroll
@@ -735,10 +746,10 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             for (int k = 0; k < NK; ++k) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    int anc = bb_min * kTile + base[k][c] + pos[k][c];
+                    int anc = bb_min * TILE + base[k][c] + pos[k][c];
                     anc = anc < a.N - 1 ? anc : a.N - 1;
                     const int i = i_first + (k * NT + tid) * 2 + c;
-                    if (a.anc && i < a.N) a.anc[rowoff + i - out0] = (uint32_t)anc;
+                    if (anc_p && i < a.N) anc_p[rowoff + i - out0] = (uint32_t)anc;
                     xin[k][c] = xin_r[anc - win0];
                     lw_old[k][c] = 0.0;
                 }
@@ -754,12 +765,12 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                     bb = bb < a.B - 1 ? bb : a.B - 1;
                     const double Pb = bb ? (BIG ? l2T[bb - 1] : lds_T[bb - 1]) : 0.0;
                     const double tloc = __builtin_ceil((target - Pb) * (BIG ? l2R[bb] : lds_R[bb]));
-                    const double* tile = cdf_r + (size_t)(bb - a.win_tile0) * kTile;
-                    const int j = count_less_pow2(kTile, tloc, [&](int q) { return tile[q]; });
-                    int anc = bb * kTile + j;
+                    const double* tile = cdf_r + (size_t)(bb - a.win_tile0) * TILE;
+                    const int j = count_less_pow2(TILE, tloc, [&](int q) { return tile[q]; });
+                    int anc = bb * TILE + j;
                     anc = anc < a.N - 1 ? anc : a.N - 1;
                     const int i = i_first + (k * NT + tid) * 2 + c;
-                    if (a.anc && i < a.N) a.anc[rowoff + i - out0] = (uint32_t)anc;
+                    if (anc_p && i < a.N) anc_p[rowoff + i - out0] = (uint32_t)anc;
                     xin[k][c] = xin_r[anc - win0];
                     lw_old[k][c] = 0.0;
                 }
@@ -789,7 +800,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         double xo[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const double xn = (a.t == 0) ? zn[k][c] * mc.a2 : model_prop<MODEL>(mc, xin[k][c], zn[k][c], zcov);
+            const double xn = first_step ? zn[k][c] * mc.a2 : model_prop<MODEL>(mc, xin[k][c], zn[k][c], zcov);
             const double l = lw_old[k][c] + (ABL(a, 3) ? -0.5 * xn * xn : model_logg<MODEL>(mc, y, xn));
             const bool valid = (i0 + c) < a.N;
             xo[c] = valid ? xn : 0.0;
@@ -798,7 +809,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         }
         const size_t idx = rowoff + (size_t)(i0 - out0);
         *reinterpret_cast<double2*>(a.x_out + idx) = make_double2(xo[0], xo[1]);
-        if (a.logw) *reinterpret_cast<double2*>(a.logw + idx) = make_double2(lg[k][0], lg[k][1]);
+        if (logw_p) *reinterpret_cast<double2*>(logw_p + idx) = make_double2(lg[k][0], lg[k][1]);
     }
     STAMP(a, 8);
     PRIO_AT(8);
@@ -821,7 +832,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) { inc[k][0] = q[k][0]; inc[k][1] = q[k][0] + q[k][1]; }
         total = inc[0][1] + 1048576.0;
-    } else block_scan_f64<NT>(q, inc, total, lds_seg_c);
+    } else block_scan_f64<NT, NK>(q, inc, total, lds_seg_c);
     STAMP(a, 12);
     PRIO_AT(12);
 #pragma unroll
@@ -932,8 +943,8 @@ __global__ __launch_bounds__(1024) void k_level2_plan(const StepArgs a, int plan
         for (int b = tid; b < a.B; b += NT) {
             double pg = 0.0, pgn = 0.0;
             if (a.resampler == RESAMP_MULTINOMIAL) { pg = a.pgam[g0 + b]; pgn = (b + 1 < a.B) ? a.pgam[g0 + b + 1] : G; }
-            const int i_first = b * kTile;
-            const int nvalid = (a.N - i_first) < kTile ? (a.N - i_first) : kTile;
+            const int i_first = b * a.tile;
+            const int nvalid = (a.N - i_first) < a.tile ? (a.N - i_first) : a.tile;
             double ts_, t_lo, t_hi;
             tile_target_bounds(a.resampler, S, a.N, i_first, nvalid, pg, pgn, G, u0, ts_, t_lo, t_hi);
             int lo = count_less_pow2(a.Bpow2, t_lo, [&](int j) { return lds_T[j]; });
@@ -995,8 +1006,8 @@ __global__ __launch_bounds__(512) void k_shard_plan(const StepArgs a, int world,
                 const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, a.first_filter, STREAM_RESAMP_EXTRA, key0, key1);
                 u0 = u01_co(ox.v0, ox.v1);
             }
-            const int iF = bF * kTile, iL = bL * kTile;
-            const int nvF = (a.N - iF) < kTile ? (a.N - iF) : kTile, nvL = (a.N - iL) < kTile ? (a.N - iL) : kTile;
+            const int iF = bF * a.tile, iL = bL * a.tile;
+            const int nvF = (a.N - iF) < a.tile ? (a.N - iF) : a.tile, nvL = (a.N - iL) < a.tile ? (a.N - iL) : a.tile;
             double ts, t_lo, t_hi, unused;
             tile_target_bounds(a.resampler, S, a.N, iF, nvF, pgF, pgFn, G, u0, ts, t_lo, unused);
             tile_target_bounds(a.resampler, S, a.N, iL, nvL, pgL, pgLn, G, u0, ts, unused, t_hi);
@@ -1015,12 +1026,12 @@ __global__ __launch_bounds__(512) void k_shard_plan(const StepArgs a, int world,
 // k_gamma_draw: grid = (ceil(B/256), nT, R).  k_gamma_prefix: one workgroup per (ti, r).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_gamma_draw(double* gam, int N, int B, int R, int t0, const uint32_t* keyp,
-                                                         uint32_t first_filter, uint32_t gamma_stream) {
+                                                         uint32_t first_filter, uint32_t gamma_stream, int tile) {
     const uint32_t key0 = keyp[0], key1 = keyp[1];
     const int b = blockIdx.x * kThreads + threadIdx.x;
     const int ti = blockIdx.y, r = blockIdx.z;
     if (b >= B) return;
-    const int nb = (N - b * kTile) < kTile ? (N - b * kTile) : kTile;
+    const int nb = (N - b * tile) < tile ? (N - b * tile) : tile;
     gam[((size_t)ti * R + r) * B + b] = gamma_draw((uint32_t)b, (uint32_t)(t0 + ti), first_filter + (uint32_t)r, key0, key1, (double)nb,
                                                    gamma_stream);
 }
@@ -1094,18 +1105,16 @@ __device__ __forceinline__ double wave_sum_xor(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(kThreads) void k_expect_partials(const double* x, const double* cdf, int N, int Npad, int Bs,
+__global__ __launch_bounds__(kThreads) void k_expect_partials(const double* x, const double* cdf, int N, int Npad, int Bs, int tile,
                                                               FunctionalIds fs, double* part /*[R][Bs][kMaxFunctionals]*/) {
     __shared__ double lds[kMaxFunctionals][4];
     const int tid = threadIdx.x, b = blockIdx.x, r = blockIdx.y;
-    const double* xr = x + (size_t)r * Npad + (size_t)b * kTile;
-    const double* cr = cdf + (size_t)r * Npad + (size_t)b * kTile;
-    const int nvalid = (N - b * kTile) < kTile ? (N - b * kTile) : kTile;
+    const double* xr = x + (size_t)r * Npad + (size_t)b * tile;
+    const double* cr = cdf + (size_t)r * Npad + (size_t)b * tile;
+    const int nvalid = (N - b * tile) < tile ? (N - b * tile) : tile;
     double num[kMaxFunctionals] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < kTile / kThreads; ++k) {
-        const int j = k * kThreads + tid;
-        if (j < nvalid) {
+    for (int j = tid; j < nvalid; j += kThreads) {
+        {
             const double q = cr[j] - (j ? cr[j - 1] : 0.0);
             const double xv = xr[j];
 #pragma unroll
@@ -1167,7 +1176,7 @@ __global__ __launch_bounds__(kThreads) void k_rows_mean(const double* in, int R,
 
 // Normalisable weights of one filter for host-side functionals (arbitrary std::function h: pswarm_filter.h:44,87-89):
 // w_j = q_j exp(m_tile - m) 2^-41  (= exp(logw_j - max logw) to 2^-41).  grid (B), block 256.
-__global__ __launch_bounds__(kThreads) void k_weights(const double* cdf, const double* tmax, int N, int B, double* w) {
+__global__ __launch_bounds__(kThreads) void k_weights(const double* cdf, const double* tmax, int N, int B, int tile, double* w) {
     __shared__ double lds_m[16];
     const int tid = threadIdx.x, b = blockIdx.x;
     double mx = -dinf();
@@ -1175,12 +1184,9 @@ __global__ __launch_bounds__(kThreads) void k_weights(const double* cdf, const d
     for (int j = tid; j < B; j += kThreads) { const double v = tmax[j]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
     const double m = block_max_nanprop<kThreads>(mx, nan, lds_m);
     const double sc = (m != m) ? dnan() : dexp_scaled(tmax[b] - m, -kTileShift);
-    const double* cr = cdf + (size_t)b * kTile;
-#pragma unroll
-    for (int k = 0; k < kTile / kThreads; ++k) {
-        const int j = k * kThreads + tid;
-        if (b * kTile + j < N) w[(size_t)b * kTile + j] = (cr[j] - (j ? cr[j - 1] : 0.0)) * sc;
-    }
+    const double* cr = cdf + (size_t)b * tile;
+    for (int j = tid; j < tile; j += kThreads)
+        if (b * tile + j < N) w[(size_t)b * tile + j] = (cr[j] - (j ? cr[j - 1] : 0.0)) * sc;
 }
 
 }  // namespace ssme

@@ -14,39 +14,6 @@
 
 namespace ssme {
 
-// Exact inclusive scan of P = 2*NT*NK integer-valued doubles (pairs q[k][c] at position (k*NT + tid)*2 + c).
-template <int NT, int NK>
-__device__ __forceinline__ void block_scan_f64_g(const double (&q)[NK][2], double (&incl)[NK][2], double& total, double* lds_seg) {
-    constexpr int WPR = NT / 64, NSEG = NK * WPR;
-    static_assert(NSEG <= 16, "segment totals are scanned inside one 16-lane row");
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double s0[NK], s1[NK], exc[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        s0[k] = q[k][0];
-        s1[k] = s0[k] + q[k][1];
-        const double inc = wave_incl_scan_f64(s1[k]);
-        exc[k] = wave_shr1_f64(inc);
-        if (lane == 63) lds_seg[k * WPR + wave] = inc;
-    }
-    __syncthreads();
-    double sv = (lane & 15) < NSEG ? lds_seg[lane & 15] : 0.0;
-    sv = sv + dpp_f64_zero<0x111, 0xF>(sv);
-    sv = sv + dpp_f64_zero<0x112, 0xF>(sv);
-    sv = sv + dpp_f64_zero<0x114, 0xF>(sv);
-    sv = sv + dpp_f64_zero<0x118, 0xF>(sv);
-    total = readlane_f64(sv, 15);
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int seg = k * WPR + wave;
-        const double pre = seg ? readlane_f64(sv, seg - 1) : 0.0;
-        const double base = pre + exc[k];
-        incl[k][0] = base + s0[k];
-        incl[k][1] = base + s1[k];
-    }
-}
-
 // min(#{ j < P : tile[j] < target }, P-1) for two targets at once by a radix-8 descent: the probes of one level are
 // independent loads, so a search costs log8(P) dependent LDS round trips instead of log2(P) -- this kernel runs one
 // wave per SIMD and is bound by dependent latency, not by issue slots.  Same count as count_less_pow2 (monotone tile).
@@ -158,7 +125,7 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
                 }
             }
             // --- exponential spacings (multinomial), exact scan ---
-            if (multinomial) block_scan_f64_g<NT, NK>(qe, le, se, lds_seg_a);
+            if (multinomial) block_scan_f64<NT, NK>(qe, le, se, lds_seg_a);
         }
 
         double xin[NK][2], lw_old[NK][2];
@@ -245,7 +212,7 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
             q[k][0] = (i0 < a.N) ? __builtin_rint(dexp_scaled(lg[k][0] - mb, kTileShift)) : 0.0;
             q[k][1] = (i0 + 1 < a.N) ? __builtin_rint(dexp_scaled(lg[k][1] - mb, kTileShift)) : 0.0;
         }
-        block_scan_f64_g<NT, NK>(q, inc, total, lds_seg_c);
+        block_scan_f64<NT, NK>(q, inc, total, lds_seg_c);
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int i0 = (k * NT + tid) * 2;

@@ -30,14 +30,18 @@ class ParticleFilterBank:
     """
 
     def __init__(self, model, n_particles, n_filters=1, seed=0, resampler=RESAMP_MULTINOMIAL, resamp_sched=1,
-                 device=0, first_filter_id=0):
+                 device=0, first_filter_id=0, tile=0):
+        """tile: particles per tile, 0 = by N (2048 for N <= 2048 and N > 2^18, 512 in between), or 2048 / 512."""
         self._h = C.c_void_p()
         self.model, self.n, self.r = int(model), int(n_particles), int(n_filters)
         self._last_T = 0
         cfg = capi.Config(model=model, n_particles=n_particles, n_filters=n_filters, dtype=capi.F64,
                           resampler=resampler, resamp_sched=resamp_sched, seed=seed, device=device,
-                          first_filter_id=first_filter_id)
+                          first_filter_id=first_filter_id, tile_particles=tile, reserved=0)
         capi.check(capi.lib().ssme_pf_create(C.byref(cfg), C.byref(self._h)))
+        t, b = C.c_int32(), C.c_int32()
+        capi.check(capi.lib().ssme_pf_get_layout(self._h, C.byref(t), C.byref(b)))
+        self.tile, self.n_tiles = t.value, b.value
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -147,7 +151,7 @@ class ParticleFilterBank:
         anc = np.empty(n, dtype=np.uint32) if ancestors else None
         self._chk(capi.lib().ssme_pf_download_state(self._h, f, capi.dptr(x), capi.dptr(lw), capi.u64ptr(cdf),
                                                     capi.u32ptr(anc)))
-        nt = (n + 2047) // 2048
+        nt = self.n_tiles
         m, s, rs = np.empty(1), np.zeros(1, dtype=np.uint64), C.c_int32()
         A, mb = np.empty(nt, dtype=np.uint64), np.empty(nt)
         self._chk(capi.lib().ssme_pf_download_scalars(self._h, f, capi.dptr(m), capi.u64ptr(s), capi.u64ptr(A),

@@ -126,15 +126,16 @@ def test_quantize_and_exact_cdf(oracle, spy):
     st = f.state()
     # per-tile scales: q = rne(exp(logw - m_tile) 2^41), exact tile-local prefix sums
     tiles, sums = [], []
-    for b, i in enumerate(range(0, 5000, 2048)):
-        lw = st["logw"][i:i + 2048]
+    assert f.tile == 512                                   # 2048 < N <= 2^18: 512-particle tiles
+    for b, i in enumerate(range(0, 5000, f.tile)):
+        lw = st["logw"][i:i + f.tile]
         assert st["mb"][b] == lw.max()
         c = np.cumsum(oracle.quantize(lw - st["mb"][b], 41), dtype=np.uint64)
         tiles.append(c)
         sums.append(c[-1])
     np.testing.assert_array_equal(st["cdf"], np.concatenate(tiles))
     np.testing.assert_array_equal(st["A"], sums)
-    assert st["m"] == st["mb"].max() and st["rshift"] == 52 - 13
+    assert st["m"] == st["mb"].max() and st["rshift"] == 52 - 13           # Npad = 10 tiles x 512 = 5120 <= 2^13
     Ap = oracle.rescale(st["A"], st["mb"] - st["m"], st["rshift"] - 41)
     assert st["S"] == int(sum(int(v) for v in Ap))
     # log-sum-exp from the integers agrees with the floating-point one to ~1e-13

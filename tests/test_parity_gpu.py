@@ -221,6 +221,36 @@ def test_block_size_tuning_is_result_invariant(sa, oracle, spy):
     bank.close()
 
 
+@pytest.mark.parametrize("tile", [512, 2048])
+@pytest.mark.parametrize("n,rs,model", [(2049, 0, 0), (5000, 0, 0), (5000, 1, 1), (40000, 0, 0), (40000, 2, 2), (70000, 3, 0), (300000, 0, 1)])
+def test_tile_sizes_against_oracle(sa, oracle, spy, tile, n, rs, model):
+    """Both tile sizes, chosen explicitly (the default is by N): particles, integer cdf, ancestors, tile sums and per-step
+    log conditional likelihoods bit-exact against the oracle configured with the same tile size; series == steps."""
+    th = {0: [1.0, 0.95, 0.25], 1: [0.9, 0.0, 1.0, -0.1], 2: [0.9, 0.5, 0.7]}[model]
+    T = 6
+    y = spy[:T]
+    z = np.concatenate([[0.0], y[:-1]]) if model == 1 else None
+    bank = sa.ParticleFilterBank(model, n, 2, 9, rs, tile=tile)
+    assert bank.tile == tile and bank.n_tiles == (n + tile - 1) // tile
+    bank.set_debug(True, True)
+    bank.set_params(th)
+    of = oracle.Filter(model, n, th, 9, rep=1, resampler=rs, tile=tile)
+    for t in range(T):
+        lg = bank.step(y[t], None if z is None else z[t])[1]
+        lo = of.step(y[t], 0.0 if z is None else z[t])
+        assert_bits_equal([lg], [lo], f"tile {tile} logcondlike t={t}")
+    sg, so = bank.state(1, ancestors=True), of.state()
+    for key in ("x", "logw"):
+        assert_bits_equal(sg[key], so[key], f"tile {tile}: {key}")
+    np.testing.assert_array_equal(sg["cdf"], so["cdf"])
+    np.testing.assert_array_equal(sg["anc"], so["anc"])
+    np.testing.assert_array_equal(sg["A"], so["A"])
+    per_steps = None
+    ll = bank.run_series(y, z)
+    assert_bits_equal(bank.per_step()[1], oracle.Filter(model, n, th, 9, rep=1, resampler=rs, tile=tile).run_series(y, z)[1], "series")
+    bank.close()
+
+
 def test_resample_schedule(sa, oracle, spy):
     th = [1.0, 0.95, 0.25]
     for rs in (2, 3):

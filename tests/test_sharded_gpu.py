@@ -47,7 +47,7 @@ def test_sharded_filter_is_bit_identical_to_unsharded(tmp_path, spy, world, mode
     res = _run_sharded(tmp_path, world, model, n, T, rs, seed)
     y = spy[:T]
     z = np.concatenate([[0.0], y[:-1]]) if model == 1 else None
-    ref = ssme_amd.ParticleFilterBank(model, n, 1, seed, rs)
+    ref = ssme_amd.ParticleFilterBank(model, n, 1, seed, rs, tile=2048)      # sharded filters use 2048-particle tiles
     ref.set_debug(True, False)
     ref.set_params(TH[model])
     ll = ref.run_series(y, z)[0]
@@ -74,7 +74,7 @@ def test_sharded_filter_with_degenerate_weights(tmp_path, spy):
     res = _run_sharded(tmp_path, world, 1, n, T, 1, seed)
     y = spy[:T]
     z = np.concatenate([[0.0], y[:-1]])
-    ref = ssme_amd.ParticleFilterBank(1, n, 1, seed, 1)
+    ref = ssme_amd.ParticleFilterBank(1, n, 1, seed, 1, tile=2048)
     ref.set_params(TH[1])
     assert float(res[0]["ll"]) == ref.run_series(y, z)[0]
     ref.close()
