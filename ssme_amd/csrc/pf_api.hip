@@ -175,7 +175,7 @@ static int default_tile(int n_particles) { return (n_particles > kTile && n_part
 
 // One launcher per instantiation of the step kernel.  The dynamic-LDS ceiling of a kernel is process-wide state: it is
 // only ever raised (a handle with few tiles must not lower what a handle with many tiles was granted).
-static thread_local int g_grant_only = 0;      // 1: launch_k only raises the LDS ceiling (handle creation), 2: ... of the hot variant
+static thread_local int g_grant_only = 0;      // != 0: launch_k only raises the LDS ceiling (handle creation); 1 general kernel, 2 / 3 the RS = 0 / 1 variants
 template <int MODEL, int NT, bool BIG, int TILE, int RS>
 static void launch_k(ssme_pf_handle h, const StepArgs& a, dim3 grid, size_t lds) {
     static std::atomic<size_t> granted{0};
@@ -188,29 +188,33 @@ static void launch_k(ssme_pf_handle h, const StepArgs& a, dim3 grid, size_t lds)
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, h->stream, a);
 }
 
-// RS: the reference's configuration (multinomial, resampling every step, t > 0, no debug outputs) has its own instantiation
-static bool hot_config(ssme_pf_handle h, const StepArgs& a) {
-    if (g_grant_only) return g_grant_only == 2;
-    return h->cfg.resampler == SSME_RESAMP_MULTINOMIAL && h->cfg.resamp_sched == 1 && a.t > 0 && !a.anc && !a.logw;
+// RS: the common configurations (multinomial -- the reference's -- or systematic resampling, every step, t > 0, no debug
+// outputs) have their own instantiations; returns the RS template argument or -1 for the general kernel
+static int hot_config(ssme_pf_handle h, const StepArgs& a) {
+    if (g_grant_only) return g_grant_only - 2;                       // 1 -> -1 (general), 2 -> 0, 3 -> 1
+    if (h->cfg.resamp_sched != 1 || a.t <= 0 || a.anc || a.logw) return -1;
+    return h->cfg.resampler == SSME_RESAMP_MULTINOMIAL ? 0 : (h->cfg.resampler == SSME_RESAMP_SYSTEMATIC ? 1 : -1);
+}
+
+template <int MODEL, int NT, bool BIG, int TILE>
+static void launch_rs(ssme_pf_handle h, const StepArgs& a, dim3 grid, size_t lds, int rs) {
+    if (rs == 0) launch_k<MODEL, NT, BIG, TILE, 0>(h, a, grid, lds);
+    else if (rs == 1) launch_k<MODEL, NT, BIG, TILE, 1>(h, a, grid, lds);
+    else launch_k<MODEL, NT, BIG, TILE, -1>(h, a, grid, lds);
 }
 
 template <int MODEL>
 static void launch_step_grid(ssme_pf_handle h, const StepArgs& a, dim3 grid) {
-    const bool hot = hot_config(h, a);
+    const int rs = hot_config(h, a);
     if (h->tile == kTileSmall) {
-        if (h->split_l2) { if (hot) launch_k<MODEL, 256, true, kTileSmall, 0>(h, a, grid, h->lds_bytes_big); else launch_k<MODEL, 256, true, kTileSmall, -1>(h, a, grid, h->lds_bytes_big); }
-        else if (hot) launch_k<MODEL, 256, false, kTileSmall, 0>(h, a, grid, h->lds_bytes);
-        else launch_k<MODEL, 256, false, kTileSmall, -1>(h, a, grid, h->lds_bytes);
+        if (h->split_l2) launch_rs<MODEL, 256, true, kTileSmall>(h, a, grid, h->lds_bytes_big, rs);
+        else launch_rs<MODEL, 256, false, kTileSmall>(h, a, grid, h->lds_bytes, rs);
         return;
     }
-    if (h->split_l2) {
-        if (hot) launch_k<MODEL, 512, true, kTile, 0>(h, a, grid, h->lds_bytes_big);
-        else launch_k<MODEL, 512, true, kTile, -1>(h, a, grid, h->lds_bytes_big);
-        return;
-    }
+    if (h->split_l2) { launch_rs<MODEL, 512, true, kTile>(h, a, grid, h->lds_bytes_big, rs); return; }
     switch (h->nt) {
         case 256: launch_k<MODEL, 256, false, kTile, -1>(h, a, grid, h->lds_bytes); break;
-        case 512: if (hot) launch_k<MODEL, 512, false, kTile, 0>(h, a, grid, h->lds_bytes); else launch_k<MODEL, 512, false, kTile, -1>(h, a, grid, h->lds_bytes); break;
+        case 512: launch_rs<MODEL, 512, false, kTile>(h, a, grid, h->lds_bytes, rs); break;
         default: launch_k<MODEL, 1024, false, kTile, -1>(h, a, grid, h->lds_bytes); break;
     }
 }
@@ -226,7 +230,7 @@ static void launch_step(ssme_pf_handle h, const StepArgs& a) { launch_step_on(h,
 static void grant_step_lds(ssme_pf_handle h) {
     const int nt0 = h->nt, sp0 = h->split_l2;
     StepArgs a{};
-    for (int hot = 1; hot <= 2; ++hot)
+    for (int hot = 1; hot <= 3; ++hot)
         for (int sp = 0; sp < 2; ++sp)
             for (int nt : {256, 512, 1024}) {
                 g_grant_only = hot; h->split_l2 = sp; h->nt = nt;

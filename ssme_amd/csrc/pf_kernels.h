@@ -123,8 +123,16 @@ __device__ __forceinline__ double dpp_f64_neginf(double v) {    // fill = -inf
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_f64_zero(double v) {      // fill = +0.0
     const u64 b = d2bits(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROWMASK, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROWMASK, 0xF, false);
+    int lo, hi;
+    if (ROWMASK == 0xF) {
+        // all rows enabled: a lane either has a source lane or is out of range, and bound_ctrl supplies the 0 --
+        // no `old` operand, so the compiler need not zero the destination before every DPP move
+        lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)b, CTRL, 0xF, 0xF, true);
+        hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROWMASK, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROWMASK, 0xF, false);
+    }
     return bits2d(((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo);
 }
 // inclusive wave scan of integer-valued doubles (exact while every partial sum < 2^53)

@@ -24,7 +24,7 @@ def test_adaptor_compiles_and_links():
 
 @pytest.mark.gpu
 def test_adaptor_matches_oracle(oracle, spy):
-    exe = EXE if os.path.exists(EXE) else _build()
+    exe = _build()                       # always from the sources on disk (a stale binary has the old config layout)
     out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "spy_returns.csv")], text=True)
     vals = dict(line.split(" ", 1) for line in out.strip().splitlines())
     th = [1.0, 0.95, 0.25]
@@ -94,8 +94,7 @@ def test_pmmh_harness_compiles():
 def test_pmmh_harness_runs(tmp_path):
     """The shipped example's CLI on the device: 30 iterations, 4 replicate filters of 2000 particles."""
     exe = os.path.join(ROOT, "examples", "estimate_univ_svol_gpu")
-    if not os.path.exists(exe):
-        test_pmmh_harness_compiles()
+    test_pmmh_harness_compiles()         # always from the sources on disk
     import json
     p = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "spy_returns.csv"), str(tmp_path / "samples"),
                         str(tmp_path / "messages"), "30", "4", "2000", "7"], capture_output=True, text=True, check=True)

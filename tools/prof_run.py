@@ -19,6 +19,7 @@ ap.add_argument("--filters", type=int, default=1)
 ap.add_argument("--model", type=int, default=0)
 ap.add_argument("--eager", action="store_true")
 ap.add_argument("--nt", type=int, default=0)
+ap.add_argument("--tile", type=int, default=0, help="particles per tile: 0 = by N, 512 or 2048")
 ap.add_argument("--sweep", action="store_true")
 ap.add_argument("--split", type=int, default=-1, help="1: force the split level-2 (k_level2_plan), 0: force the in-kernel one")
 ap.add_argument("--lw", action="store_true", help="Liu-West filter instead of the bootstrap filter")
@@ -38,15 +39,16 @@ if a.lw:
     print(f"liu-west N={a.n} R={a.filters} loglik {ll[:2]} best ms {best:.3f} us/step {best*1e3/a.T:.2f} "
           f"p-s/s {a.n * a.filters * a.T / (best * 1e-3):.4g} means {g.param_means()[0]}")
     sys.exit(0)
-bank = ssme_amd.ParticleFilterBank(a.model, a.n, a.filters, 20260101, a.resampler)
+bank = ssme_amd.ParticleFilterBank(a.model, a.n, a.filters, 20260101, a.resampler, tile=a.tile)
 if a.eager:
     bank.set_graph_mode(False)
 if a.split >= 0:
     bank.set_debug(False, False, split_level2=bool(a.split))
 bank.set_params(th)
-combos = [256, 512, 1024] if a.sweep else [a.nt or 512]
+combos = [256, 512, 1024] if a.sweep else [a.nt]
 for nt in combos:
-    bank.set_tuning(nt)
+    if nt:
+        bank.set_tuning(nt)
     best = 1e9
     for _ in range(a.passes):
         ll = bank.run_series(y, z)
