@@ -343,14 +343,18 @@ private:
 // test/test_liu_west.cpp:22-157: ctor (delta, phi_l, phi_u, mu_l, mu_u, sig_l, sig_u, rho_l, rho_u[, dte]);
 // filter(y, z), getLogCondLike() (liu_west_filter.h:971-1159).  Transforms as svol_lw_1_par passes them to its base:
 // logit, null, log, twice_fisher (test_liu_west.cpp:70).
-template <std::size_t nparts, typename float_t = double>
+// FORM 0 = auxiliary-particle form (LWFilterWithCovs, svol_lw_1_par); 1 = SISR form (LWFilter2WithCovs::filter,
+// liu_west_filter.h:2191-2343, svol_lw_2_par of test/test_liu_west.cpp:214-358).  gpu_options::resamp_sched = m_rs.
+template <std::size_t nparts, typename float_t = double, int FORM = 0>
 class svol_lw_1_par_gpu {
 public:
     svol_lw_1_par_gpu(const float_t& delta, const float_t& phi_l, const float_t& phi_u, const float_t& mu_l, const float_t& mu_u,
                       const float_t& sig_l, const float_t& sig_u, const float_t& rho_l, const float_t& rho_u, unsigned /*dte*/ = 0,
-                      gpu_options o = gpu_options()) {
+                      gpu_options o = gpu_options(), unsigned filter_id = auto_filter_id) {
         ssme_lw_config c{};
-        c.n_particles = (int)nparts; c.n_filters = 1; c.seed = o.seed; c.device = o.device; c.first_filter_id = 0;
+        c.n_particles = (int)nparts; c.n_filters = 1; c.seed = o.seed; c.device = o.device;
+        c.first_filter_id = detail::resolve_filter_id(filter_id);
+        c.form = FORM; c.resamp_sched = o.resamp_sched;
         c.delta = (double)delta;
         const int tr[4] = {2, 0, 3, 1};
         const double lo[4] = {(double)phi_l, (double)mu_l, (double)sig_l, (double)rho_l};
@@ -375,12 +379,21 @@ public:
         check(ssme_lw_get_param_means(h_.get(), m.data()));
         return m;
     }
+    // getExpectations() for built-in functionals: ids 0-3 = SSME_H_* of the state, 4-7 = phi, mu, sigma, rho
+    std::vector<double> getExpectations(const std::vector<int32_t>& ids) const {
+        std::vector<double> e(ids.size());
+        if (!ids.empty()) check(ssme_lw_get_expectations(h_.get(), ids.data(), (int32_t)ids.size(), e.data()));
+        return e;
+    }
     ssme_lw_handle native() const { return h_.get(); }
 
 private:
     std::shared_ptr<ssme_lw_s> h_;
     float_t last_ = 0;
 };
+
+template <std::size_t nparts, typename float_t = double>
+using svol_lw_2_par_gpu = svol_lw_1_par_gpu<nparts, float_t, 1>;
 
 // ---- SwarmWithCovs over SVOL-leverage members (include/ssme/pswarm_filter.h:325-560; test/test_pswarm.cpp:146-208) ----
 // All nparamparts member filters live in ONE handle (n_filters = nparamparts, one theta row each): update(y, z) is one

@@ -75,9 +75,10 @@ typedef struct ssme_pf_config {
     int32_t  device;           /* HIP device ordinal                                         */
     uint32_t first_filter_id;  /* global id of filter 0 of this handle; enters the Philox
                                   counter, so sharding R over GPUs keeps every stream        */
-    int32_t  tile_particles;   /* particles per tile: 0 = by N (2048 for N <= 2048 and N > 2^18,
-                                  512 in between, so that mid-size filters spread over the
-                                  chip), or 2048 / 512.  Part of the arithmetic specification:
+    int32_t  tile_particles;   /* particles per tile: 2048 or 512, or 0 = chosen from (N, n_filters):
+                                  512 for 2048 < N <= 2^18 when n_filters * ceil(N / 2048) < 512 (a
+                                  mid-size handle then spreads over the chip), else 2048.
+                                  Part of the arithmetic specification:
                                   weights are fixed point relative to their tile's maximum and
                                   the resampler draws one Gamma variate per tile */
     int32_t  reserved;         /* 0 */
@@ -238,6 +239,10 @@ typedef struct ssme_lw_config {
     int32_t  transforms[4];     /* ctor argument `transforms`; svol_lw_1_par: logit, null, log, twice_fisher */
     double   prior_lo[4];       /* paramPriorSamp(): theta_d ~ U(lo_d, hi_d), test_liu_west.cpp:140-150  */
     double   prior_hi[4];
+    int32_t  form;              /* 0: auxiliary-particle form, LWFilterWithCovs::filter (liu_west_filter.h:971-1159, model
+                                   svol_lw_1_par); 1: SISR form, LWFilter2WithCovs::filter (:2191-2343, model svol_lw_2_par,
+                                   test/test_liu_west.cpp:214-358)                                           */
+    int32_t  resamp_sched;      /* m_rs / m_resampSched: resample when (t + 1) % m_rs == 0; 0 or 1 = every step (default) */
 } ssme_lw_config;
 
 int ssme_lw_create(const ssme_lw_config* cfg, ssme_lw_handle* out);
@@ -250,6 +255,13 @@ int ssme_lw_run_series(ssme_lw_handle h, const double* y, const double* z, int32
 int ssme_lw_get_per_step(ssme_lw_handle h, double* out, int32_t T);
 /* weighted means of the untransformed parameters under the last step's weights: out[r*4 + d] */
 int ssme_lw_get_param_means(ssme_lw_handle h, double* out);
+/* E[h | y_{1:t}] under the last step's (pre-resampling) weights for built-in functionals (the reference takes
+ * std::function h(x, z, theta), liu_west_filter.h:1054-1075 / :2267-2290): ids 0-3 = SSME_H_X, SSME_H_X2, SSME_H_VOL,
+ * SSME_H_CONST42 of the state; 4-7 = the untransformed parameters phi, mu, sigma, rho.  out[i*R + r]. */
+int ssme_lw_get_expectations(ssme_lw_handle h, const int32_t* functionals, int32_t n, double* out);
+/* Arbitrary host-side h: particles x (N), UNTRANSFORMED parameters theta[d*N + i] (4N) and weights w (N) of one filter
+ * after the last step, w_i = exp(logw_i - max logw) in the resampler's fixed point; any pointer but w may be NULL. */
+int ssme_lw_download_weights(ssme_lw_handle h, int32_t filter, double* x, double* theta_untrans, double* w);
 /* parity/debug: particles, transformed parameters theta[d*N + i] (getParamSamples()), k indices and resampling
  * ancestors of the last step (after set_debug(1)), theta-bar and the Cholesky factor of (1 - a^2) V (row-major 4x4) */
 int ssme_lw_download_state(ssme_lw_handle h, int32_t filter, double* x, double* theta, uint32_t* kidx, uint32_t* ancestors,

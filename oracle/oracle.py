@@ -96,7 +96,9 @@ def lib():
         L.orc_kalman_loglik.argtypes = [C.c_double, C.c_double, C.c_double, dp, C.c_int, dp]
         i32p = C.POINTER(C.c_int32)
         L.orc_lw_create.restype = C.c_void_p
-        L.orc_lw_create.argtypes = [C.c_int, C.c_uint64, C.c_uint32, i32p, dp, dp, C.c_double]
+        L.orc_lw_create.argtypes = [C.c_int, C.c_uint64, C.c_uint32, i32p, dp, dp, C.c_double, C.c_int, C.c_int]
+        L.orc_lw_expectation.restype = C.c_double
+        L.orc_lw_expectation.argtypes = [C.c_void_p, C.c_int]
         L.orc_lw_destroy.argtypes = [C.c_void_p]
         L.orc_lw_step.restype = C.c_double
         L.orc_lw_step.argtypes = [C.c_void_p, C.c_double, C.c_double]
@@ -105,7 +107,7 @@ def lib():
         L.orc_lw_param_means.argtypes = [C.c_void_p, dp]
         L.orc_lw_state.argtypes = [C.c_void_p, dp, dp, dp, u32p, u32p, dp, dp]
         L.orc_lw_ref_run.restype = C.c_double
-        L.orc_lw_ref_run.argtypes = [C.c_int, i32p, dp, dp, C.c_double, dp, dp, C.c_int, C.c_uint32, dp, dp]
+        L.orc_lw_ref_run.argtypes = [C.c_int, i32p, dp, dp, C.c_double, dp, dp, C.c_int, C.c_uint32, dp, dp, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -191,9 +193,12 @@ def quantize(x, sc):
     return q
 
 
-def default_tile(n):
-    """The device's rule when the caller does not choose a tile size (pf_api.hip: default_tile)."""
-    return 512 if 2048 < n <= (1 << 18) else 2048
+def default_tile(n, n_filters=1):
+    """The device's rule when the caller does not choose a tile size (pf_api.hip: default_tile): 512-particle tiles
+    for 2048 < N <= 2^18 when the handle's filters would fill fewer than 512 workgroups with 2048-particle tiles."""
+    if n <= 2048 or n > (1 << 18):
+        return 2048
+    return 512 if n_filters * ((n + 2047) // 2048) < 512 else 2048
 
 
 class Filter:
@@ -301,14 +306,15 @@ def _i32p(a):
 
 
 class LWFilter:
-    """Kernel-matched Liu-West oracle (auxiliary form with covariates), one filter."""
+    """Kernel-matched Liu-West oracle with covariates, one filter.  form 0: auxiliary form (LWFilterWithCovs), 1: SISR form
+    (LWFilter2WithCovs); resamp_sched = m_rs."""
 
-    def __init__(self, n, seed, rep=0, delta=0.99, transforms=LW_TRANSFORMS, lo=LW_PRIOR_LO, hi=LW_PRIOR_HI):
+    def __init__(self, n, seed, rep=0, delta=0.99, transforms=LW_TRANSFORMS, lo=LW_PRIOR_LO, hi=LW_PRIOR_HI, form=0, resamp_sched=1):
         self.n = int(n)
         tr = np.ascontiguousarray(transforms, dtype=np.int32)
         lo = np.ascontiguousarray(lo, dtype=np.float64)
         hi = np.ascontiguousarray(hi, dtype=np.float64)
-        self._h = lib().orc_lw_create(n, seed, rep, _i32p(tr), _dp(lo), _dp(hi), float(delta))
+        self._h = lib().orc_lw_create(n, seed, rep, _i32p(tr), _dp(lo), _dp(hi), float(delta), int(form), int(resamp_sched))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -327,6 +333,10 @@ class LWFilter:
         lib().orc_lw_param_means(self._h, _dp(out))
         return out
 
+    def expectation(self, functional):
+        """ids 0-3: x, x^2, exp(x/2), 42 of the state; 4-7: untransformed phi, mu, sigma, rho."""
+        return lib().orc_lw_expectation(self._h, int(functional))
+
     def state(self):
         n = self.n
         x, th, lw = np.empty(n), np.empty((4, n)), np.empty(n)
@@ -336,13 +346,15 @@ class LWFilter:
         return dict(x=x, theta=th, logw=lw, kidx=k, anc=a, thetabar=tb, L=L)
 
 
-def lw_ref_run(n, y, z, seed=1, delta=0.99, transforms=LW_TRANSFORMS, lo=LW_PRIOR_LO, hi=LW_PRIOR_HI):
-    """Mode A: reference-faithful Liu-West (mt19937). Returns (loglik, per-step, posterior means of phi, mu, sigma, rho)."""
+def lw_ref_run(n, y, z, seed=1, delta=0.99, transforms=LW_TRANSFORMS, lo=LW_PRIOR_LO, hi=LW_PRIOR_HI, form=0, resamp_sched=1):
+    """Mode A: reference-faithful Liu-West (mt19937), auxiliary (form 0) or SISR (form 1) form, resampling schedule m_rs.
+    Returns (loglik, per-step, posterior means of phi, mu, sigma, rho)."""
     tr = np.ascontiguousarray(transforms, dtype=np.int32)
     lo = np.ascontiguousarray(lo, dtype=np.float64)
     hi = np.ascontiguousarray(hi, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64)
     z = np.ascontiguousarray(z, dtype=np.float64)
     per, means = np.empty(y.size), np.empty(4)
-    ll = lib().orc_lw_ref_run(n, _i32p(tr), _dp(lo), _dp(hi), float(delta), _dp(y), _dp(z), y.size, seed, _dp(per), _dp(means))
+    ll = lib().orc_lw_ref_run(n, _i32p(tr), _dp(lo), _dp(hi), float(delta), _dp(y), _dp(z), y.size, seed, _dp(per), _dp(means),
+                              int(form), int(resamp_sched))
     return ll, per, means

@@ -734,8 +734,16 @@ struct LWFilter {
     std::vector<uint32_t> anc, kidx;
     double thetabar[DP], L[DP][DP];
     double loglik, last_ll, lse1;
+    // form 0: auxiliary-particle form (LWFilterWithCovs::filter, :971-1159); form 1: SISR form (LWFilter2WithCovs::filter,
+    // :2191-2343, model svol_lw_2_par: the proposal is the transition, logFEv - logQEv = 0).  rs = m_rs: resample when
+    // (t + 1) % rs == 0 (:1139-1140, :2317-2318); prev = log-sum-exp of the weights the step starts from.
+    int form = 0, rs = 1;
+    double prev = 0.0;
+    std::vector<double> lwB;           // second-stage log-weights of the last step (carried when no resampling follows)
 
-    void init(int N_, uint64_t seed, uint32_t rep_, const int* tr, const double* lo_, const double* hi_, double delta) {
+    void init(int N_, uint64_t seed, uint32_t rep_, const int* tr, const double* lo_, const double* hi_, double delta,
+              int form_ = 0, int rs_ = 1) {
+        form = form_; rs = rs_ < 1 ? 1 : rs_;
         N = N_; rep = rep_;
         key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32);
         double dummy[3] = {1.0, 0.5, 0.1};
@@ -744,8 +752,9 @@ struct LWFilter {
         B = cdfA.B; Npad = cdfA.Npad;
         for (int d = 0; d < DP; ++d) { trans[d] = tr[d]; lo[d] = lo_[d]; hi[d] = hi_[d]; th[d].assign(Npad, 0.0); thr[d].assign(Npad, 0.0); }
         x.assign(Npad, 0.0); xr.assign(Npad, 0.0); lw1.assign(Npad, 0.0); anc.assign(Npad, 0); kidx.assign(Npad, 0);
+        lwB.assign(Npad, 0.0);
         a_shrink = (3.0 * delta - 1.0) / (2.0 * delta);
-        t = 0; loglik = 0.0; last_ll = 0.0; lse1 = 0.0;
+        t = 0; loglik = 0.0; last_ll = 0.0; lse1 = 0.0; prev = o_log((double)N);
         for (int d = 0; d < DP; ++d) { thetabar[d] = 0.0; for (int e = 0; e < DP; ++e) L[d][e] = 0.0; }
     }
     void words(int idx, int tt, int stream, uint32_t o[4]) const {
@@ -773,27 +782,44 @@ struct LWFilter {
                 cdfB.logw[i] = lw_logg(y, x[i]);
             }
             const double Sd = cdfB.build_cdf();
-            last_ll = (cdfB.m + o_log(Sd)) - logN;
+            const double lseB = cdfB.m + o_log(Sd);
+            last_ll = lseB - prev;                     // prev = log N
+            for (int i = 0; i < N; ++i) lwB[i] = cdfB.logw[i];
+            prev = ((t + 1) % rs == 0) ? logN : lseB;
         } else {
-            // ---- stage 1: resample (x, theta) by the previous second-stage weights (:91-145 via the exact cdf)
+            // ---- stage 1: resample (x, theta) by the previous second-stage weights (:91-145 via the exact cdf) if the
+            //      schedule resampled at the end of step t-1; otherwise the population stays and its weights are carried
+            const bool resampled = (t % rs) == 0;
             std::vector<uint64_t> tau;
-            cdfB.targets(t, tau);
-            for (int i = 0; i < N; ++i) anc[i] = (uint32_t)cdfB.search(tau[i]);
+            if (resampled) {
+                cdfB.targets(t, tau);
+                for (int i = 0; i < N; ++i) anc[i] = (uint32_t)cdfB.search(tau[i]);
+            } else {
+                for (int i = 0; i < N; ++i) anc[i] = (uint32_t)i;
+            }
             std::vector<double> mom[14];
             for (auto& v : mom) v.assign(Npad, 0.0);
             for (int i = 0; i < N; ++i) {
                 xr[i] = x[anc[i]];
                 double tt[DP], tu[DP];
                 for (int d = 0; d < DP; ++d) { tt[d] = th[d][anc[i]]; thr[d][i] = tt[d]; tu[d] = tr_inv(trans[d], tt[d]); }
-                // first-stage weight :985-991 (logGEv ignores its parameter argument in this model)
-                lw1[i] = lw_logg(y, lw_propmu(xr[i], z, tu));
-                cdfA.logw[i] = lw1[i];
+                const double lw_old = resampled ? 0.0 : lwB[i];
+                if (form == 0) {
+                    // first-stage weight :985-991 = carried weight + logG(y | propMu) (logGEv ignores its parameter argument
+                    // in this model); lw1 keeps the logG part alone, which is what stage 2 subtracts (:1041-1043)
+                    lw1[i] = lw_logg(y, lw_propmu(xr[i], z, tu));
+                    cdfA.logw[i] = lw_old + lw1[i];
+                } else {
+                    lw1[i] = lw_old;                   // SISR form: no first stage; the carried weight goes to stage 2
+                }
                 int q = 0;
                 for (int d = 0; d < DP; ++d) mom[q++][i] = tt[d];
                 for (int d = 0; d < DP; ++d) for (int e = 0; e <= d; ++e) mom[q++][i] = tt[d] * tt[e];
             }
-            const double S1 = cdfA.build_cdf();
-            lse1 = cdfA.m + o_log(S1);
+            if (form == 0) {
+                const double S1 = cdfA.build_cdf();
+                lse1 = cdfA.m + o_log(S1);
+            }
             // ---- proposal components :1184-1198 (theta-bar, V over the resampled population), Cholesky of (1-a^2) V
             double sums[14];
             for (int q = 0; q < 14; ++q) {
@@ -818,8 +844,12 @@ struct LWFilter {
                 }
             }
             // ---- stage 2: k ~ Categorical(first-stage weights) :1006, jitter :1024-1027, fSamp, second-stage weight :1030-1033
-            cdfA.targets(t, tau, STREAM_LW_K, STREAM_LW_K_EXTRA, STREAM_GAMMA_K);
-            for (int i = 0; i < N; ++i) kidx[i] = (uint32_t)cdfA.search(tau[i]);
+            if (form == 0) {
+                cdfA.targets(t, tau, STREAM_LW_K, STREAM_LW_K_EXTRA, STREAM_GAMMA_K);
+                for (int i = 0; i < N; ++i) kidx[i] = (uint32_t)cdfA.search(tau[i]);
+            } else {
+                for (int i = 0; i < N; ++i) kidx[i] = (uint32_t)i;       // :2206-2235 every particle continues itself
+            }
             for (int i = 0; i < N; ++i) {
                 const int k = (int)kidx[i];
                 double e[DP];
@@ -838,15 +868,28 @@ struct LWFilter {
                 const double xn = mean + state_normal(i, t) * (tu[2] * std::sqrt(1.0 - tu[3] * tu[3]));
                 x[i] = xn;
                 for (int d = 0; d < DP; ++d) th[d][i] = tn[d];
-                cdfB.logw[i] = lw_logg(y, xn) - lw1[k];
+                cdfB.logw[i] = (form == 0) ? lw_logg(y, xn) - lw1[k] : lw1[k] + lw_logg(y, xn);
             }
             const double S2 = cdfB.build_cdf();
-            // :1047  m1 + log(sum1) + m2 + log(sum2) - 2 m3 - 2 log(sum3), with every old weight = 1 after resampling
-            last_ll = ((cdfB.m + o_log(S2)) + lse1) - 2.0 * logN;
+            const double lseB = cdfB.m + o_log(S2);
+            // form 0, :1047: m1 + log(sum1) + m2 + log(sum2) - 2 m3 - 2 log(sum3); form 1, :2257-2264: lse(new) - lse(old)
+            last_ll = (form == 0) ? (lseB + lse1) - 2.0 * prev : lseB - prev;
+            for (int i = 0; i < N; ++i) lwB[i] = cdfB.logw[i];
+            prev = ((t + 1) % rs == 0) ? logN : lseB;
         }
         loglik += last_ll;
         ++t;
         return last_ll;
+    }
+    // E[h] under the current second-stage weights: ids 0-3 = x, x^2, exp(x/2), 42; 4-7 = untransformed phi, mu, sigma, rho
+    double expectation(int id) const {
+        double den = 0.0, num = 0.0;
+        for (int i = 0; i < N; ++i) {
+            const double w = o_exp(cdfB.logw[i] - cdfB.m);
+            const double hv = id == 0 ? x[i] : id == 1 ? x[i] * x[i] : id == 2 ? o_exp(0.5 * x[i]) : id == 3 ? 42.0 : tr_inv(trans[id - 4], th[id - 4][i]);
+            den += w; num += w * hv;
+        }
+        return num / den;
     }
     // weighted mean of the untransformed parameters under the current second-stage weights
     void param_means(double* out) const {
@@ -865,7 +908,8 @@ struct LWFilter {
 // MVNSampler is restated with a Cholesky factor (pf uses an eigen-decomposition square root [pf-recollection];
 // any square root gives the same law); k_gen = discrete_distribution on max-subtracted weights [pf-recollection].
 double lw_ref_run(int N, const int* tr, const double* lo, const double* hi, double delta, const double* y, const double* z, int T,
-                  uint32_t seed, double* per_step, double* means_out) {
+                  uint32_t seed, double* per_step, double* means_out, int form = 0, int rs = 1) {
+    if (rs < 1) rs = 1;
     std::mt19937 gen(seed), rgen(seed ^ 0x9E3779B9u), kgen(seed ^ 0x85EBCA6Bu);
     std::normal_distribution<double> nd(0.0, 1.0);
     std::uniform_real_distribution<double> ud(0.0, 1.0);
@@ -914,6 +958,7 @@ double lw_ref_run(int N, const int* tr, const double* lo, const double* hi, doub
                 Lc[j][j] = sd > 0 ? std::sqrt(sd) : 0.0;
                 for (int i = j + 1; i < DP; ++i) { double v = V[i][j]; for (int k = 0; k < j; ++k) v -= Lc[i][k] * Lc[j][k]; Lc[i][j] = Lc[j][j] > 0 ? v / Lc[j][j] : 0.0; }
             }
+            if (form == 0) {
             std::vector<double> lw1(N), w1(N);
             double m3 = -INFINITY, m2 = -INFINITY;
             for (int i = 0; i < N; ++i) {
@@ -942,6 +987,28 @@ double lw_ref_run(int N, const int* tr, const double* lo, const double* hi, doub
             }
             for (int i = 0; i < N; ++i) s1 += std::exp(lw[i] - m1);
             ll = m1 + std::log(s1) + m2 + std::log(s2) - 2 * m3 - 2 * std::log(s3);
+            } else {
+            // LWFilter2WithCovs::filter :2196-2264 with svol_lw_2_par (test/test_liu_west.cpp:274-336): jitter, qSamp (= the
+            // transition), weight += logFEv + logGEv - logQEv added and subtracted literally as the reference does
+            std::vector<double> old = lw;
+            const double mold = *std::max_element(old.begin(), old.end());
+            for (int i = 0; i < N; ++i) {
+                double tn[DP], tu[DP], e[DP];
+                for (int d = 0; d < DP; ++d) e[d] = nd(gen);
+                for (int d = 0; d < DP; ++d) { double acc = 0; for (int q = 0; q <= d; ++q) acc += Lc[d][q] * e[q]; tn[d] = a * th[i][d] + (1.0 - a) * tb[d] + acc; tu[d] = inv(tr[d], tn[d]); }
+                const double mean = tu[1] + tu[0] * (x[i] - tu[1]) + zt * tu[3] * tu[2] * std::exp(-0.5 * x[i]);
+                const double sd = tu[2] * std::sqrt(1.0 - tu[3] * tu[3]);
+                const double xn = mean + nd(gen) * sd;
+                lw[i] += evalUnivNormLog<double>(xn, mean, sd);
+                lw[i] += logg(yt, xn);
+                lw[i] -= evalUnivNormLog<double>(xn, mean, sd);
+                x[i] = xn; for (int d = 0; d < DP; ++d) th[i][d] = tn[d];
+            }
+            const double mx = *std::max_element(lw.begin(), lw.end());
+            double s1 = 0, s2 = 0;
+            for (int i = 0; i < N; ++i) { s1 += std::exp(lw[i] - mx); s2 += std::exp(old[i] - mold); }
+            ll = mx + std::log(s1) - mold - std::log(s2);
+            }
         }
         if (per_step) per_step[t] = ll;
         loglik += ll;
@@ -951,8 +1018,8 @@ double lw_ref_run(int N, const int* tr, const double* lo, const double* hi, doub
             for (int i = 0; i < N; ++i) { const double w = std::exp(lw[i] - mx); den += w; for (int d = 0; d < DP; ++d) num[d] += w * inv(tr[d], th[i][d]); }
             for (int d = 0; d < DP; ++d) means_out[d] = num[d] / den;
         }
-        // resample states and parameters (:91-145), weights reset
-        {
+        // resample states and parameters (:91-145), weights reset -- when the schedule says so (:1139-1140, :2317-2318)
+        if ((t + 1) % rs == 0) {
             const double mx = *std::max_element(lw.begin(), lw.end());
             std::vector<double> w(N); for (int i = 0; i < N; ++i) w[i] = std::exp(lw[i] - mx);
             std::discrete_distribution<int> dd(w.begin(), w.end());
@@ -1037,9 +1104,10 @@ double orc_ref_run_series(int model, const double* theta, int N, const double* y
 }
 
 // ---- Liu-West ----
-void* orc_lw_create(int N, uint64_t seed, uint32_t rep, const int* trans, const double* lo, const double* hi, double delta) {
-    LWFilter* f = new LWFilter(); f->init(N, seed, rep, trans, lo, hi, delta); return f;
+void* orc_lw_create(int N, uint64_t seed, uint32_t rep, const int* trans, const double* lo, const double* hi, double delta, int form, int rs) {
+    LWFilter* f = new LWFilter(); f->init(N, seed, rep, trans, lo, hi, delta, form, rs); return f;
 }
+double orc_lw_expectation(void* h, int id) { return ((LWFilter*)h)->expectation(id); }
 void orc_lw_destroy(void* h) { delete (LWFilter*)h; }
 double orc_lw_step(void* h, double y, double z) { return ((LWFilter*)h)->step(y, z); }
 double orc_lw_loglik(void* h) { return ((LWFilter*)h)->loglik; }
@@ -1056,8 +1124,8 @@ void orc_lw_state(void* h, double* x, double* theta, double* logw, uint32_t* kid
     if (L) std::memcpy(L, f->L, sizeof(double) * DP * DP);
 }
 double orc_lw_ref_run(int N, const int* trans, const double* lo, const double* hi, double delta, const double* y, const double* z,
-                      int T, uint32_t seed, double* per_step, double* means_out) {
-    return lw_ref_run(N, trans, lo, hi, delta, y, z, T, seed, per_step, means_out);
+                      int T, uint32_t seed, double* per_step, double* means_out, int form, int rs) {
+    return lw_ref_run(N, trans, lo, hi, delta, y, z, T, seed, per_step, means_out, form, rs);
 }
 
 // replicate aggregation, thread_pool.h:263-268

@@ -29,7 +29,7 @@ EXPORTS = [
     "ssme_pf_strerror", "ssme_pf_last_error",
     "ssme_pf_version",
     "ssme_lw_create", "ssme_lw_destroy", "ssme_lw_reset", "ssme_lw_step", "ssme_lw_run_series", "ssme_lw_get_per_step",
-    "ssme_lw_get_param_means", "ssme_lw_download_state", "ssme_lw_set_debug", "ssme_lw_last_elapsed_ms",
+    "ssme_lw_get_param_means", "ssme_lw_get_expectations", "ssme_lw_download_weights", "ssme_lw_download_state", "ssme_lw_set_debug", "ssme_lw_last_elapsed_ms",
     "ssme_lw_last_error",
     "ssme_lw_shard_create", "ssme_lw_set_stream", "ssme_lw_shard_set_plane_tiles", "ssme_lw_shard_prepare", "ssme_lw_shard_init", "ssme_lw_shard_plan",
     "ssme_lw_shard_stage1", "ssme_lw_shard_mid", "ssme_lw_shard_stage2", "ssme_lw_shard_finalize", "ssme_lw_get_loglik",
@@ -48,7 +48,7 @@ class LwConfig(C.Structure):
     _fields_ = [
         ("n_particles", C.c_int32), ("n_filters", C.c_int32), ("seed", C.c_uint64), ("device", C.c_int32),
         ("first_filter_id", C.c_uint32), ("delta", C.c_double), ("transforms", C.c_int32 * 4),
-        ("prior_lo", C.c_double * 4), ("prior_hi", C.c_double * 4),
+        ("prior_lo", C.c_double * 4), ("prior_hi", C.c_double * 4), ("form", C.c_int32), ("resamp_sched", C.c_int32),
     ]
 
 
@@ -128,6 +128,8 @@ def lib():
         L.ssme_lw_run_series.argtypes = [H, dp, dp, C.c_int32, dp]
         L.ssme_lw_get_per_step.argtypes = [H, dp, C.c_int32]
         L.ssme_lw_get_param_means.argtypes = [H, dp]
+        L.ssme_lw_get_expectations.argtypes = [H, i32p, C.c_int32, dp]
+        L.ssme_lw_download_weights.argtypes = [H, C.c_int32, dp, dp, dp]
         L.ssme_lw_download_state.argtypes = [H, C.c_int32, dp, dp, u32p, u32p, dp, dp]
         L.ssme_lw_set_debug.argtypes = [H, C.c_int32]
         L.ssme_lw_last_elapsed_ms.argtypes = [H, C.POINTER(C.c_float)]

@@ -4,7 +4,14 @@
 // svol_lw_1_par (test/test_liu_west.cpp:82-157), update_parameter_proposal_components (:1184-1198), the
 // multinomial resampler of states and parameters (:91-145) and the inverse parameter transforms
 // (include/ssme/parameters.h:317-457, evaluated per dimension by enum instead of polymorphic objects).
-// Resampling every step (the reference's default schedule).  One time step t >= 1 is three launches:
+// Both forms of the reference's filter family with covariates:
+//   form 0  auxiliary-particle form   LWFilterWithCovs::filter    liu_west_filter.h:971-1159   (model svol_lw_1_par)
+//   form 1  plain SISR form           LWFilter2WithCovs::filter   liu_west_filter.h:2191-2343  (model svol_lw_2_par,
+//           test/test_liu_west.cpp:214-358: qSamp = the transition, so logFEv - logQEv cancels; no first-stage weights,
+//           no k draw: stage 1 only resamples and takes the parameter moments, stage 2 adds logG to the carried weight)
+// and the resampling schedule m_rs (:1139-1140, :2317-2318): resampling is lazy (the draw "of step t-1" runs at the
+// start of step t); on steps without it the populations stay in place and the second-stage log-weights are carried.
+// One time step t >= 1 is three launches:
 //   k_lw_stage1 : resample (x, theta) by the previous second-stage weights (exact integer cdf B, search in LDS,
 //                 gather) -> first-stage weight logG(y, propMu(x, z, theta)) -> cdf A; tile partial sums of the
 //                 14 moments of the transformed parameters
@@ -28,12 +35,14 @@ struct LwScalars {
     double mB, SB;       // level-2 of the second-stage weights of the last step
     double lse1;         // log-sum-exp of the first-stage weights of the last step
     double loglik, last_ll;
-    double pad[3];
+    double prev;         // log-sum-exp of the log-weights the step started from: log N after a resampling, else the last lse
+    double pad[2];
 };
 
 struct LwArgs {
     double* xB; double* thB;                    // [R][Npad], [R][4][Npad]: population after stage 2 (pre-resampling)
-    double* xr; double* thr; double* lw1;       // resampled population and its first-stage log-weights
+    double* xr; double* thr; double* lw1;       // resampled population and (form 0) logG(y | propMu) of it, (form 1) its carried log-weights
+    double* lwB;                                // second-stage log-weights of the last step, kept only when resamp_sched > 1 (else null)
     double *cdfA, *tsumA, *tmaxA;               // exact integer cdf of the first-stage weights
     double *cdfB, *tsumB, *tmaxB;               // ... of the second-stage weights
     double* mom;                                // [R][B][16] tile partial sums of the 14 moments
@@ -47,6 +56,8 @@ struct LwArgs {
     int32_t N, Npad, B, Bs, Bpow2, rshift, R;
     int32_t t, yi, gi, Tcap;
     int32_t finalize_prev;                      // stage 1 accounts log p(y_{t-1} | .) (series mode); 0 in step mode
+    int32_t form;                               // 0: auxiliary-particle form (LWFilterWithCovs), 1: SISR form (LWFilter2WithCovs)
+    int32_t resamp_sched;                       // m_rs: resample when (t + 1) % m_rs == 0
     // particle-sharded filter (all zero / Npad otherwise): this launch computes tiles tile0 .. tile0 + gridDim.x - 1 and
     // stores them at local offsets; the arrays a stage READS (stage 1: xB, thB, cdfB; stage 2: xr, thr, lw1, cdfA) are
     // windows starting at tile win_tile0 with parameter planes th_src_stride apart; written planes are th_dst_stride apart
@@ -263,6 +274,19 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
     __builtin_amdgcn_s_setprio(1);
 }
 
+// Level-2 alone (steps without a resampling draw still account the log-sum-exp of the weights they start from)
+template <bool BIG>
+__device__ __forceinline__ void lw_level2_only(const double* tsum, const double* tmax, int B, int rshift, const LwLds& L,
+                                               double& m_out, double& S_out, const L2View& v) {
+    if constexpr (BIG) { m_out = v.m; S_out = v.S; }
+    else {
+        constexpr int NT = kLwNT, NE = 4;
+        double A2[NE], M2[NE], Ap[NE], Tinc[NE];
+        level2_load<NT>(tsum, tmax, B, A2, M2);
+        level2_scan<NT>(A2, M2, B, rshift, m_out, Ap, Tinc, S_out, L.d1, L.seg_l2);
+    }
+}
+
 // log-weights lg[k][c] of this tile -> tile max, fixed-point weights, exact tile scan; stores cdf / tile sum / tile max
 __device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int N, int i_first, double* cdf_row, double* tsum_row,
                                              double* tmax_row, int b, double* lds_d, double* lds_seg, int tile0 = 0) {
@@ -343,6 +367,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_init(const LwArgs a) {
             if (i >= a.N) { xo[c] = 0.0; lg[k][c] = -dinf(); for (int d = 0; d < kDP; ++d) tho[d][c] = 0.0; }
         }
         *reinterpret_cast<double2*>(a.xB + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
+        if (a.lwB) *reinterpret_cast<double2*>(a.lwB + rowoff + (i0 - out0)) = make_double2(lg[k][0], lg[k][1]);
 #pragma unroll
         for (int d = 0; d < kDP; ++d)
             *reinterpret_cast<double2*>(a.thB + ((size_t)r * kDP + d) * a.th_dst_stride + (i0 - out0)) = make_double2(tho[d][0], tho[d][1]);
@@ -371,7 +396,9 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
     const double G = a.gtotB[(size_t)a.gi * a.R + r];
     const double pgam_next = (b + 1 < a.B) ? a.pgamB[gidx + 1] : G;
 
-    // resample (x, theta) by the previous second-stage weights: liu_west_filter.h:91-145 via the exact cdf
+    // resample (x, theta) by the previous second-stage weights: liu_west_filter.h:91-145 via the exact cdf -- if the
+    // schedule resampled at the end of step t-1 ((t - 1 + 1) % m_rs == 0, :1139-1140); otherwise everything stays in place
+    const bool resampled = (a.t % a.resamp_sched) == 0;
     int anc[NK][2];
     double mB, SB;
     L2View vB{};
@@ -379,16 +406,27 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
         vB.T = a.l2B_T + (size_t)r * a.Bs; vB.R = a.l2B_R + (size_t)r * a.Bs; vB.lo = a.l2B_lo + (size_t)r * a.Bs;
         vB.hi = a.l2B_hi + (size_t)r * a.Bs; vB.m = a.l2B_s[r].m; vB.S = a.l2B_s[r].S;
     }
-    lw_select<BIG>(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.cdfB + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
-                   a.gamB[gidx], a.pgamB[gidx], pgam_next, G, STREAM_RESAMP, (uint32_t)a.t, rep, a.key0, a.key1, L, anc, mB, SB,
-                   a.win_tile0, vB);
+    if (resampled) {
+        lw_select<BIG>(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.cdfB + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
+                       a.gamB[gidx], a.pgamB[gidx], pgam_next, G, STREAM_RESAMP, (uint32_t)a.t, rep, a.key0, a.key1, L, anc, mB, SB,
+                       a.win_tile0, vB);
+    } else {
+        lw_level2_only<BIG>(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.B, a.rshift, L, mB, SB, vB);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { const int i = i_first + (k * NT + tid) * 2 + c; anc[k][c] = i < a.N - 1 ? i : a.N - 1; }
+        }
+    }
     if (bloc == 0 && tid == 0 && a.finalize_prev) {
-        // log p(y_{t-1} | y_{1:t-2}): :1047 with all old weights equal after resampling; :1136 at t-1 = 0
+        // log p(y_{t-1} | y_{1:t-2}).  Auxiliary form: :1047-1051 (two log-sum-exps minus twice that of the weights the step
+        // started from; :1136 at t-1 = 0); SISR form: :2257-2264 (:2301 at t-1 = 0).
         LwScalars* sc = a.scal + r;
         const double Sd = (SB > 0.0) ? dldexp(SB, -a.rshift) : dnan();
         const double lseB = mB + dlog(Sd);
-        const double ll = (a.t == 1) ? lseB - a.logN : (lseB + sc->lse1) - 2.0 * a.logN;
+        const double ll = (a.form == 0 && a.t > 1) ? (lseB + sc->lse1) - 2.0 * sc->prev : lseB - sc->prev;
         sc->mB = mB; sc->SB = SB; sc->last_ll = ll; sc->loglik = sc->loglik + ll;
+        sc->prev = resampled ? a.logN : lseB;
         if (a.per_step) a.per_step[(size_t)r * a.Tcap + (a.t - 1)] = ll;
     }
     double lg[NK][2];
@@ -397,7 +435,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int i0 = i_first + (k * NT + tid) * 2;
-        double xo[2], tt[kDP][2];
+        double xo[2], tt[kDP][2], g1[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int j = anc[k][c];
@@ -411,9 +449,14 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
             double tu[kDP];
 #pragma unroll
             for (int d = 0; d < kDP; ++d) tu[d] = tr_inv(a.trans[d], tt[d][c]);
-            lg[k][c] = lw_logg(y, lw_propmu(xo[c], z, tu));          // first-stage weight, :985-991
+            // the log-weight this particle starts the step with: 0 after a resampling, else the carried second-stage weight
             const bool valid = (i0 + c) < a.N;
-            if (!valid) { xo[c] = 0.0; lg[k][c] = -dinf(); }
+            const double lw_old = (resampled || !valid) ? 0.0 : a.lwB[rowoff + (i0 - out0) + c];
+            // form 0: first-stage weight :985-991 = carried weight + logG(y | propMu); g1 alone is what stage 2 subtracts (:1041-1043)
+            // form 1: no first stage; the carried weight travels to stage 2 in the same buffer
+            g1[c] = (a.form == 0) ? lw_logg(y, lw_propmu(xo[c], z, tu)) : lw_old;
+            lg[k][c] = (a.form == 0) ? lw_old + g1[c] : lw_old;
+            if (!valid) { xo[c] = 0.0; lg[k][c] = -dinf(); g1[c] = -dinf(); }
             // moments of the transformed parameters (:1189-1193); canonical tree: fold the tile halves (k), then the pair (c)
             int q = 0;
 #pragma unroll
@@ -425,7 +468,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
             }
         }
         *reinterpret_cast<double2*>(a.xr + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
-        *reinterpret_cast<double2*>(a.lw1 + rowoff + (i0 - out0)) = make_double2(lg[k][0], lg[k][1]);
+        *reinterpret_cast<double2*>(a.lw1 + rowoff + (i0 - out0)) = make_double2(g1[0], g1[1]);
 #pragma unroll
         for (int d = 0; d < kDP; ++d)
             *reinterpret_cast<double2*>(a.thr + ((size_t)r * kDP + d) * a.th_dst_stride + (i0 - out0)) = make_double2(tt[d][0], tt[d][1]);
@@ -436,8 +479,9 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
         const double s = wave_incl_scan_f64(fold[q][0] + fold[q][1]);
         if ((tid & 63) == 63) lds_mom[tid >> 6][q] = s;
     }
-    lw_store_cdf(lg, a.N, i_first, a.cdfA + rowoff, a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, a.tile0);
-    // (lw_store_cdf contains barriers after the lds_mom writes)
+    if (a.form == 0) lw_store_cdf(lg, a.N, i_first, a.cdfA + rowoff, a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, a.tile0);
+    else __syncthreads();
+    // (a barrier after the lds_mom writes either way)
     if (tid < kNMom) {
         double s = 0.0;
 #pragma unroll
@@ -456,7 +500,8 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid(const LwArgs a) {
     __shared__ double sums[kNMom];
     const int tid = threadIdx.x, r = blockIdx.x;
     double A2[8], Ap[8], Tinc[8], M2[8], S, m;
-    if (!BIG) level2_load<kThreads>(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.B, A2, M2);
+    const bool aux = a.form == 0;                  // the SISR form has no first-stage weights
+    if (!BIG && aux) level2_load<kThreads>(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.B, A2, M2);
     // moment totals: wave w handles moments w, w+4, ...: 64 lanes add contiguous chunks of tiles in order, then the wave tree
     const int lane = tid & 63, wave = tid >> 6;
     const int c = (a.B + 63) / 64;
@@ -487,13 +532,16 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid(const LwArgs a) {
             if (lane == 63 && q < kNMom) sums[q] = sw;
         }
     }
-    if (BIG) { m = a.l2A_s[r].m; S = a.l2A_s[r].S; }
-    else level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
+    m = 0.0; S = 0.0;
+    if (aux) {
+        if (BIG) { m = a.l2A_s[r].m; S = a.l2A_s[r].S; }
+        else level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
+    }
     __syncthreads();
     if (tid == 0) {
         LwScalars* sc = a.scal + r;
         const double Sd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
-        sc->lse1 = m + dlog(Sd);
+        if (aux) sc->lse1 = m + dlog(Sd);
         const double invN = 1.0 / (double)a.N;
         double tb[kDP], Sig[kDP][kDP], Lc[kDP][kDP];
         for (int d = 0; d < kDP; ++d) tb[d] = sums[d] * invN;
@@ -540,7 +588,8 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
 #pragma unroll
     for (int q = 0; q < 14; ++q) prop[q] = a.prop[(size_t)r * 16 + q];
 
-    // k ~ Categorical(first-stage weights): k_gen.sample, :1006
+    // form 0: k ~ Categorical(first-stage weights): k_gen.sample, :1006 (every step, whatever the resampling schedule);
+    // form 1: every particle continues itself (:2206-2235)
     int kk[NK][2];
     double mA, SA;
     L2View vA{};
@@ -548,9 +597,17 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
         vA.T = a.l2A_T + (size_t)r * a.Bs; vA.R = a.l2A_R + (size_t)r * a.Bs; vA.lo = a.l2A_lo + (size_t)r * a.Bs;
         vA.hi = a.l2A_hi + (size_t)r * a.Bs; vA.m = a.l2A_s[r].m; vA.S = a.l2A_s[r].S;
     }
-    lw_select<BIG>(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.cdfA + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
-                   a.gamA[gidx], a.pgamA[gidx], pgam_next, G, STREAM_LW_K, (uint32_t)a.t, rep, a.key0, a.key1, L, kk, mA, SA,
-                   a.win_tile0, vA);
+    if (a.form == 0) {
+        lw_select<BIG>(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.cdfA + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
+                       a.gamA[gidx], a.pgamA[gidx], pgam_next, G, STREAM_LW_K, (uint32_t)a.t, rep, a.key0, a.key1, L, kk, mA, SA,
+                       a.win_tile0, vA);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { const int i = i_first + (k * NT + tid) * 2 + c; kk[k][c] = i < a.N - 1 ? i : a.N - 1; }
+        }
+    }
     double lg[NK][2];
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -590,11 +647,14 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
             }
             const double mean = (tu[1] + tu[0] * (xk - tu[1])) + ((z * tu[3]) * tu[2]) * dexp(-0.5 * xk);       // fSamp :114-121
             xo[c] = mean + zs[c] * (tu[2] * dsqrt(1.0 - tu[3] * tu[3]));
-            lg[k][c] = lw_logg(y, xo[c]) - lw1k;                                         // :1032-1033
+            // form 0: logG(y | x', theta') - logG(y | propMu_k, m_k)  (:1041-1043);  form 1: carried weight + logG  (:2223-2225,
+            // where logFEv - logQEv vanishes: svol_lw_2_par proposes from the transition)
+            lg[k][c] = (a.form == 0) ? lw_logg(y, xo[c]) - lw1k : lw1k + lw_logg(y, xo[c]);
             if (a.kidx && i < a.N) a.kidx[rowoff + (i - out0)] = (uint32_t)j;
             if (i >= a.N) { xo[c] = 0.0; lg[k][c] = -dinf(); }
         }
         *reinterpret_cast<double2*>(a.xB + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
+        if (a.lwB) *reinterpret_cast<double2*>(a.lwB + rowoff + (i0 - out0)) = make_double2(lg[k][0], lg[k][1]);
 #pragma unroll
         for (int d = 0; d < kDP; ++d)
             *reinterpret_cast<double2*>(a.thB + ((size_t)r * kDP + d) * a.th_dst_stride + (i0 - out0)) = make_double2(tho[d][0], tho[d][1]);
@@ -620,17 +680,21 @@ __global__ __launch_bounds__(kThreads) void k_lw_finalize(const LwArgs a) {
         LwScalars* sc = a.scal + r;
         const double Sd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
         const double lseB = m + dlog(Sd);
-        const double ll = (a.t == 0) ? lseB - a.logN : (lseB + sc->lse1) - 2.0 * a.logN;
+        const double ll = (a.form == 0 && a.t > 0) ? (lseB + sc->lse1) - 2.0 * sc->prev : lseB - sc->prev;
         sc->mB = m; sc->SB = S; sc->last_ll = ll; sc->loglik = sc->loglik + ll;
+        sc->prev = ((a.t + 1) % a.resamp_sched == 0) ? a.logN : lseB;
         if (a.per_step) a.per_step[(size_t)r * a.Tcap + a.t] = ll;
     }
 }
 
-// Weighted means of the untransformed parameters under the last second-stage weights, two launches:
-// k_lw_param_partials, grid = (B tiles, R): per-tile sums of w and w * theta_d with w = q_j exp(m_tile - m), into the
-// moment scratch mom[r][b][0..4]; k_lw_param_means, grid = (R): adds the tile partials in tile order and divides.
+// Weighted expectations under the last second-stage (pre-resampling) weights, two launches (getExpectations(),
+// liu_west_filter.h:1054-1075 / :2267-2290, for built-in functionals):
+// k_lw_param_partials, grid = (B tiles, R): per-tile sums of w, w theta_d (untransformed), w x, w x^2, w exp(x/2) with
+// w = q_j exp(m_tile - m), into the moment scratch mom[r][b][0..7]; k_lw_param_means, grid = (R): adds the tile partials
+// in tile order and divides: out[r][0..3] = E[theta_d], [4] = E[x], [5] = E[x^2], [6] = E[exp(x/2)], [7] = E[42].
+constexpr int kLwNExp = 8;
 __global__ __launch_bounds__(kThreads) void k_lw_param_partials(const LwArgs a) {
-    __shared__ double lds_n[4][kDP + 1];
+    __shared__ double lds_n[4][kLwNExp];
     __shared__ double lds_m[16];
     const int tid = threadIdx.x, b = blockIdx.x, r = blockIdx.y;
     double mx = -dinf();
@@ -638,30 +702,56 @@ __global__ __launch_bounds__(kThreads) void k_lw_param_partials(const LwArgs a) 
     for (int j = tid; j < a.B; j += kThreads) { const double v = a.tmaxB[(size_t)r * a.Bs + j]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
     const double m = block_max_nanprop<kThreads>(mx, nan, lds_m);
     const double scale = dexp(a.tmaxB[(size_t)r * a.Bs + b] - m);
-    double acc[kDP + 1] = {0, 0, 0, 0, 0};
+    double acc[kLwNExp] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int i_end = ((b + 1) * kTile < a.N) ? (b + 1) * kTile : a.N;
     for (int i = b * kTile + tid; i < i_end; i += kThreads) {
         const double c1 = a.cdfB[(size_t)r * a.Npad + i];
         const double c0 = (i & (kTile - 1)) ? a.cdfB[(size_t)r * a.Npad + i - 1] : 0.0;
         const double w = (c1 - c0) * scale;
+        const double xv = a.xB[(size_t)r * a.Npad + i];
         acc[kDP] += w;
         for (int d = 0; d < kDP; ++d) acc[d] += w * tr_inv(a.trans[d], a.thB[((size_t)r * kDP + d) * a.Npad + i]);
+        acc[5] += w * xv;
+        acc[6] += w * (xv * xv);
+        acc[7] += w * dexp(0.5 * xv);
     }
-    for (int q = 0; q <= kDP; ++q) {
+    for (int q = 0; q < kLwNExp; ++q) {
         double v = acc[q];
         for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, kWave);
         if ((tid & 63) == 0) lds_n[tid >> 6][q] = v;
     }
     __syncthreads();
-    if (tid <= kDP) a.mom[((size_t)r * a.B + b) * 16 + tid] = ((lds_n[0][tid] + lds_n[1][tid]) + lds_n[2][tid]) + lds_n[3][tid];
+    if (tid < kLwNExp) a.mom[((size_t)r * a.B + b) * 16 + tid] = ((lds_n[0][tid] + lds_n[1][tid]) + lds_n[2][tid]) + lds_n[3][tid];
 }
 
-__global__ __launch_bounds__(kWave) void k_lw_param_means(const LwArgs a, double* out /*[R][4]*/) {
+__global__ __launch_bounds__(kWave) void k_lw_param_means(const LwArgs a, double* out /*[R][8]*/) {
     const int r = blockIdx.x, q = threadIdx.x;
     double t = 0.0;
-    if (q <= kDP) for (int b = 0; b < a.B; ++b) t = t + a.mom[((size_t)r * a.B + b) * 16 + q];
+    if (q < kLwNExp) for (int b = 0; b < a.B; ++b) t = t + a.mom[((size_t)r * a.B + b) * 16 + q];
     const double den = __shfl(t, kDP, kWave);
-    if (q < kDP) out[(size_t)r * kDP + q] = t / den;
+    if (q < kDP) out[(size_t)r * kLwNExp + q] = t / den;
+    else if (q == kDP) out[(size_t)r * kLwNExp + 7] = 42.0 * (den / den);          // NaN weights stay NaN
+    else if (q < kLwNExp) out[(size_t)r * kLwNExp + q - 1] = t / den;               // x, x^2, exp(x/2) -> slots 4, 5, 6
+}
+
+// weights w_j = q_j exp(m_tile - m) 2^-41 and UNTRANSFORMED parameters of one filter, for host-side functionals.
+// grid = (B), block = 256.  out: w[Npad], theta[4][Npad]
+__global__ __launch_bounds__(kThreads) void k_lw_weights(const LwArgs a, int r, double* out) {
+    __shared__ double lds_m[16];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    double mx = -dinf();
+    bool nan = false;
+    for (int j = tid; j < a.B; j += kThreads) { const double v = a.tmaxB[(size_t)r * a.Bs + j]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
+    const double m = block_max_nanprop<kThreads>(mx, nan, lds_m);
+    const double sc = (m != m) ? dnan() : dexp_scaled(a.tmaxB[(size_t)r * a.Bs + b] - m, -kTileShift);
+    for (int j = tid; j < kTile; j += kThreads) {
+        const int i = b * kTile + j;
+        if (i >= a.N) break;
+        const double c1 = a.cdfB[(size_t)r * a.Npad + i];
+        const double c0 = j ? a.cdfB[(size_t)r * a.Npad + i - 1] : 0.0;
+        out[i] = (c1 - c0) * sc;
+        for (int d = 0; d < kDP; ++d) out[(size_t)(1 + d) * a.Npad + i] = tr_inv(a.trans[d], a.thB[((size_t)r * kDP + d) * a.Npad + i]);
+    }
 }
 
 }  // namespace ssme

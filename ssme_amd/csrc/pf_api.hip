@@ -168,10 +168,17 @@ static StepArgs step_args(ssme_pf_handle h) {
     return a;
 }
 
-// Tile size by N when the caller does not choose (part of the arithmetic specification: the oracle applies the same rule).
-// One tile for N <= 2048 (the whole-series kernel), 512-particle tiles up to 2^18 particles so that a mid-size filter
-// spreads over the chip (N = 2^16: 128 workgroups instead of 32), 2048-particle tiles above.
-static int default_tile(int n_particles) { return (n_particles > kTile && n_particles <= (1 << 18)) ? kTileSmall : kTile; }
+// Tile size when the caller does not choose (part of the arithmetic specification: the oracle applies the same rule).
+// 2048-particle tiles are the efficient shape (fewer, fatter workgroups; N <= 2048 is the whole-series kernel).  A handle
+// whose filters would occupy fewer than 512 workgroups that way (two per CU) and whose N lies in (2048, 2^18] gets
+// 512-particle tiles instead, so that mid-size filters spread over the chip (one filter of 2^16: 128 workgroups
+// instead of 32, 10.2 -> 7.3 us per step).  The rule reads the handle's (N, n_filters): callers that shard filters over
+// GPUs and want results independent of the sharding pass tile_particles explicitly.
+static int default_tile(int n_particles, int n_filters) {
+    if (n_particles <= kTile || n_particles > (1 << 18)) return kTile;
+    const long big_tiles = (long)n_filters * ((n_particles + kTile - 1) / kTile);
+    return big_tiles < 512 ? kTileSmall : kTile;
+}
 
 // One launcher per instantiation of the step kernel.  The dynamic-LDS ceiling of a kernel is process-wide state: it is
 // only ever raised (a handle with few tiles must not lower what a handle with many tiles was granted).
@@ -395,7 +402,7 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     if (cfg->resamp_sched < 1) return SSME_ERR_INVALID_ARG;
     if (cfg->dtype != SSME_F64) return SSME_ERR_UNSUPPORTED;
     if (cfg->tile_particles != 0 && cfg->tile_particles != kTile && cfg->tile_particles != kTileSmall) return SSME_ERR_INVALID_ARG;
-    const int tile = shard_world > 0 ? kTile : (cfg->tile_particles ? cfg->tile_particles : default_tile(cfg->n_particles));
+    const int tile = shard_world > 0 ? kTile : (cfg->tile_particles ? cfg->tile_particles : default_tile(cfg->n_particles, cfg->n_filters));
     const int B = (cfg->n_particles + tile - 1) / tile;
     if (B > kMaxTilesSplit) return SSME_ERR_UNSUPPORTED;   // at most 16384 tiles per filter (N <= 2^25 with 2048-particle tiles)
     ssme_pf_handle h = new (std::nothrow) ssme_pf_s();
@@ -1171,6 +1178,9 @@ struct ssme_lw_s {
     hipEvent_t ev0, ev1;
     float last_ms;
     double *xB, *thB, *xr, *thr, *lw1, *cdfA, *tsumA, *tmaxA, *cdfB, *tsumB, *tmaxB, *mom, *prop;
+    double* lwB;                     // carried second-stage log-weights (resamp_sched > 1 only)
+    double* wscratch;                // [5][Npad] weights + untransformed parameters of one filter (host-side functionals)
+    int form, rs;                    // 0 auxiliary form / 1 SISR form; resampling schedule m_rs
     double *ybuf, *zbuf, *per_step, *scratch;
     double *gamA, *pgamA, *gtotA, *gamB, *pgamB, *gtotB;
     uint32_t *anc, *kidx, *keybuf;
@@ -1199,6 +1209,7 @@ static int lw_fail(ssme_lw_handle h, const char* what, hipError_t e) {
 static LwArgs lw_args(ssme_lw_handle h) {
     LwArgs a{};
     a.xB = h->xB; a.thB = h->thB; a.xr = h->xr; a.thr = h->thr; a.lw1 = h->lw1;
+    a.lwB = h->rs > 1 ? h->lwB : nullptr; a.form = h->form; a.resamp_sched = h->rs;
     a.cdfA = h->cdfA; a.tsumA = h->tsumA; a.tmaxA = h->tmaxA; a.cdfB = h->cdfB; a.tsumB = h->tsumB; a.tmaxB = h->tmaxB;
     a.mom = h->mom; a.prop = h->prop;
     a.anc = (h->debug & 1) ? h->anc : nullptr; a.kidx = (h->debug & 1) ? h->kidx : nullptr;
@@ -1284,12 +1295,13 @@ static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record
     a.t = t; a.yi = yi; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
     a.per_step = record ? h->per_step : nullptr;
     const dim3 grid(h->B, h->R);
+    const bool resampled = (t % h->rs) == 0;           // a resampling draw closes step t-1 (lazily: it runs at the start of step t)
     if (t == 0) {
         hipLaunchKernelGGL(k_lw_init, grid, dim3(kLwNT), 0, h->stream, a);
     } else if (h->split_l2) {
-        lw_launch_plan(h, 0, t, gi, h->tsumB, h->tmaxB, true);
+        lw_launch_plan(h, 0, t, gi, h->tsumB, h->tmaxB, resampled);
         hipLaunchKernelGGL(k_lw_stage1<true>, grid, dim3(kLwNT), h->lds_bytes_big, h->stream, a);
-        lw_launch_plan(h, 1, t, gi, h->tsumA, h->tmaxA, true);
+        if (h->form == 0) lw_launch_plan(h, 1, t, gi, h->tsumA, h->tmaxA, true);
         hipLaunchKernelGGL(k_lw_mid<true>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
         hipLaunchKernelGGL(k_lw_stage2<true>, grid, dim3(kLwNT), h->lds_bytes_big, h->stream, a);
     } else {
@@ -1311,7 +1323,8 @@ static void lw_enqueue_finalize(ssme_lw_handle h, int t, bool record) {
 
 static int lw_reset(ssme_lw_handle h) {
     std::vector<LwScalars> sc(h->R);
-    for (auto& s : sc) std::memset(&s, 0, sizeof(s));
+    const double logN = dlog((double)h->N);
+    for (auto& s : sc) { std::memset(&s, 0, sizeof(s)); s.prev = logN; }
     LWCHK(hipMemcpyAsync(h->scal, sc.data(), sizeof(LwScalars) * h->R, hipMemcpyHostToDevice, h->stream));
     LWCHK(hipStreamSynchronize(h->stream));
     h->t = 0;
@@ -1329,7 +1342,7 @@ int ssme_lw_destroy(ssme_lw_handle h) {
     void* bufs[] = {h->xB, h->thB, h->xr, h->thr, h->lw1, h->cdfA, h->tsumA, h->tmaxA, h->cdfB, h->tsumB, h->tmaxB, h->mom, h->prop,
                     h->ybuf, h->zbuf, h->per_step, h->scratch, h->gamA, h->pgamA, h->gtotA, h->gamB, h->pgamB, h->gtotB, h->anc,
                     h->kidx, h->scal, h->keybuf, h->plan_dev, h->l2T[0], h->l2T[1], h->l2R[0], h->l2R[1], h->l2lo[0], h->l2lo[1],
-                    h->l2hi[0], h->l2hi[1], h->l2s[0], h->l2s[1]};
+                    h->l2hi[0], h->l2hi[1], h->l2s[0], h->l2s[1], h->lwB, h->wscratch};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->plan_pin) hipHostFree(h->plan_pin);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -1344,6 +1357,8 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
     *out = nullptr;
     if (cfg->n_particles < 1 || cfg->n_filters < 1 || cfg->n_filters > 65535) return SSME_ERR_INVALID_ARG;
     if (!(cfg->delta > 0.0 && cfg->delta <= 1.0)) return SSME_ERR_INVALID_ARG;
+    if (cfg->form < 0 || cfg->form > 1 || cfg->resamp_sched < 0) return SSME_ERR_INVALID_ARG;
+    if (shard_world > 0 && (cfg->form != 0 || cfg->resamp_sched > 1)) return SSME_ERR_UNSUPPORTED;   // sharded: auxiliary form, every step
     for (int d = 0; d < kDP; ++d) {
         if (cfg->transforms[d] < 0 || cfg->transforms[d] > 3) return SSME_ERR_INVALID_ARG;     // parameters.h:283 invalid_argument
         if (!(cfg->prior_lo[d] <= cfg->prior_hi[d])) return SSME_ERR_INVALID_ARG;
@@ -1353,6 +1368,7 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
     ssme_lw_handle h = new (std::nothrow) ssme_lw_s();
     if (!h) return SSME_ERR_INVALID_ARG;
     h->cfg = *cfg;
+    h->form = cfg->form; h->rs = cfg->resamp_sched < 1 ? 1 : cfg->resamp_sched;
     h->shard_rank = shard_rank; h->shard_world = shard_world;
     h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * kTile;
     h->Bs = (B + 1) & ~1; h->Bpow2 = next_pow2(B);
@@ -1383,6 +1399,7 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
         if (h->shard_world == 0) {               // a sharded handle works on the caller's buffers
             double** big[] = {&h->xB, &h->xr, &h->lw1, &h->cdfA, &h->cdfB};
             for (auto p : big) { LWCHK(hipMalloc(p, sizeof(double) * np)); LWCHK(hipMemset(*p, 0, sizeof(double) * np)); }
+            if (h->rs > 1) { LWCHK(hipMalloc(&h->lwB, sizeof(double) * np)); LWCHK(hipMemset(h->lwB, 0, sizeof(double) * np)); }
             double** big4[] = {&h->thB, &h->thr};
             for (auto p : big4) { LWCHK(hipMalloc(p, sizeof(double) * np * kDP)); LWCHK(hipMemset(*p, 0, sizeof(double) * np * kDP)); }
             double** small[] = {&h->tsumA, &h->tmaxA, &h->tsumB, &h->tmaxB};
@@ -1396,7 +1413,7 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
         LWCHK(hipMalloc(&h->prop, sizeof(double) * (size_t)h->R * 16));
         LWCHK(hipMemset(h->prop, 0, sizeof(double) * (size_t)h->R * 16));
         LWCHK(hipMalloc(&h->scal, sizeof(LwScalars) * h->R));
-        LWCHK(hipMalloc(&h->scratch, sizeof(double) * h->R * kDP));
+        LWCHK(hipMalloc(&h->scratch, sizeof(double) * h->R * kLwNExp));
         LWCHK(hipMalloc(&h->keybuf, sizeof(uint32_t) * 2));
         {
             const uint32_t k[2] = {(uint32_t)h->cfg.seed, (uint32_t)(h->cfg.seed >> 32)};
@@ -1686,17 +1703,58 @@ int ssme_lw_get_per_step(ssme_lw_handle h, double* out, int32_t T) {
     return SSME_OK;
 }
 
-int ssme_lw_get_param_means(ssme_lw_handle h, double* out) {
-    if (!h || !out) return SSME_ERR_INVALID_ARG;
-    if (h->shard_world > 0) return SSME_ERR_STATE;     // sharded handles own no particle buffers: ssme_lw_shard_* drives them
-    if (h->t < 1) return SSME_ERR_STATE;
-    LWCHK(hipSetDevice(h->cfg.device));
+// [R][8] on the host: E[theta_d] (4), E[x], E[x^2], E[exp(x/2)], E[42] under the last step's weights
+static int lw_expect_table(ssme_lw_handle h, std::vector<double>& tab) {
     LwArgs a = lw_args(h);
     // the per-tile moment scratch is free between steps (stage 1 rewrites it before k_lw_mid reads it)
     hipLaunchKernelGGL(k_lw_param_partials, dim3(h->B, h->R), dim3(kThreads), 0, h->stream, a);
     hipLaunchKernelGGL(k_lw_param_means, dim3(h->R), dim3(kWave), 0, h->stream, a, h->scratch);
     LWCHK(hipGetLastError());
-    LWCHK(hipMemcpyAsync(out, h->scratch, sizeof(double) * h->R * kDP, hipMemcpyDeviceToHost, h->stream));
+    tab.resize((size_t)h->R * kLwNExp);
+    LWCHK(hipMemcpyAsync(tab.data(), h->scratch, sizeof(double) * tab.size(), hipMemcpyDeviceToHost, h->stream));
+    LWCHK(hipStreamSynchronize(h->stream));
+    return SSME_OK;
+}
+
+int ssme_lw_get_param_means(ssme_lw_handle h, double* out) {
+    if (!h || !out) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;     // sharded handles own no particle buffers: ssme_lw_shard_* drives them
+    if (h->t < 1) return SSME_ERR_STATE;
+    LWCHK(hipSetDevice(h->cfg.device));
+    std::vector<double> tab;
+    int rc = lw_expect_table(h, tab);
+    if (rc != SSME_OK) return rc;
+    for (int r = 0; r < h->R; ++r) for (int d = 0; d < kDP; ++d) out[(size_t)r * kDP + d] = tab[(size_t)r * kLwNExp + d];
+    return SSME_OK;
+}
+
+int ssme_lw_get_expectations(ssme_lw_handle h, const int32_t* functionals, int32_t n, double* out) {
+    if (!h || !out || !functionals || n < 1) return SSME_ERR_INVALID_ARG;
+    for (int i = 0; i < n; ++i) if (functionals[i] < 0 || functionals[i] > 7) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;
+    if (h->t < 1) return SSME_ERR_STATE;
+    LWCHK(hipSetDevice(h->cfg.device));
+    std::vector<double> tab;
+    int rc = lw_expect_table(h, tab);
+    if (rc != SSME_OK) return rc;
+    static const int slot[8] = {4, 5, 6, 7, 0, 1, 2, 3};      // ids 0-3: x, x^2, exp(x/2), 42; 4-7: phi, mu, sigma, rho
+    for (int i = 0; i < n; ++i) for (int r = 0; r < h->R; ++r) out[(size_t)i * h->R + r] = tab[(size_t)r * kLwNExp + slot[functionals[i]]];
+    return SSME_OK;
+}
+
+int ssme_lw_download_weights(ssme_lw_handle h, int32_t f, double* x, double* theta_untrans, double* w) {
+    if (!h || f < 0 || f >= h->R || !w) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world > 0) return SSME_ERR_STATE;
+    if (h->t < 1) return SSME_ERR_STATE;
+    LWCHK(hipSetDevice(h->cfg.device));
+    if (!h->wscratch) LWCHK(hipMalloc(&h->wscratch, sizeof(double) * (size_t)h->Npad * (1 + kDP)));
+    LwArgs a = lw_args(h);
+    hipLaunchKernelGGL(k_lw_weights, dim3(h->B), dim3(kThreads), 0, h->stream, a, (int)f, h->wscratch);
+    LWCHK(hipGetLastError());
+    LWCHK(hipMemcpyAsync(w, h->wscratch, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (theta_untrans) for (int d = 0; d < kDP; ++d)
+        LWCHK(hipMemcpyAsync(theta_untrans + (size_t)d * h->N, h->wscratch + (size_t)(1 + d) * h->Npad, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (x) LWCHK(hipMemcpyAsync(x, h->xB + (size_t)f * h->Npad, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
     LWCHK(hipStreamSynchronize(h->stream));
     return SSME_OK;
 }

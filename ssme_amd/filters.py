@@ -16,7 +16,7 @@ from . import _capi as capi
 from ._capi import (MODEL_LIN_GAUSS, MODEL_SVOL, MODEL_SVOL_LEVERAGE, RESAMP_MULTINOMIAL, RESAMP_MULTINOMIAL_IID,
                     RESAMP_STRATIFIED, RESAMP_SYSTEMATIC, SsmeError)
 
-__all__ = ["ParticleFilterBank", "svol_bs", "svol_leverage", "lin_gauss_bs", "log_like_eval", "svol_lw_1_par", "SwarmWithCovs", "Swarm", "svol_swarm_1",
+__all__ = ["ParticleFilterBank", "svol_bs", "svol_leverage", "lin_gauss_bs", "log_like_eval", "svol_lw_1_par", "svol_lw_2_par", "SwarmWithCovs", "Swarm", "svol_swarm_1",
            "TR_NULL", "TR_TWICE_FISHER", "TR_LOGIT", "TR_LOG",
            "MODEL_SVOL", "MODEL_SVOL_LEVERAGE", "MODEL_LIN_GAUSS", "RESAMP_MULTINOMIAL", "RESAMP_SYSTEMATIC",
            "RESAMP_STRATIFIED", "RESAMP_MULTINOMIAL_IID", "SsmeError"]
@@ -351,12 +351,15 @@ class svol_lw_1_par:
     plus run_series / param_means for whole-series use.  n_filters independent filters share one handle.
     """
 
+    _form = 0            # auxiliary-particle form (LWFilterWithCovs); svol_lw_2_par overrides
+
     def __init__(self, delta, phi_l, phi_u, mu_l, mu_u, sig_l, sig_u, rho_l, rho_u, dte=0, nparts=10, n_filters=1, seed=0,
-                 device=0, first_filter_id=0, transforms=(TR_LOGIT, TR_NULL, TR_LOG, TR_TWICE_FISHER)):
+                 device=0, first_filter_id=0, transforms=(TR_LOGIT, TR_NULL, TR_LOG, TR_TWICE_FISHER), rs=1):
+        """rs: the reference's resampling schedule m_rs (resample when (t + 1) % rs == 0; liu_west_filter.h:1139-1140)."""
         self._h = C.c_void_p()
         self.n, self.r = int(nparts), int(n_filters)
         cfg = capi.LwConfig(n_particles=nparts, n_filters=n_filters, seed=seed, device=device, first_filter_id=first_filter_id,
-                            delta=delta)
+                            delta=delta, form=self._form, resamp_sched=rs)
         cfg.transforms[:] = list(transforms)
         cfg.prior_lo[:] = [phi_l, mu_l, sig_l, rho_l]
         cfg.prior_hi[:] = [phi_u, mu_u, sig_u, rho_u]
@@ -414,6 +417,20 @@ class svol_lw_1_par:
         self._chk(capi.lib().ssme_lw_get_param_means(self._h, capi.dptr(out)))
         return out
 
+    def expectations(self, functionals):
+        """E[h | y_{1:t}] under the last step's weights, [n, R]: ids 0-3 = x, x^2, exp(x/2), 42 (the SSME_H_* ids);
+        4-7 = untransformed phi, mu, sigma, rho (getExpectations(), liu_west_filter.h:1054-1075)."""
+        fs = np.ascontiguousarray(functionals, dtype=np.int32)
+        out = np.empty((fs.size, self.r))
+        self._chk(capi.lib().ssme_lw_get_expectations(self._h, fs.ctypes.data_as(C.POINTER(C.c_int32)), fs.size, capi.dptr(out)))
+        return out
+
+    def weights(self, f=0):
+        """(x, untransformed theta [4, N], w) of filter f after the last step, for host-side functionals h(x, z, theta)."""
+        x, th, w = np.empty(self.n), np.empty((4, self.n)), np.empty(self.n)
+        self._chk(capi.lib().ssme_lw_download_weights(self._h, f, capi.dptr(x), capi.dptr(th), capi.dptr(w)))
+        return x, th, w
+
     def state(self, f=0, indices=False):
         n = self.n
         x, th = np.empty(n), np.empty((4, n))
@@ -431,3 +448,10 @@ class svol_lw_1_par:
         ms = C.c_float()
         self._chk(capi.lib().ssme_lw_last_elapsed_ms(self._h, C.byref(ms)))
         return ms.value
+
+
+class svol_lw_2_par(svol_lw_1_par):
+    """test/test_liu_west.cpp:214-358: the "alternative" Liu-West filter -- LWFilter2WithCovs, plain SISR form
+    (liu_west_filter.h:2191-2343): jitter, qSamp (= the transition), weight += logFEv + logGEv - logQEv = logGEv.
+    Same ctor arguments and methods as svol_lw_1_par."""
+    _form = 1

@@ -110,13 +110,22 @@ int main(int argc, char** argv) {
     ev(theta, 5);                                        // some other stream first
     std::printf("evaluator %.17g\n", ev(theta, 77));
     // (6) Liu-West model as test/test_liu_west.cpp:160-200 drives it
-    ssme_gpu::svol_lw_1_par_gpu<800> lwmod(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, 0, o);
+    ssme_gpu::svol_lw_1_par_gpu<800> lwmod(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, 0, o, 0);
     double lwll = 0.0;
     for (size_t row = 0; row < 6; ++row) {
         lwmod.filter(data[row], vec1{row ? data[row - 1].v : 0.0});
         lwll += lwmod.getLogCondLike();
     }
     std::printf("liu_west %.17g\n", lwll);
+    // (6b) the alternative (SISR) Liu-West filter as test/test_liu_west.cpp:365-406 drives it, E[42] = 42
+    ssme_gpu::svol_lw_2_par_gpu<800> lw2(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, 10, o, 0);
+    double lw2ll = 0.0;
+    for (size_t row = 0; row < 6; ++row) {
+        lw2.filter(data[row], vec1{row ? data[row - 1].v : 0.0});
+        lw2ll += lw2.getLogCondLike();
+    }
+    std::printf("liu_west2 %.17g\n", lw2ll);
+    std::printf("liu_west2_42 %.17g\n", lw2.getExpectations({SSME_H_CONST42})[0]);
     // (7) utils::read_data stand-in
     const auto rows = ssme_gpu::read_data(argv[1], 1);
     std::printf("read_data %zu %.17g\n", rows.size(), rows.empty() ? 0.0 : rows[0](0));

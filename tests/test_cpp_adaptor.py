@@ -49,6 +49,9 @@ def test_adaptor_matches_oracle(oracle, spy):
     assert abs(float(vals["evaluator"]) - oracle.log_mean_exp(np.array(lls))) < 1e-12
     lw = oracle.LWFilter(800, 77)
     assert float(vals["liu_west"]) == sum(lw.step(y[t], z[t]) for t in range(6))
+    lw2 = oracle.LWFilter(800, 77, form=1)
+    assert float(vals["liu_west2"]) == sum(lw2.step(y[t], z[t]) for t in range(6))
+    assert abs(float(vals["liu_west2_42"]) - 42.0) < 1e-9
     # swarm: 5 members, theta rows as test_swarm::samp_untrans_params, plain averages over members
     mem = []
     for k in range(5):

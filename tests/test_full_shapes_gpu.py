@@ -30,13 +30,14 @@ def test_config4_per_gpu_slice_512_leverage_filters_of_2e14(dev, oracle, spy):
     y = spy[:T]
     z = np.concatenate([[0.0], y[:-1]])
     bank = dev.ParticleFilterBank(dev.MODEL_SVOL_LEVERAGE, N, R, seed=2026, first_filter_id=1024)   # e.g. rank 2 of 8
+    assert bank.tile == 2048                     # 512 filters x 8 tiles fill the chip: the default keeps 2048-particle tiles
     bank.set_params(theta)
     ll_graph = bank.run_series(y, z)
     per_graph = bank.per_step()
     assert np.all(np.isfinite(ll_graph)) and len(set(ll_graph.tolist())) == R
     pick = sorted({0, R - 1, *rng.choice(R, 3, replace=False).tolist()})
     for r in pick:
-        o = oracle.Filter(oracle.MODEL_SVOL_LEVERAGE, N, theta[r], 2026, rep=1024 + r)
+        o = oracle.Filter(oracle.MODEL_SVOL_LEVERAGE, N, theta[r], 2026, rep=1024 + r, tile=bank.tile)
         lo_, po = o.run_series(y, z)
         assert np.array_equal(_bits(per_graph[r]), _bits(po)), f"filter {r}: per-step differs from the oracle"
         assert ll_graph[r] == lo_

@@ -233,6 +233,25 @@ def test_mode_a_vs_mode_b_liu_west(oracle):
     sa.assert_same_mean(a, b, "Liu-West mode A vs mode B (loglik, phi, mu, sigma, rho)")
 
 
+@pytest.mark.parametrize("form,rs", [(1, 1), (0, 3), (1, 3)])
+def test_mode_a_vs_mode_b_liu_west_forms(oracle, form, rs):
+    """SISR form (LWFilter2WithCovs) and resampling schedules: the kernel-matched restatement has the law of the
+    reference-faithful one (200 seeds, 3 SE; log-likelihood and the four posterior means)."""
+    import stat_anchor as sa
+    y, z = sa.sim_leverage(100, 0.95, 0.0, 0.05, -0.3, seed=9)
+
+    def ma(s):
+        l, _, m = oracle.lw_ref_run(2000, y, z, seed=1 + s, form=form, resamp_sched=rs)
+        return (l,) + tuple(m)
+
+    def mb(s):
+        o = oracle.LWFilter(2000, 1000 + s, form=form, resamp_sched=rs)
+        for t in range(y.size):
+            o.step(y[t], z[t])
+        return (o.loglik,) + tuple(o.param_means())
+    sa.assert_same_mean(np.array(sa.pmap(ma, range(sa.SEEDS))), np.array(sa.pmap(mb, range(sa.SEEDS))), f"Liu-West form {form} rs {rs}")
+
+
 def test_variance_scales_with_n(oracle, spy):
     th = [1.0, 0.95, 0.25]
     y = spy[:200]

@@ -208,9 +208,9 @@ def test_block_size_tuning_is_result_invariant(sa, oracle, spy):
     """Exact integer cdf: the kernel's block shape cannot change any result bit."""
     th = [1.0, 0.95, 0.25]
     n, seed, T = 9000, 12, 25
-    of = oracle.Filter(oracle.MODEL_SVOL, n, th, seed)
+    of = oracle.Filter(oracle.MODEL_SVOL, n, th, seed, tile=2048)
     ll_o, per_o = of.run_series(spy[:T])
-    bank = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, seed)
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, seed, tile=2048)       # 2048-particle tiles run 256 / 512 / 1024 threads
     bank.set_debug(True)
     bank.set_params(th)
     for nt in (256, 512, 1024):
@@ -513,6 +513,45 @@ def test_liu_west_bit_exact_vs_oracle(sa, oracle, n):
         assert_bits_equal([g.getLogCondLike()], [lo], f"LW logcondlike t={t}")
     # convenience reduction outside filter(): summation order differs (strided block sum vs sequential), fp64 tolerance
     np.testing.assert_allclose(g.param_means()[0], o.param_means(), rtol=1e-12, atol=0)
+    g.close()
+
+
+@pytest.mark.parametrize("form,rs", [(1, 1), (0, 3), (1, 3), (1, 2)])
+@pytest.mark.parametrize("n", [700, 5000])
+def test_liu_west_forms_and_schedules_bit_exact_vs_oracle(sa, oracle, form, rs, n):
+    """The SISR form (LWFilter2WithCovs::filter, liu_west_filter.h:2191-2343, model svol_lw_2_par) and the resampling
+    schedule m_rs (:1139-1140, :2317-2318) for both forms: particles, transformed parameters, indices and per-step log
+    conditional likelihoods bit-identical to the oracle; series API == step API; expectations of built-in functionals."""
+    T = 9
+    y, z = _lw_series(T, seed=21)
+    cls = sa.svol_lw_2_par if form == 1 else sa.svol_lw_1_par
+    g = cls(0.98, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, seed=13, rs=rs)
+    g.set_debug(True)
+    o = oracle.LWFilter(n, 13, rep=0, delta=0.98, form=form, resamp_sched=rs)
+    steps = []
+    for t in range(T):
+        g.filter(y[t], z[t])
+        lo = o.step(y[t], z[t])
+        steps.append(g.getLogCondLike())
+        assert_bits_equal([g.getLogCondLike()], [lo], f"LW form {form} rs {rs}: logcondlike t={t}")
+        sg, so = g.state(0, indices=True), o.state()
+        assert_bits_equal(sg["x"], so["x"], f"x t={t}")
+        assert_bits_equal(sg["theta"], so["theta"], f"theta t={t}")
+        if t > 0:
+            np.testing.assert_array_equal(sg["anc"], so["anc"], err_msg=f"ancestors t={t}")
+            np.testing.assert_array_equal(sg["kidx"], so["kidx"], err_msg=f"k t={t}")
+    ex = g.expectations([3, 0, 1, 2, 4, 5, 6, 7])[:, 0]
+    assert abs(ex[0] - 42.0) < 1e-9                                       # test/test_liu_west.cpp:199,401
+    np.testing.assert_allclose(ex[1:], [o.expectation(i) for i in (0, 1, 2, 4, 5, 6, 7)], rtol=1e-11)
+    np.testing.assert_allclose(ex[4:], g.param_means()[0], rtol=1e-15)
+    xs, ths, ws = g.weights(0)                         # host-side h(x, z, theta) = sigma * x from the downloaded (x, theta, w)
+    so = o.state()
+    wo = np.exp(so["logw"] - so["logw"].max())
+    sig_o = np.array([oracle.inv_transform(3, v) for v in so["theta"][2]])          # log transform of sigma (parameters.h:27)
+    np.testing.assert_allclose((ths[2] * xs * ws).sum() / ws.sum(), (sig_o * so["x"] * wo).sum() / wo.sum(), rtol=1e-9)
+    ll = g.run_series(y, z)
+    assert_bits_equal(g.per_step()[0], np.array(steps), "LW series API == step API")
+    assert abs(ll[0] - sum(steps)) < 1e-9
     g.close()
 
 

@@ -36,11 +36,13 @@ def test_svol_bs_device_vs_mode_a(dev, oracle, spy):
     sa.assert_same_mean(a, g, "svol_bs device vs mode A")
 
 
-def test_svol_bs_tiled_kernel_device_vs_mode_a(dev, oracle, spy):
-    """The same through the tiled step kernel with several tiles per filter (N = 5000: level-2 rescale + tile search)."""
+@pytest.mark.parametrize("tile", [512, 2048])
+def test_svol_bs_tiled_kernel_device_vs_mode_a(dev, oracle, spy, tile):
+    """The same through the tiled step kernel with several tiles per filter (N = 5000: level-2 rescale + tile search),
+    for both tile sizes (the per-tile weight scale and the per-tile Gamma draw must not move the mean)."""
     th = [1.0, 0.95, 0.25]
     y = spy[:100]
-    bank = dev.ParticleFilterBank(dev.MODEL_SVOL, 5000, sa.SEEDS, seed=7)
+    bank = dev.ParticleFilterBank(dev.MODEL_SVOL, 5000, sa.SEEDS, seed=7, tile=tile)
     bank.set_params(th)
     g = bank.run_series(y)
     bank.close()
@@ -71,3 +73,21 @@ def test_liu_west_device_vs_mode_a(dev, oracle, delta):
     g.close()
     a = sa.mode_a_liu_west(oracle, 2000, y, z, delta=delta)
     sa.assert_same_mean(a, np.column_stack([ll, pm]), f"Liu-West delta={delta} device vs mode A (loglik, phi, mu, sigma, rho)")
+
+
+@pytest.mark.parametrize("form,rs", [(1, 1), (0, 3)])
+def test_liu_west_forms_device_vs_mode_a(dev, oracle, form, rs):
+    """The SISR form (LWFilter2WithCovs, liu_west_filter.h:2191-2343) and a resampling schedule m_rs = 3 of the auxiliary
+    form against the reference-faithful restatement: 200 seeds, 3 SE, log-likelihood and the four posterior means."""
+    y, z = sa.sim_leverage(100, 0.95, 0.0, 0.05, -0.3, seed=9)
+    cls = dev.svol_lw_2_par if form == 1 else dev.svol_lw_1_par
+    g = cls(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=2000, n_filters=sa.SEEDS, seed=57, rs=rs)
+    ll = g.run_series(y, z)
+    pm = g.param_means()
+    g.close()
+
+    def one(s):
+        l, _, m = oracle.lw_ref_run(2000, y, z, seed=1 + s, delta=0.99, form=form, resamp_sched=rs)
+        return (l,) + tuple(m)
+    a = np.array(sa.pmap(one, range(sa.SEEDS)))
+    sa.assert_same_mean(a, np.column_stack([ll, pm]), f"Liu-West form {form} rs {rs} device vs mode A")
