@@ -60,7 +60,7 @@ def lib():
         L = C.CDLL(_SO)
         dp, u32p = C.POINTER(C.c_double), C.POINTER(C.c_uint32)
         L.orc_philox4x32_10.argtypes = [u32p, u32p, u32p]
-        for f in (L.orc_exp, L.orc_log, L.orc_log_u):
+        for f in (L.orc_exp, L.orc_log, L.orc_log_u, L.orc_exp_t):
             f.argtypes = [dp, dp, C.c_long]
         L.orc_sincos2pi.argtypes = [dp, dp, dp, C.c_long]
         L.orc_normals.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, dp]
@@ -141,6 +141,11 @@ def exp(x):
 
 def log(x):
     return _map1(lib().orc_log, x)
+
+
+def exp_t(x):
+    """The bootstrap filter's exp (256-entry table + degree-5 series)."""
+    return _map1(lib().orc_exp_t, x)
 
 
 def log_u(x):

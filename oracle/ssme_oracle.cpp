@@ -175,6 +175,28 @@ double o_log_u(double x) {
     const double dk = (double)k;
     return std::fma(dk, LN2_HI, e.l) + std::fma(dk, LN2_LO, p);
 }
+// The bootstrap filter's exp (mirror of ssme_math.h: dexp_scaled_t): 256-entry double-double table of 2^(j/256) + degree-5 series
+struct ExpTabEntry { double hi, lo; };
+static const ExpTabEntry EXP_TABLE[SSME_EXP_TABLE_SIZE] = {SSME_EXP_TABLE_ROWS};
+double o_exp_scaled_t(double x, int sc) {
+    const double INV = 369.3299304675746;
+    const double C_HI = 6.93147180369123816490e-01 * 0.00390625, C_LO = 1.90821492927058770002e-10 * 0.00390625;
+    const double SH = 6755399441055744.0;
+    const double xc = std::fmin(std::fmax(x, -746.0), 710.0);
+    const double kf = std::fma(xc, INV, SH) - SH;
+    const int n = (int)kf;
+    double r = std::fma(-kf, C_HI, xc);
+    r = std::fma(-kf, C_LO, r);
+    const ExpTabEntry e = EXP_TABLE[n & 255];
+    double q = std::fma(r, 0.008333333333333333, 0.041666666666666664);
+    q = std::fma(q, r, 0.16666666666666666);
+    q = std::fma(q, r, 0.5);
+    const double p = std::fma(r * r, q, r);
+    const double res = e.hi + std::fma(e.hi, p, e.lo);
+    return std::ldexp(res, (n >> 8) + sc);
+}
+double o_exp_t(double x) { return o_exp_scaled_t(x, 0); }
+
 // uniforms strictly inside (0,1) on a 2^-40 / 2^-32 midpoint grid; [0,1) on a 2^-24 grid (Box-Muller angle)
 inline double u01_mid40(uint32_t a, uint32_t b) {
     const uint64_t man = ((uint64_t)a << 20) | ((uint64_t)(b >> 24) << 12) | 0x800ull;
@@ -272,7 +294,7 @@ inline double m_init(const ModelConst& c, double zn) { return zn * c.a2; }
 // fSamp (univ_svol_bootstrap_filter.h:74-79; test_pswarm.cpp:90-97)
 inline double m_prop(const ModelConst& c, double x, double zn, double zcov) {
     if (c.model == MODEL_SVOL_LEVERAGE) {
-        const double e = o_exp(-0.5 * x);
+        const double e = o_exp_t(-0.5 * x);
         const double mean = (c.a1 + c.a0 * (x - c.a1)) + (c.a4 * zcov) * e;
         return mean + zn * c.a3;
     }
@@ -294,7 +316,7 @@ inline double m_logg(const ModelConst& c, double y, double x) {
     if (c.model == MODEL_SVOL) { if (c.bad) return NEG_INF; logb = c.a3; ib2 = c.a4; }
     const double hl = logb + 0.5 * x;
     if (hl < -745.1332191019412) return NEG_INF;
-    const double e = o_exp(-x);
+    const double e = o_exp_t(-x);
     const double q = (y * y) * ib2;
     return (-hl - HALF_LOG_2PI) - 0.5 * (q * e);
 }
@@ -496,6 +518,9 @@ struct Filter {
         return std::min(b * tile + j, N - 1);
     }
 
+    // the exp of the weight arithmetic: the bootstrap filter's table form, or the Taylor form the Liu-West kernels use
+    double xexp(double v, int sc) const { return bootstrap_draws ? o_exp_scaled_t(v, sc) : o_exp_scaled(v, sc); }
+
     // logw[0..N) -> per-tile maxima, tile-local exact cdf, rescaled tile sums, their prefixes; returns S' 2^-rg
     double build_cdf() {
         // per-tile NaN-propagating max, tile-local exact cdf
@@ -510,7 +535,7 @@ struct Filter {
             uint64_t s = 0;
             for (int j = 0; j < tile; ++j) {
                 const int i = b * tile + j;
-                if (i < N) s += rne_u64(o_exp_scaled(logw[i] - mb[b], TILE_SHIFT));
+                if (i < N) s += rne_u64(xexp(logw[i] - mb[b], TILE_SHIFT));
                 loc[i] = s;
             }
             A[b] = s;
@@ -524,7 +549,7 @@ struct Filter {
         }
         uint64_t run = 0;
         for (int b = 0; b < B; ++b) {
-            Ap[b] = rint_to_u64((double)A[b] * o_exp_scaled(mb[b] - m, rshift - TILE_SHIFT));
+            Ap[b] = rint_to_u64((double)A[b] * xexp(mb[b] - m, rshift - TILE_SHIFT));
             run += Ap[b]; Tincl[b] = run;
         }
         Sint = run;
@@ -1047,6 +1072,8 @@ void orc_normals(uint64_t seed, uint32_t rep, int t, int n, double* out) {
     for (int i = 0; i < n; ++i) out[i] = f.normal(i, t);
 }
 void orc_log_u(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_log_u(x[i]); }
+void orc_exp_t(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_exp_t(x[i]); }
+void orc_exp_scaled_t(const double* x, int sc, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_exp_scaled_t(x[i], sc); }
 void orc_exp_scaled(const double* x, int sc, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_exp_scaled(x[i], sc); }
 // Gamma(shape) draws for tiles b = 0..n-1 at time t (Marsaglia-Tsang, counter driven)
 void orc_gamma(uint64_t seed, uint32_t rep, int t, double shape, int n, double* out) {
@@ -1055,8 +1082,8 @@ void orc_gamma(uint64_t seed, uint32_t rep, int t, double shape, int n, double* 
 }
 // fixed-point quantisation of weights: q = rne(exp(x) * 2^sc) for x <= 0
 // A'_b = rint((double)A * exp(dm) * 2^sc)
-void orc_rescale(const uint64_t* A, const double* dm, int sc, uint64_t* out, long n) { for (long i = 0; i < n; ++i) out[i] = rint_to_u64((double)A[i] * o_exp_scaled(dm[i], sc)); }
-void orc_quantize(const double* x, int sc, uint64_t* q, long n) { for (long i = 0; i < n; ++i) q[i] = rne_u64(o_exp_scaled(x[i], sc)); }
+void orc_rescale(const uint64_t* A, const double* dm, int sc, uint64_t* out, long n) { for (long i = 0; i < n; ++i) out[i] = rint_to_u64((double)A[i] * o_exp_scaled_t(dm[i], sc)); }
+void orc_quantize(const double* x, int sc, uint64_t* q, long n) { for (long i = 0; i < n; ++i) q[i] = rne_u64(o_exp_scaled_t(x[i], sc)); }
 
 void* orc_pf_create(int model, int N, int resamp, int rs, uint64_t seed, uint32_t rep, const double* theta, int tile) {
     Filter* f = new Filter(); f->bootstrap_draws = true; f->tile = tile; f->init(model, N, resamp, rs, seed, rep, theta); return f;

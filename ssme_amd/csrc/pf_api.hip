@@ -137,7 +137,7 @@ static StepArgs step_args(ssme_pf_handle h) {
     a.scal = h->scal; a.mc = h->mc; a.y = h->ybuf; a.z = nullptr; a.per_step = nullptr;
     a.gam = h->gam; a.pgam = h->pgam; a.gtot = h->gtot;
     a.N = h->N; a.Npad = h->Npad; a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = h->R;
-    a.tile = h->tile;
+    a.tile = h->tile; a.exp_table = 1;
     a.Tcap = h->tcap;
     a.resampler = h->cfg.resampler; a.resamp_sched = h->cfg.resamp_sched;
     a.keyp = h->keybuf; a.first_filter = h->cfg.first_filter_id;
@@ -1001,6 +1001,7 @@ __global__ void k_test_math(int fn, const double* in, double* out, long n) {
         case 3: dsincos2pi(x, &s, &c); r = c; break;
         case 4: r = dsqrt(x); break;
         case 6: r = dlog_u(x, kLogTable); break;
+        case 7: r = dexp_scaled_t(x, 0, kExpTable); break;
         default: r = dlog_pn(x); break;
     }
     out[i] = r;
@@ -1011,11 +1012,11 @@ __global__ void k_test_philox(const uint32_t* ctr, const uint32_t* key, uint32_t
 }
 __global__ void k_test_quantize(const double* in, int shift, u64* out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (u64)__builtin_rint(dexp_scaled(in[i], shift));
+    if (i < n) out[i] = (u64)__builtin_rint(dexp_scaled_t(in[i], shift, kExpTable));
 }
 __global__ void k_test_rescale(const u64* A, const double* dm, int shift, u64* out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (u64)__builtin_rint((double)A[i] * dexp_scaled(dm[i], shift));
+    if (i < n) out[i] = (u64)__builtin_rint((double)A[i] * dexp_scaled_t(dm[i], shift, kExpTable));
 }
 template <int NT>
 __global__ __launch_bounds__(NT) void k_test_block_scan(const u64* in, u64* incl, u64* total) {

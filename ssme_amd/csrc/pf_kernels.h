@@ -90,6 +90,8 @@ struct StepArgs {
     const double* gtot;        // [nT][R]    sum(gam) + E_{N+1}
     int32_t N, Npad, B, Bs, Bpow2, rshift, R;
     int32_t tile;              // particles per tile (2048 or 512): part of the arithmetic specification
+    int32_t exp_table;         // 1: the bootstrap filter's table exp in the level-2 rescale (k_level2_plan / k_shard_plan serve
+                               // the Liu-West filter too, whose weight arithmetic uses the Taylor exp: 0)
     int32_t t, yi, gi, Tcap;   // t: time index (RNG counter, schedule); yi / gi: rows of y / gamma tables
     int32_t resampler, resamp_sched;
     int32_t finalize_prev;     // account log p(y_{t-1}|.) of the previous step
@@ -227,9 +229,9 @@ __device__ __forceinline__ void block_scan_f64(const double (&q)[NK][2], double 
 // Model callbacks, compiled in (the reference's virtual fSamp/q1Samp/logGEv).
 // ---------------------------------------------------------------------------------------
 template <int MODEL>
-__device__ __forceinline__ double model_prop(const ModelConst& c, double x, double zn, double zcov) {
+__device__ __forceinline__ double model_prop(const ModelConst& c, double x, double zn, double zcov, const ExpTabEntry* etab) {
     if (MODEL == MODEL_SVOL_LEVERAGE) {   // test/test_pswarm.cpp:90-97
-        const double e = dexp(-0.5 * x);
+        const double e = dexp_scaled_t(-0.5 * x, 0, etab);
         const double mean = (c.a1 + c.a0 * (x - c.a1)) + (c.a4 * zcov) * e;
         return mean + zn * c.a3;
     }
@@ -237,7 +239,7 @@ __device__ __forceinline__ double model_prop(const ModelConst& c, double x, doub
 }
 
 template <int MODEL>
-__device__ __forceinline__ double model_logg(const ModelConst& c, double y, double x) {
+__device__ __forceinline__ double model_logg(const ModelConst& c, double y, double x, const ExpTabEntry* etab) {
     if (MODEL == MODEL_LIN_GAUSS) {
         const double d = (y - x) * c.a4;
         const double v = (-c.a3 - SSME_HALF_LOG_2PI) - 0.5 * (d * d);
@@ -247,7 +249,7 @@ __device__ __forceinline__ double model_logg(const ModelConst& c, double y, doub
     const double logb = (MODEL == MODEL_SVOL) ? c.a3 : 0.0;
     const double ib2 = (MODEL == MODEL_SVOL) ? c.a4 : 1.0;
     const double hl = logb + 0.5 * x;
-    const double e = dexp(-x);
+    const double e = dexp_scaled_t(-x, 0, etab);
     const double q = (y * y) * ib2;
     double v = (-hl - SSME_HALF_LOG_2PI) - 0.5 * (q * e);
     if (hl < -745.1332191019412) v = -dinf();
@@ -300,11 +302,23 @@ __device__ __forceinline__ void pair_normals(uint32_t w0, uint32_t w1, const Log
     *z0 = rad * cs;
     *z1 = rad * sn;
 }
-// the table of dlog_u, in device memory; every workgroup copies it into LDS (128 x 16 bytes) before its first draw
+// the tables of dlog_u and dexp_scaled_t, in device memory; every workgroup of the hot kernels copies them into LDS
+// (128 x 16 + 256 x 16 bytes) before its first use
 static __device__ const LogTabEntry kLogTable[SSME_LOG_TABLE_SIZE] = {SSME_LOG_TABLE_ROWS};
+static __device__ const ExpTabEntry kExpTable[SSME_EXP_TABLE_SIZE] = {SSME_EXP_TABLE_ROWS};
 template <int NT>
 __device__ __forceinline__ void load_log_table(LogTabEntry* lds_tab) {
     for (int i = threadIdx.x; i < SSME_LOG_TABLE_SIZE; i += NT) lds_tab[i] = kLogTable[i];
+}
+template <int NT>
+__device__ __forceinline__ void load_exp_table(ExpTabEntry* lds_tab) {
+    for (int i = threadIdx.x; i < SSME_EXP_TABLE_SIZE; i += NT) lds_tab[i] = kExpTable[i];
+}
+// exp(x) 2^sc of the weight arithmetic: the bootstrap filter's table form (TAB) or the Taylor form (Liu-West kernels)
+template <bool TAB>
+__device__ __forceinline__ double xexp_scaled(double x, int sc, const ExpTabEntry* tab) {
+    if constexpr (TAB) return dexp_scaled_t(x, sc, tab);
+    else return dexp_scaled(x, sc);
 }
 
 // Gamma(shape) draw, Marsaglia & Tsang (2000), attempts driven by the Philox counter
@@ -356,10 +370,10 @@ __device__ __forceinline__ void level2_load(const double* ts, const double* tm, 
     }
 }
 
-template <int NT>
+template <int NT, bool TAB = false>
 __device__ __forceinline__ void level2_scan(const double (&A)[2048 / NT], const double (&mb)[2048 / NT], int B, int rshift,
                                             double& m, double (&Ap)[2048 / NT], double (&Tinc)[2048 / NT], double& S,
-                                            double* lds_d, double* lds_seg) {
+                                            double* lds_d, double* lds_seg, const ExpTabEntry* etab = nullptr) {
     constexpr int NE = 2048 / NT, NW = NT / 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -380,7 +394,7 @@ __device__ __forceinline__ void level2_scan(const double (&A)[2048 / NT], const 
         if (e * NT < B) {
             const int j = e * NT + threadIdx.x;
             // NaN (m or m_b NaN) is squashed to 0 by dexp_scaled's clamp: A' = rint(A * 0) = 0
-            if (j < B) Ap[e] = __builtin_rint(A[e] * dexp_scaled(mb[e] - m, rshift - kTileShift));
+            if (j < B) Ap[e] = __builtin_rint(A[e] * xexp_scaled<TAB>(mb[e] - m, rshift - kTileShift, etab));
             inc[e] = wave_incl_scan_f64(Ap[e]);
             if (lane == 63) lds_seg[e * 16 + wave] = inc[e];
         }
@@ -481,12 +495,15 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     __shared__ double lds_seg_l2[64];
     __shared__ double lds_seg_c[16];
     __shared__ int lds_cnt[2];
+    __shared__ double lds_R3[4];         // A_b / A'_b of the staged tiles
     __shared__ double lds_d1[16];
     __shared__ double lds_d2[16];
     __shared__ __attribute__((aligned(16))) LogTabEntry lds_ltab[SSME_LOG_TABLE_SIZE];
+    __shared__ __attribute__((aligned(16))) ExpTabEntry lds_etab[SSME_EXP_TABLE_SIZE];
 
     const int tid = threadIdx.x;
     load_log_table<NT>(lds_ltab);        // visible after the first barrier below (every path has one before its first draw)
+    load_exp_table<NT>(lds_etab);        // first used behind level2_scan's first barrier (block max)
     // (filter, tile) of this workgroup: the launch's tiles in filter-major order, a contiguous range per XCD
     const int gtile = xcd_tile_of_block((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
     const int r = gtile / (int)gridDim.x, bloc = gtile - r * (int)gridDim.x;
@@ -512,7 +529,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     PRIO_AT(0);
     // --- issue the level-2 loads first: previous step's tile sums and maxima ---
     constexpr int NE = 2048 / NT;
-    double A2[NE], M2[NE];
+    double A2[NE], M2[NE], ApL2[NE];
     if (need_l2 && !BIG) level2_load<NT>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
     const double* l2T = a.l2_T + (size_t)r * a.Bs;
     const double* l2R = a.l2_R + (size_t)r * a.Bs;
@@ -541,13 +558,13 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         tile_target_bounds(rsm, S, a.N, i_first, nvalid, pgam, pgam_next, G, u0, t_scale, t_lo, t_hi);
     }
     if (need_l2 && !BIG) {
-        double Ap[NE], Tinc[NE];
+        double Tinc[NE];
         double m;
 #ifdef SSME_ABLATE
         if (a.stamps) { asm volatile("" :: "v"(A2[0]), "v"(M2[0])); }   // force the loads to have landed
         STAMP(a, 13);
 #endif
-        level2_scan<NT>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d1, lds_seg_l2);
+        level2_scan<NT, true>(A2, M2, a.B, a.rshift, m, ApL2, Tinc, S, lds_d1, lds_seg_l2, lds_etab);
         STAMP(a, 14);
         // bounds [t_lo, t_hi] of this tile's targets, known to every thread without the spacings
         double t_lo = 0.0, t_hi = dinf();
@@ -560,10 +577,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         for (int e = 0; e < NE; ++e) {
             if (e * NT < a.Bpow2) {
                 const int j = e * NT + tid;
-                if (j < a.Bpow2) {
-                    lds_T[j] = (j < a.B) ? Tinc[e] : dinf();
-                    lds_R[j] = (j < a.B) ? A2[e] / Ap[e] : 0.0;
-                }
+                if (j < a.Bpow2) lds_T[j] = (j < a.B) ? Tinc[e] : dinf();
                 if (resampled && sorted) {
                     // #{T'_j < t_lo}, #{T'_j < t_hi}: wave popcounts, one LDS atomic per wave
                     const int w_lo = __popcll(__ballot(j < a.B && Tinc[e] < t_lo));
@@ -598,7 +612,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     const double* cdf_r = a.cdf_in + rowoff;
     const double* xin_r = a.x_in + rowoff;
     if (resampled) {
-        __syncthreads();          // lds_T, lds_R, lds_cnt visible
+        __syncthreads();          // lds_T, lds_cnt visible
         if (sorted) {
             int lo, hi;
             if (BIG) { lo = a.l2_lo[(size_t)r * a.Bs + b]; hi = a.l2_hi[(size_t)r * a.Bs + b]; }
@@ -607,6 +621,33 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             hi = hi < a.B - 1 ? hi : a.B - 1;
             bb_min = __builtin_amdgcn_readfirstlane(lo);
             span = __builtin_amdgcn_readfirstlane(hi) - bb_min + 1;
+        }
+        if (!BIG) {
+            // A_b / A'_b (maps a global target into its tile's fixed point).  Only the staged tiles' ratios are needed, so the
+            // IEEE division runs in the one or two waves that hold those entries, off the path to the first barrier; an
+            // output tile spanning more than three source tiles (iid resampling, degenerate weights) publishes all of them.
+            if (span <= kStageTiles) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    if (e * NT < a.Bpow2) {
+                        const int j = e * NT + tid;
+#pragma unroll
+                        for (int sl = 0; sl < kStageTiles; ++sl) {
+                            const int bs = bb_min + sl < a.B ? bb_min + sl : a.B - 1;
+                            if (j == bs) lds_R3[sl] = A2[e] / ApL2[e];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    if (e * NT < a.Bpow2) {
+                        const int j = e * NT + tid;
+                        if (j < a.Bpow2) lds_R[j] = (j < a.B) ? A2[e] / ApL2[e] : 0.0;
+                    }
+                }
+                __syncthreads();
+            }
         }
         if (span <= kStageTiles) {
             const double* src = cdf_r + (size_t)(bb_min - a.win_tile0) * TILE + tid * 2;
@@ -713,8 +754,8 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             const double T0 = BIG ? l2T[bb_min] : lds_T[bb_min];
             const double T1 = (bb_min + 1 < a.B) ? (BIG ? l2T[bb_min + 1] : lds_T[bb_min + 1]) : dinf();
             const double Pm = bb_min ? (BIG ? l2T[bb_min - 1] : lds_T[bb_min - 1]) : 0.0;
-            const double R0 = BIG ? l2R[bb_min] : lds_R[bb_min], R1 = BIG ? l2R[b1] : lds_R[b1], R2 = BIG ? l2R[b2] : lds_R[b2];
             __syncthreads();
+            const double R0 = BIG ? l2R[bb_min] : lds_R3[0], R1 = BIG ? l2R[b1] : lds_R3[1], R2 = BIG ? l2R[b2] : lds_R3[2];
             STAMP(a, 5);
             PRIO_AT(5);
             // All 2*NK count-searches of a thread descend together, one level per iteration: the probes of a level are
@@ -808,8 +849,8 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         double xo[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const double xn = first_step ? zn[k][c] * mc.a2 : model_prop<MODEL>(mc, xin[k][c], zn[k][c], zcov);
-            const double l = lw_old[k][c] + (ABL(a, 3) ? -0.5 * xn * xn : model_logg<MODEL>(mc, y, xn));
+            const double xn = first_step ? zn[k][c] * mc.a2 : model_prop<MODEL>(mc, xin[k][c], zn[k][c], zcov, lds_etab);
+            const double l = lw_old[k][c] + (ABL(a, 3) ? -0.5 * xn * xn : model_logg<MODEL>(mc, y, xn, lds_etab));
             const bool valid = (i0 + c) < a.N;
             xo[c] = valid ? xn : 0.0;
             lg[k][c] = valid ? l : -dinf();
@@ -832,8 +873,8 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         const int i0 = i_first + (k * NT + tid) * 2;
         if (ABL(a, 4)) { q[k][0] = (double)(d2bits(lg[k][0] - mb) >> 24); q[k][1] = (double)(d2bits(lg[k][1] - mb) >> 24); }
         else {
-            q[k][0] = (i0 < a.N) ? __builtin_rint(dexp_scaled(lg[k][0] - mb, kTileShift)) : 0.0;
-            q[k][1] = (i0 + 1 < a.N) ? __builtin_rint(dexp_scaled(lg[k][1] - mb, kTileShift)) : 0.0;
+            q[k][0] = (i0 < a.N) ? __builtin_rint(dexp_scaled_t(lg[k][0] - mb, kTileShift, lds_etab)) : 0.0;
+            q[k][1] = (i0 + 1 < a.N) ? __builtin_rint(dexp_scaled_t(lg[k][1] - mb, kTileShift, lds_etab)) : 0.0;
         }
     }
     if (ABL(a, 5)) {
@@ -872,7 +913,7 @@ __global__ __launch_bounds__(kThreads) void kf_finalize(const StepArgs a) {
     const int r = blockIdx.x;
     double A2[8], Ap[8], Tinc[8], M2[8], S, m;
     level2_load<kThreads>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
-    level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
+    level2_scan<kThreads, true>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
     if (tid == 0) {
         FilterScalars* sc = a.scal + r;
         const bool resample_now = ((a.t + 1) % a.resamp_sched == 0);
@@ -921,7 +962,11 @@ __global__ __launch_bounds__(1024) void k_level2_plan(const StepArgs a, int plan
     for (int j0 = 0; j0 < a.Bpow2; j0 += NT) {
         const int j = j0 + tid;
         double A = 0.0, Ap = 0.0;
-        if (j < a.B) { A = ts[j]; Ap = __builtin_rint(A * dexp_scaled(tm[j] - m, a.rshift - kTileShift)); }
+        if (j < a.B) {
+            A = ts[j];
+            const double ex = a.exp_table ? dexp_scaled_t(tm[j] - m, a.rshift - kTileShift, kExpTable) : dexp_scaled(tm[j] - m, a.rshift - kTileShift);
+            Ap = __builtin_rint(A * ex);
+        }
         const double inc = wave_incl_scan_f64(Ap);
         __syncthreads();                                         // lds_seg of the previous round has been read
         if (lane == 63) lds_seg[wave] = inc;
@@ -992,7 +1037,8 @@ __global__ __launch_bounds__(512) void k_shard_plan(const StepArgs a, int world,
     const int tid = threadIdx.x;
     double A2[NE], M2[NE], Ap[NE], Tinc[NE], S, m;
     level2_load<NT>(a.tsum_in, a.tmax_in, a.B, A2, M2);
-    level2_scan<NT>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
+    if (a.exp_table) level2_scan<NT, true>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
+    else level2_scan<NT, false>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int j = e * NT + tid;

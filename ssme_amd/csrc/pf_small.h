@@ -48,9 +48,11 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
     __shared__ double lds_seg_c[16];
     __shared__ double lds_d2[16];
     __shared__ __attribute__((aligned(16))) LogTabEntry lds_ltab[SSME_LOG_TABLE_SIZE];
+    __shared__ __attribute__((aligned(16))) ExpTabEntry lds_etab[SSME_EXP_TABLE_SIZE];
 
     const int tid = threadIdx.x;
     load_log_table<NT>(lds_ltab);
+    load_exp_table<NT>(lds_etab);
     __syncthreads();
     const int r = blockIdx.x;
     const uint32_t rep = a.first_filter + (uint32_t)r;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
             // one tile: m_b - m is +0 unless the max is NaN or infinite, and the shift is 0 (Npad = 2048); exp(0) 2^0 = 1 exactly
             const double dm = mb_prev - m;
             const int sh = a.rshift - kTileShift;
-            const double Ap = (dm == 0.0 && sh == 0) ? __builtin_rint(A_prev) : __builtin_rint(A_prev * dexp_scaled(dm, sh));
+            const double Ap = (dm == 0.0 && sh == 0) ? __builtin_rint(A_prev) : __builtin_rint(A_prev * dexp_scaled_t(dm, sh, lds_etab));
             S = Ap;
             R0 = A_prev / Ap;
             const double Sdd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
@@ -193,8 +195,8 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
             const int i0 = (k * NT + tid) * 2;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const double xn = (t == 0) ? zn[k][c] * mc.a2 : model_prop<MODEL>(mc, xin[k][c], zn[k][c], zcov);
-                const double l = lw_old[k][c] + model_logg<MODEL>(mc, y, xn);
+                const double xn = (t == 0) ? zn[k][c] * mc.a2 : model_prop<MODEL>(mc, xin[k][c], zn[k][c], zcov, lds_etab);
+                const double l = lw_old[k][c] + model_logg<MODEL>(mc, y, xn, lds_etab);
                 const bool valid = (i0 + c) < a.N;
                 xcur[k][c] = valid ? xn : 0.0;
                 lg[k][c] = valid ? l : -dinf();
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int i0 = (k * NT + tid) * 2;
-            q[k][0] = (i0 < a.N) ? __builtin_rint(dexp_scaled(lg[k][0] - mb, kTileShift)) : 0.0;
-            q[k][1] = (i0 + 1 < a.N) ? __builtin_rint(dexp_scaled(lg[k][1] - mb, kTileShift)) : 0.0;
+            q[k][0] = (i0 < a.N) ? __builtin_rint(dexp_scaled_t(lg[k][0] - mb, kTileShift, lds_etab)) : 0.0;
+            q[k][1] = (i0 + 1 < a.N) ? __builtin_rint(dexp_scaled_t(lg[k][1] - mb, kTileShift, lds_etab)) : 0.0;
         }
         block_scan_f64<NT, NK>(q, inc, total, lds_seg_c);
 #pragma unroll
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
     // --- log conditional likelihood of the last step (kf_finalize) and the state hand-over ---
     {
         const double m = (mb_prev != mb_prev) ? dnan() : mb_prev;
-        const double S = __builtin_rint(A_prev * dexp_scaled(mb_prev - m, a.rshift - kTileShift));
+        const double S = __builtin_rint(A_prev * dexp_scaled_t(mb_prev - m, a.rshift - kTileShift, lds_etab));
         const bool resample_now = (T % a.resamp_sched == 0);
         const double Sd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
         const double lse = m + dlog(Sd);

@@ -28,6 +28,9 @@ def test_math_accuracy(oracle):
     assert _ulp(oracle.exp(x), np.exp(x)) <= 1.0
     x = rng.uniform(-3, 3, 100000)
     assert _ulp(oracle.exp(x), np.exp(x)) <= 1.0
+    for lo, hi in ((-700, 700), (-3, 3), (-45, 5)):            # the bootstrap filter's table form
+        x = rng.uniform(lo, hi, 100000)
+        assert _ulp(oracle.exp_t(x), np.exp(x)) <= 1.0
     u = rng.uniform(0, 1, 100000)
     assert _ulp(oracle.log(u), np.log(u)) <= 1.0
     x = np.exp(rng.uniform(-700, 700, 100000))

@@ -61,6 +61,7 @@ def test_device_math_bit_exact(sa, oracle):
         x = np.concatenate([rng.uniform(-750, 715, 200000), rng.uniform(-40, 40, 200000),
                             [0.0, -0.0, np.inf, -np.inf, np.nan, 709.782712893384, -745.1332191019412, 1e-320, 710.0, -746.0]])
         assert_bits_equal(_dev_math(0, x), oracle.exp(x), "exp")
+        assert_bits_equal(_dev_math(7, x), oracle.exp_t(x), "exp (table form)")
         u = np.concatenate([rng.uniform(0, 1, 200000), np.exp(rng.uniform(-740, 700, 200000)),
                             (np.arange(1, 4097) * 2.0 ** -53), [1.0, 0.0, np.inf, 5e-324, 1e-310, -1.0, np.nan]])
         assert_bits_equal(_dev_math(1, u), oracle.log(u), "log")
