@@ -222,6 +222,26 @@ int ssme_pf_shard_step(ssme_pf_handle h, int32_t t, const double* x_win, const d
  * ssme_pf_get_loglik / ssme_pf_get_per_step return the same values on every rank. */
 int ssme_pf_shard_finalize(ssme_pf_handle h, int32_t t, const double* tsum_all, const double* tmax_all);
 
+/* ---- the same loop in C++ over RCCL: a C or C++ caller of ssme needs no Python to use several GPUs ------------------------
+ * RCCL is resolved at run time from what the process has loaded (dlsym; `librccl.so` from the loader path otherwise); this
+ * library does not link against it.  comm = an ncclComm_t whose rank / size equal the handle's (pass your own, or make
+ * one: rank 0 calls ssme_shard_comm_get_unique_id, ships the 128 bytes to the other ranks by any means, every rank calls
+ * ssme_shard_comm_init).
+ * ssme_pf_shard_run_series runs the whole series on the handle's stream.  mode 0: fixed-halo exchange with the two
+ * neighbouring ranks and no host synchronisation inside the time loop; a device flag records whether any rank's
+ * resampling window ever left the halo, and if so the series is run again on the exact path; mode 1: fixed halo only
+ * (SSME_ERR_STATE if a window left it); mode 2: exact path (the plan is downloaded every step, exactly the planned tiles
+ * travel between any two ranks).  Results are bit-identical to the unsharded filter on every path.  loglik_out: 1 value,
+ * identical on every rank.  Buffers are owned by the handle. */
+int ssme_shard_comm_get_unique_id(void* id128 /*128 bytes*/);
+int ssme_shard_comm_init(const void* id128, int32_t rank, int32_t world, int32_t device, void** comm_out);
+int ssme_shard_comm_destroy(void* comm);
+int ssme_pf_shard_run_series(ssme_pf_handle h, void* nccl_comm, const double* y, const double* z, int32_t T, int32_t mode,
+                             double* loglik_out);
+/* after ssme_pf_shard_run_series: this rank's N / world particles and integer cdf (nullable), the path the last series
+ * took (1 fixed halo, 2 exact) and the number of tiles this rank received from other ranks */
+int ssme_pf_shard_download(ssme_pf_handle h, double* x_local, uint64_t* cdf_local, int32_t* path, int64_t* exchanged_tiles);
+
 /* ============================================================================================
  * Liu-West filter: LWFilterWithCovs<nparts,1,1,1,4,float_t>::filter (include/ssme/liu_west_filter.h:971-1159)
  * with the model of svol_lw_1_par (test/test_liu_west.cpp:22-157): parameters (phi, mu, sigma, rho), one

@@ -50,6 +50,9 @@ struct LwArgs {
     uint32_t *anc, *kidx;                       // debug: resampling ancestors / k indices, or null
     LwScalars* scal;
     const double *y, *z;
+    double y_now, z_now;                        // step API: this call's observation / covariate in the kernel arguments (by_value = 1)
+    int32_t by_value;
+    double* ll_host;                            // step API: host-mapped buffer for the R log conditional likelihoods, or null
     double* per_step;
     const double *gamB, *pgamB, *gtotB;         // Gamma tables of the resampling draw   (stream base 16)
     const double *gamA, *pgamA, *gtotA;         // Gamma tables of the k draw            (stream base 80)
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_init(const LwArgs a) {
     const int out0 = a.tile0 * kTile;
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const size_t rowoff = (size_t)r * a.Npad;
-    const double y = a.y[a.yi];
+    const double y = a.by_value ? a.y_now : a.y[a.yi];
     const int i_first = b * kTile;
     double lg[NK][2];
 #pragma unroll
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
     const int out0 = a.tile0 * kTile, win0 = a.win_tile0 * kTile;
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const size_t rowoff = (size_t)r * a.Npad;
-    const double y = a.y[a.yi], z = a.z ? a.z[a.yi] : 0.0;
+    const double y = a.by_value ? a.y_now : a.y[a.yi], z = a.by_value ? a.z_now : (a.z ? a.z[a.yi] : 0.0);
     const int i_first = b * kTile;
     const size_t gidx = ((size_t)a.gi * a.R + r) * a.B + b;
     const double G = a.gtotB[(size_t)a.gi * a.R + r];
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
     const int out0 = a.tile0 * kTile, win0 = a.win_tile0 * kTile;
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const size_t rowoff = (size_t)r * a.Npad;
-    const double y = a.y[a.yi], z = a.z ? a.z[a.yi] : 0.0;
+    const double y = a.by_value ? a.y_now : a.y[a.yi], z = a.by_value ? a.z_now : (a.z ? a.z[a.yi] : 0.0);
     const int i_first = b * kTile;
     const size_t gidx = ((size_t)a.gi * a.R + r) * a.B + b;
     const double G = a.gtotA[(size_t)a.gi * a.R + r];
@@ -684,6 +687,7 @@ __global__ __launch_bounds__(kThreads) void k_lw_finalize(const LwArgs a) {
         sc->mB = m; sc->SB = S; sc->last_ll = ll; sc->loglik = sc->loglik + ll;
         sc->prev = ((a.t + 1) % a.resamp_sched == 0) ? a.logN : lseB;
         if (a.per_step) a.per_step[(size_t)r * a.Tcap + a.t] = ll;
+        if (a.ll_host) a.ll_host[r] = ll;
     }
 }
 

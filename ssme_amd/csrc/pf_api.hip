@@ -5,6 +5,7 @@
 #include "pf_kernels.h"
 #include "lw_kernels.h"
 #include "pf_small.h"
+#include "shard_driver.h"
 
 #include <atomic>
 #include <cmath>
@@ -35,11 +36,18 @@ struct ssme_pf_s {
     int32_t *l2_lo, *l2_hi;
     size_t lds_bytes_big, lds_bytes_plan;
     double* yz_step;         // device [2]: y and z of the step API, uploaded by ONE copy
-    double* pin;             // pinned host staging of the step API: [0] y, [1] z, [2 .. 2+R) log conditional likelihoods
+    double* pin;             // pinned, device-mapped host staging: [2 .. 2+R) log conditional likelihoods of the step API (written by the accounting kernel)
+    double* pin_dev;         // the same memory as the device sees it
     int gamma_t0, gamma_rows;   // step API: the Gamma tables hold time indices gamma_t0 .. gamma_t0 + gamma_rows - 1
     int num_cus;             // compute units of the device (priority schedule of the step kernel)
     int small_series;        // 1: one-tile filters run the whole series in one launch (k_filter_series_small)
     int nt;                  // threads per 2048-particle tile of k_filter_step (256, 512, 1024)
+    // C++ shard driver (ssme_pf_shard_run_series): halo buffers [margin | own tiles | margin] x 2048 doubles, ping-pong;
+    // this rank's tile sums / maxima, their gathered and repacked forms; exact-path window buffers; flag + statistics
+    double *sh_x[2], *sh_c[2], *sh_loc, *sh_raw, *sh_tsum, *sh_tmax, *sh_winx, *sh_winc;
+    int32_t* sh_flag;        // [0] a window left the halo, [1] / [2] widest reach left / right of the own tiles (in tiles)
+    int sh_margin, sh_rows, sh_path;   // sh_path: path of the last native series (1 fixed halo, 2 exact)
+    long sh_exchanged;       // tiles received from other ranks during the last native series
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     float last_ms;
@@ -261,15 +269,18 @@ static void launch_gamma(ssme_pf_handle h, int t0, int nT) {
 }
 // accounts the log conditional likelihood of step t from the buffers the step wrote (now `cur`)
 // split level-2 of the buffers `cur` holds: for the step t about to run (plan_ranges) or only the accounting of step t-1
-static void launch_plan(ssme_pf_handle h, int t, int gi, bool plan_ranges, bool finalize_prev, bool record_per_step) {
+static void launch_plan(ssme_pf_handle h, int t, int gi, bool plan_ranges, bool finalize_prev, bool record_per_step,
+                        double* ll_host = nullptr) {
     StepArgs a = step_args(h);
     a.t = t; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
+    a.ll_host = ll_host;
     a.per_step = record_per_step ? h->per_step : nullptr;
     hipLaunchKernelGGL(k_level2_plan, dim3(h->R), dim3(1024), h->lds_bytes_plan, h->stream, a, plan_ranges ? 1 : 0);
 }
-static void launch_kf(ssme_pf_handle h, int t, bool record_per_step) {
-    if (h->split_l2) { launch_plan(h, t + 1, 0, false, true, record_per_step); return; }
+static void launch_kf(ssme_pf_handle h, int t, bool record_per_step, double* ll_host = nullptr) {
+    if (h->split_l2) { launch_plan(h, t + 1, 0, false, true, record_per_step, ll_host); return; }
     StepArgs a = step_args(h);
+    a.ll_host = ll_host;
     a.t = t;
     a.per_step = record_per_step ? h->per_step : nullptr;
     hipLaunchKernelGGL(kf_finalize, dim3(h->R), dim3(kThreads), 0, h->stream, a);
@@ -280,7 +291,7 @@ static void enqueue_step(ssme_pf_handle h, int t, int yi, int gi, bool has_z, bo
                          bool from_step_staging = false) {
     StepArgs a = step_args(h);
     a.z = has_z ? h->zbuf : nullptr;
-    if (from_step_staging) { a.y = h->yz_step; a.z = has_z ? h->yz_step + 1 : nullptr; }
+    if (from_step_staging) { a.by_value = 1; a.y_now = h->pin[0]; a.z_now = has_z ? h->pin[1] : 0.0; }
     a.per_step = record_per_step ? h->per_step : nullptr;
     a.t = t; a.yi = yi; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
     if (h->split_l2 && t > 0) launch_plan(h, t, gi, true, finalize_prev, record_per_step);
@@ -461,7 +472,8 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
         HIPCHK(hipMalloc(&h->exp_out, sizeof(double) * ((size_t)(kMaxFunctionals + 1) * h->R + kMaxFunctionals + 1)));
         HIPCHK(hipMalloc(&h->keybuf, sizeof(uint32_t) * 2));
         HIPCHK(hipMalloc(&h->yz_step, sizeof(double) * 2));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pin), sizeof(double) * (2 + (size_t)h->R + 64 + 8), hipHostMallocDefault));   // + 128 ints for the shard plan + 8 swarm aggregates
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pin), sizeof(double) * (2 + (size_t)h->R + 64 + 8), hipHostMallocMapped));   // + 128 ints for the shard plan + 8 swarm aggregates
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_dev), h->pin, 0));
         int rc2 = upload_key(h);
         if (rc2 != SSME_OK) return rc2;
         if (h->shard_world > 0) return ensure_series_capacity(h, 1);
@@ -481,7 +493,8 @@ int ssme_pf_destroy(ssme_pf_handle h) {
     h->stream = h->own_stream;
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     void* bufs[] = {h->x[0], h->x[1], h->cdf[0], h->cdf[1], h->tsum[0], h->tsum[1], h->tmax[0], h->tmax[1], h->logw,
-                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_lo, h->l2_hi, h->yz_step, h->exp_part, h->exp_out, h->wscratch};
+                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_lo, h->l2_hi, h->yz_step, h->exp_part, h->exp_out, h->wscratch,
+                    h->sh_x[0], h->sh_x[1], h->sh_c[0], h->sh_c[1], h->sh_loc, h->sh_raw, h->sh_tsum, h->sh_tmax, h->sh_winx, h->sh_winc, h->sh_flag};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->pin) hipHostFree(h->pin);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -540,20 +553,30 @@ static StepArgs shard_args(ssme_pf_handle h, int t, const double* tsum_all, cons
     return a;
 }
 
+// the plan of step t on the device: every rank's window into h->plan_dev (up to 512 tiles) or every tile's range into
+// l2_lo / l2_hi (split level-2, which also accounts log p(y_{t-1} | .))
+static void shard_plan_device(ssme_pf_handle h, int t, const double* tsum_all, const double* tmax_all) {
+    StepArgs a = shard_args(h, t, tsum_all, tmax_all);
+    if (h->split_l2) {
+        a.finalize_prev = 1;
+        hipLaunchKernelGGL(k_level2_plan, dim3(1), dim3(1024), h->lds_bytes_plan, h->stream, a, 1);
+    } else {
+        hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(512), sizeof(double) * (h->Bpow2 < 2 ? 2 : h->Bpow2), h->stream, a,
+                           h->shard_world, h->plan_dev);
+    }
+}
+
 int ssme_pf_shard_plan(ssme_pf_handle h, const double* tsum_all, const double* tmax_all, int32_t t, int32_t* lo_hi) {
     if (!h || !tsum_all || !tmax_all || !lo_hi || t < 1) return SSME_ERR_INVALID_ARG;
     if (h->shard_world < 1) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
-    StepArgs a = shard_args(h, t, tsum_all, tmax_all);
+    shard_plan_device(h, t, tsum_all, tmax_all);
+    HIPCHK(hipGetLastError());
+    int32_t* stage = reinterpret_cast<int32_t*>(h->pin + 2 + h->R);            // pinned
     if (h->split_l2) {
-        // more than 512 tiles in total: the split level-2 plans every tile (and accounts log p(y_{t-1} | .)); a rank's
-        // window is [lo of its first tile, hi of its last tile]
-        a.finalize_prev = 1;
-        hipLaunchKernelGGL(k_level2_plan, dim3(1), dim3(1024), h->lds_bytes_plan, h->stream, a, 1);
-        HIPCHK(hipGetLastError());
+        // more than 512 tiles in total: the split level-2 plans every tile; a rank's window is [lo of its first tile, hi of its last]
         const int Bl = h->B / h->shard_world;
         const bool sorted = h->cfg.resampler != SSME_RESAMP_MULTINOMIAL_IID;
-        int32_t* stage = reinterpret_cast<int32_t*>(h->pin + 2 + h->R);        // pinned
         for (int d = 0; d < h->shard_world; ++d) {
             stage[2 * d] = 0; stage[2 * d + 1] = h->B - 1;
             if (sorted) {
@@ -561,15 +584,9 @@ int ssme_pf_shard_plan(ssme_pf_handle h, const double* tsum_all, const double* t
                 HIPCHK(hipMemcpyAsync(stage + 2 * d + 1, h->l2_hi + (size_t)(d + 1) * Bl - 1, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
             }
         }
-        HIPCHK(wait_stream_low_latency(h->stream));
-        for (int d = 0; d < 2 * h->shard_world; ++d) lo_hi[d] = stage[d];
-        return SSME_OK;
+    } else {
+        HIPCHK(hipMemcpyAsync(stage, h->plan_dev, sizeof(int32_t) * 2 * h->shard_world, hipMemcpyDeviceToHost, h->stream));
     }
-    hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(512), sizeof(double) * (h->Bpow2 < 2 ? 2 : h->Bpow2), h->stream, a,
-                       h->shard_world, h->plan_dev);
-    HIPCHK(hipGetLastError());
-    int32_t* stage = reinterpret_cast<int32_t*>(h->pin + 2 + h->R);            // pinned
-    HIPCHK(hipMemcpyAsync(stage, h->plan_dev, sizeof(int32_t) * 2 * h->shard_world, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(wait_stream_low_latency(h->stream));
     for (int d = 0; d < 2 * h->shard_world; ++d) lo_hi[d] = stage[d];
     return SSME_OK;
@@ -608,6 +625,202 @@ int ssme_pf_shard_finalize(ssme_pf_handle h, int32_t t, const double* tsum_all, 
         hipLaunchKernelGGL(kf_finalize, dim3(1), dim3(kThreads), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
+    return SSME_OK;
+}
+
+// ---- C++ driver of the sharded filter over RCCL (shard_driver.h) ----------------------------------------------------------
+#define NCCLCHK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
+    if (h) h->err = std::string(#call) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r_) : "RCCL error"); return SSME_ERR_HIP; } } while (0)
+
+int ssme_shard_comm_get_unique_id(void* id128) {
+    ssme_pf_handle h = nullptr;
+    if (!id128) return SSME_ERR_INVALID_ARG;
+    if (!rccl().ok) return SSME_ERR_UNSUPPORTED;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    NCCLCHK(rccl().GetUniqueId(reinterpret_cast<ncclUniqueId*>(id128)));
+    return SSME_OK;
+}
+int ssme_shard_comm_init(const void* id128, int32_t rank, int32_t world, int32_t device, void** comm_out) {
+    ssme_pf_handle h = nullptr;
+    if (!id128 || !comm_out || world < 1 || rank < 0 || rank >= world) return SSME_ERR_INVALID_ARG;
+    if (!rccl().ok) return SSME_ERR_UNSUPPORTED;
+    if (hipSetDevice(device) != hipSuccess) return SSME_ERR_HIP;
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    NCCLCHK(rccl().CommInitRank(&c, world, id, rank));
+    *comm_out = c;
+    return SSME_OK;
+}
+int ssme_shard_comm_destroy(void* comm) {
+    ssme_pf_handle h = nullptr;
+    if (!comm) return SSME_ERR_INVALID_ARG;
+    if (!rccl().ok) return SSME_ERR_UNSUPPORTED;
+    NCCLCHK(rccl().CommDestroy(reinterpret_cast<ncclComm_t>(comm)));
+    return SSME_OK;
+}
+
+static int shard_alloc(ssme_pf_handle h, bool exact) {
+    const int world = h->shard_world, Bl = h->B / world;
+    if (!h->sh_x[0]) {
+        // halo margin: a rank's resampling window normally reaches a tile or two into its neighbours (the cumulative tile
+        // weights wander like sqrt(tiles) around the uniform split); 4 tiles or 1/64 of the share, never more than the share
+        int m = Bl / 64 > 4 ? Bl / 64 : 4;
+        if (m > Bl) m = Bl;
+        if (world == 1) m = 0;
+        h->sh_margin = m; h->sh_rows = Bl + 2 * m;
+        const size_t nb = sizeof(double) * (size_t)h->sh_rows * kTile;
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipMalloc(&h->sh_x[i], nb)); HIPCHK(hipMemset(h->sh_x[i], 0, nb));
+            HIPCHK(hipMalloc(&h->sh_c[i], nb)); HIPCHK(hipMemset(h->sh_c[i], 0, nb));
+        }
+        HIPCHK(hipMalloc(&h->sh_loc, sizeof(double) * 2 * Bl));
+        HIPCHK(hipMalloc(&h->sh_raw, sizeof(double) * 2 * (size_t)h->B));
+        HIPCHK(hipMalloc(&h->sh_tsum, sizeof(double) * h->Bs));
+        HIPCHK(hipMalloc(&h->sh_tmax, sizeof(double) * h->Bs));
+        HIPCHK(hipMalloc(&h->sh_flag, sizeof(int32_t) * 4));
+    }
+    if (exact && !h->sh_winx) {
+        HIPCHK(hipMalloc(&h->sh_winx, sizeof(double) * (size_t)h->B * kTile));
+        HIPCHK(hipMalloc(&h->sh_winc, sizeof(double) * (size_t)h->B * kTile));
+    }
+    return SSME_OK;
+}
+
+static int shard_gather(ssme_pf_handle h, ncclComm_t comm) {
+    const int world = h->shard_world, Bl = h->B / world;
+    NCCLCHK(rccl().AllGather(h->sh_loc, h->sh_raw, (size_t)2 * Bl, ncclDouble, comm, h->stream));
+    hipLaunchKernelGGL(k_shard_repack, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, (const double*)h->sh_raw, world, Bl, h->sh_tsum, h->sh_tmax);
+    HIPCHK(hipGetLastError());
+    return SSME_OK;
+}
+
+// One series on one path.  fast: fixed halo exchange, no host synchronisation inside the loop; exact: planned exchange.
+static int shard_series(ssme_pf_handle h, ncclComm_t comm, const double* y, const double* z, int T, bool fast, bool* overflow) {
+    const int world = h->shard_world, rank = h->shard_rank, Bl = h->B / world, m = h->sh_margin, tile0 = rank * Bl;
+    const size_t TL = kTile;
+    int rc = ssme_pf_shard_prepare(h, y, z, T);
+    if (rc != SSME_OK) return rc;
+    HIPCHK(hipMemsetAsync(h->sh_flag, 0, sizeof(int32_t) * 4, h->stream));
+    h->sh_exchanged = 0;
+    int cur = 0;
+    std::vector<int32_t> lo_hi(2 * (size_t)world);
+    for (int t = 0; t < T; ++t) {
+        double* xs = h->sh_x[cur]; double* cs = h->sh_c[cur];                     // sources: own rows + halos
+        double* xo = h->sh_x[cur ^ 1] + (size_t)m * TL; double* co = h->sh_c[cur ^ 1] + (size_t)m * TL;   // outputs: the own rows of the other pair
+        const double *xw = nullptr, *cw = nullptr;
+        int win0 = 0;
+        if (t > 0) {
+            rc = shard_gather(h, comm);
+            if (rc != SSME_OK) return rc;
+            if (fast) {
+                shard_plan_device(h, t, h->sh_tsum, h->sh_tmax);
+                hipLaunchKernelGGL(k_shard_window_check, dim3(1), dim3(64), 0, h->stream, h->split_l2 ? (const int32_t*)nullptr : (const int32_t*)h->plan_dev,
+                                   (const int32_t*)h->l2_lo, (const int32_t*)h->l2_hi, world, Bl, m, h->sh_flag, h->sh_flag + 1);
+                HIPCHK(hipGetLastError());
+                if (world > 1) {
+                    // fixed halo: my first m tiles are the left neighbour's right halo, my last m tiles the right neighbour's left halo
+                    NCCLCHK(rccl().GroupStart());
+                    for (double* buf : {xs, cs}) {
+                        if (rank > 0) {
+                            NCCLCHK(rccl().Send(buf + (size_t)m * TL, (size_t)m * TL, ncclDouble, rank - 1, comm, h->stream));
+                            NCCLCHK(rccl().Recv(buf, (size_t)m * TL, ncclDouble, rank - 1, comm, h->stream));
+                        }
+                        if (rank + 1 < world) {
+                            NCCLCHK(rccl().Send(buf + (size_t)Bl * TL, (size_t)m * TL, ncclDouble, rank + 1, comm, h->stream));
+                            NCCLCHK(rccl().Recv(buf + (size_t)(m + Bl) * TL, (size_t)m * TL, ncclDouble, rank + 1, comm, h->stream));
+                        }
+                    }
+                    NCCLCHK(rccl().GroupEnd());
+                    h->sh_exchanged += (long)m * ((rank > 0) + (rank + 1 < world));
+                }
+                xw = xs; cw = cs; win0 = tile0 - m;                                   // row 0 of the halo buffer is global tile tile0 - m
+            } else {
+                rc = ssme_pf_shard_plan(h, h->sh_tsum, h->sh_tmax, t, lo_hi.data());   // synchronises: the exact path is host-planned
+                if (rc != SSME_OK) return rc;
+                const int lo = lo_hi[2 * rank], hi = lo_hi[2 * rank + 1];
+                NCCLCHK(rccl().GroupStart());
+                for (int pass = 0; pass < 2; ++pass) {
+                    const double* own = (pass == 0 ? xs : cs) + (size_t)m * TL;          // my tiles tile0 .. tile0 + Bl - 1
+                    double* win = pass == 0 ? h->sh_winx : h->sh_winc;               // window: global tiles lo .. hi
+                    for (int p = 0; p < world; ++p) {
+                        // what I need from rank p: [lo, hi] x p's tiles
+                        const int a1 = lo > p * Bl ? lo : p * Bl, b1 = hi < (p + 1) * Bl - 1 ? hi : (p + 1) * Bl - 1;
+                        if (b1 >= a1) {
+                            if (p == rank) HIPCHK(hipMemcpyAsync(win + (size_t)(a1 - lo) * TL, own + (size_t)(a1 - tile0) * TL, sizeof(double) * (size_t)(b1 - a1 + 1) * TL,
+                                                                 hipMemcpyDeviceToDevice, h->stream));
+                            else { NCCLCHK(rccl().Recv(win + (size_t)(a1 - lo) * TL, (size_t)(b1 - a1 + 1) * TL, ncclDouble, p, comm, h->stream)); if (pass == 0) h->sh_exchanged += b1 - a1 + 1; }
+                        }
+                        // what rank p needs from me: [lo_p, hi_p] x my tiles
+                        if (p != rank) {
+                            const int lp = lo_hi[2 * p], hp = lo_hi[2 * p + 1];
+                            const int a2 = lp > tile0 ? lp : tile0, b2 = hp < tile0 + Bl - 1 ? hp : tile0 + Bl - 1;
+                            if (b2 >= a2) NCCLCHK(rccl().Send(own + (size_t)(a2 - tile0) * TL, (size_t)(b2 - a2 + 1) * TL, ncclDouble, p, comm, h->stream));
+                        }
+                    }
+                }
+                NCCLCHK(rccl().GroupEnd());
+                xw = h->sh_winx; cw = h->sh_winc; win0 = lo;
+            }
+        }
+        rc = ssme_pf_shard_step(h, t, xw, cw, win0, h->sh_tsum, h->sh_tmax, xo, co, h->sh_loc, h->sh_loc + Bl, nullptr);
+        if (rc != SSME_OK) return rc;
+        cur ^= 1;
+    }
+    rc = shard_gather(h, comm);
+    if (rc != SSME_OK) return rc;
+    rc = ssme_pf_shard_finalize(h, T - 1, h->sh_tsum, h->sh_tmax);                    // synchronises
+    if (rc != SSME_OK) return rc;
+    h->cur = cur;                                                                     // sh_x[cur] holds the final particles
+    int32_t flag[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(flag, h->sh_flag, sizeof(flag), hipMemcpyDeviceToHost));
+    *overflow = fast && flag[0] != 0;
+    return SSME_OK;
+}
+
+int ssme_pf_shard_run_series(ssme_pf_handle h, void* nccl_comm, const double* y, const double* z, int32_t T, int32_t mode, double* loglik_out) {
+    if (!h || !nccl_comm || !y || mode < 0 || mode > 2) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1 || !h->params_set) return SSME_ERR_STATE;
+    if (T < 1) return SSME_ERR_LENGTH;
+    if (!rccl().ok) { h->err = "RCCL (librccl.so) not found in this process"; return SSME_ERR_UNSUPPORTED; }
+    if (h->cfg.resampler == SSME_RESAMP_MULTINOMIAL_IID && mode == 1) return SSME_ERR_UNSUPPORTED;      // unsorted targets need every tile
+    HIPCHK(hipSetDevice(h->cfg.device));
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+    const bool want_fast = mode != 2 && h->cfg.resampler != SSME_RESAMP_MULTINOMIAL_IID;
+    int rc = shard_alloc(h, !want_fast);
+    if (rc != SSME_OK) return rc;
+    bool overflow = false;
+    h->sh_path = want_fast ? 1 : 2;
+    rc = shard_series(h, comm, y, z, T, want_fast, &overflow);
+    if (rc != SSME_OK) return rc;
+    if (overflow) {
+        // a window left the fixed halo on SOME rank (the flag is computed from the shared plan, so every rank sees it):
+        // mode 1 reports it, mode 0 runs the series again on the exact path
+        if (mode == 1) { h->err = "a resampling window left the fixed halo"; return SSME_ERR_STATE; }
+        rc = shard_alloc(h, true);
+        if (rc != SSME_OK) return rc;
+        h->sh_path = 2;
+        rc = shard_series(h, comm, y, z, T, false, &overflow);
+        if (rc != SSME_OK) return rc;
+    }
+    if (loglik_out) return ssme_pf_get_loglik(h, loglik_out);
+    return SSME_OK;
+}
+
+// this rank's particles and integer cdf after the last native series (N / world values each); path / statistics
+int ssme_pf_shard_download(ssme_pf_handle h, double* x_local, uint64_t* cdf_local, int32_t* path, int64_t* exchanged_tiles) {
+    if (!h) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1 || !h->sh_x[0]) return SSME_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t n = (size_t)(h->B / h->shard_world) * kTile, off = (size_t)h->sh_margin * kTile;
+    if (x_local) HIPCHK(hipMemcpy(x_local, h->sh_x[h->cur] + off, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (cdf_local) {
+        HIPCHK(hipMemcpy(cdf_local, h->sh_c[h->cur] + off, sizeof(double) * n, hipMemcpyDeviceToHost));
+        double dv;
+        for (size_t i = 0; i < n; ++i) { std::memcpy(&dv, &cdf_local[i], 8); cdf_local[i] = (uint64_t)dv; }
+    }
+    if (path) *path = h->sh_path;
+    if (exchanged_tiles) *exchanged_tiles = h->sh_exchanged;
     return SSME_OK;
 }
 
@@ -691,9 +904,9 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
         int rc = ensure_gamma_capacity(h, kStepGammaChunk);
         if (rc != SSME_OK) return rc;
     }
-    // y, z and the results travel through pinned memory: pageable copies cost a staging round trip each
+    // y and z travel in the kernel arguments; the R results come back through device-mapped pinned memory, written by the
+    // accounting kernel itself: a filter() call is two launches and a poll, no copy operation in either direction
     h->pin[0] = *y; h->pin[1] = z ? *z : 0.0;
-    HIPCHK(hipMemcpyAsync(h->yz_step, h->pin, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     // Gamma tables are drawn kStepGammaChunk time steps at a time (data independent), so that the two table launches are paid
     // once per chunk and not once per filter() call
     int gi = 0;
@@ -705,17 +918,11 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
         gi = h->t - h->gamma_t0;
     }
     enqueue_step(h, h->t, 0, gi, z != nullptr, /*finalize_prev=*/false, /*per_step=*/false, /*from_step_staging=*/true);
-    launch_kf(h, h->t, false);
+    launch_kf(h, h->t, false, h->pin_dev + 2);
     HIPCHK(hipGetLastError());
     h->t += 1;
-    if (out) {
-        hipLaunchKernelGGL(k_collect_last_ll, dim3((h->R + 255) / 256), dim3(256), 0, h->stream, (const FilterScalars*)h->scal, h->scratchR, h->R);
-        HIPCHK(hipMemcpyAsync(h->pin + 2, h->scratchR, sizeof(double) * h->R, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(wait_stream_low_latency(h->stream));
-        for (int r = 0; r < h->R; ++r) out[r] = h->pin[2 + r];
-    } else {
-        HIPCHK(wait_stream_low_latency(h->stream));
-    }
+    HIPCHK(wait_stream_low_latency(h->stream));
+    if (out) for (int r = 0; r < h->R; ++r) out[r] = h->pin[2 + r];
     return SSME_OK;
 }
 
@@ -1190,6 +1397,7 @@ struct ssme_lw_s {
     hipStream_t own_stream;
     int32_t* plan_dev;
     int32_t* plan_pin;               // pinned staging of the plan download
+    double *pin, *pin_dev;           // step API: device-mapped pinned buffer for the R log conditional likelihoods
     int gamma_t0, gamma_rows;        // step API: the Gamma tables hold time indices gamma_t0 .. gamma_t0 + gamma_rows - 1
     int split_l2;                    // level-2 of both draws by k_level2_plan (more than 512 tiles)
     double *l2T[2], *l2R[2];         // [draw: 0 resampling (B), 1 k draw (A)][R][Bs]
@@ -1291,8 +1499,9 @@ static void lw_launch_plan(ssme_lw_handle h, int draw, int t, int gi, const doub
     hipLaunchKernelGGL(k_level2_plan, dim3(h->shard_world > 0 ? 1 : h->R), dim3(1024), h->lds_bytes_plan, h->stream, a, ranges ? 1 : 0);
 }
 
-static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record, bool finalize_prev) {
+static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record, bool finalize_prev, const double* yz_now = nullptr) {
     LwArgs a = lw_args(h);
+    if (yz_now) { a.by_value = 1; a.y_now = yz_now[0]; a.z_now = yz_now[1]; }
     a.t = t; a.yi = yi; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
     a.per_step = record ? h->per_step : nullptr;
     const dim3 grid(h->B, h->R);
@@ -1311,9 +1520,9 @@ static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record
         hipLaunchKernelGGL(k_lw_stage2<false>, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
     }
 }
-static void lw_enqueue_finalize(ssme_lw_handle h, int t, bool record) {
+static void lw_enqueue_finalize(ssme_lw_handle h, int t, bool record, double* ll_host = nullptr) {
     LwArgs a = lw_args(h);
-    a.t = t;
+    a.t = t; a.ll_host = ll_host;
     a.per_step = record ? h->per_step : nullptr;
     if (h->split_l2) {
         lw_launch_plan(h, 0, t + 1, 0, h->tsumB, h->tmaxB, false);
@@ -1346,6 +1555,7 @@ int ssme_lw_destroy(ssme_lw_handle h) {
                     h->l2hi[0], h->l2hi[1], h->l2s[0], h->l2s[1], h->lwB, h->wscratch};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->plan_pin) hipHostFree(h->plan_pin);
+    if (h->pin) hipHostFree(h->pin);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1415,6 +1625,8 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
         LWCHK(hipMemset(h->prop, 0, sizeof(double) * (size_t)h->R * 16));
         LWCHK(hipMalloc(&h->scal, sizeof(LwScalars) * h->R));
         LWCHK(hipMalloc(&h->scratch, sizeof(double) * h->R * kLwNExp));
+        LWCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pin), sizeof(double) * (size_t)h->R, hipHostMallocMapped));
+        LWCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_dev), h->pin, 0));
         LWCHK(hipMalloc(&h->keybuf, sizeof(uint32_t) * 2));
         {
             const uint32_t k[2] = {(uint32_t)h->cfg.seed, (uint32_t)(h->cfg.seed >> 32)};
@@ -1647,8 +1859,9 @@ int ssme_lw_step(ssme_lw_handle h, const double* y, const double* z, double* out
         int rc = lw_ensure_gamma(h, kStepGammaChunk);
         if (rc != SSME_OK) return rc;
     }
-    LWCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double), hipMemcpyHostToDevice, h->stream));
-    LWCHK(hipMemcpyAsync(h->zbuf, &z0, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // y and z travel in the kernel arguments, the R results come back through device-mapped pinned memory written by the
+    // accounting kernel: no copy operation in either direction
+    const double yz[2] = {*y, z0};
     int gi = 0;
     if (h->t > 0) {                              // Gamma tables of both draws, kStepGammaChunk steps at a time
         if (h->t < h->gamma_t0 || h->t >= h->gamma_t0 + h->gamma_rows) {
@@ -1657,13 +1870,11 @@ int ssme_lw_step(ssme_lw_handle h, const double* y, const double* z, double* out
         }
         gi = h->t - h->gamma_t0;
     }
-    lw_enqueue_step(h, h->t, 0, gi, false, /*finalize_prev=*/false);
-    lw_enqueue_finalize(h, h->t, false);          // the step API accounts each step right away
+    lw_enqueue_step(h, h->t, 0, gi, false, /*finalize_prev=*/false, yz);
+    lw_enqueue_finalize(h, h->t, false, h->pin_dev);          // the step API accounts each step right away
     LWCHK(hipGetLastError());
-    std::vector<LwScalars> sc(h->R);
-    LWCHK(hipMemcpyAsync(sc.data(), h->scal, sizeof(LwScalars) * h->R, hipMemcpyDeviceToHost, h->stream));
     LWCHK(wait_stream_low_latency(h->stream));
-    if (out) for (int r = 0; r < h->R; ++r) out[r] = sc[r].last_ll;
+    if (out) for (int r = 0; r < h->R; ++r) out[r] = h->pin[r];
     h->t += 1;
     return SSME_OK;
 }

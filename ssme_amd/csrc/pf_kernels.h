@@ -84,6 +84,9 @@ struct StepArgs {
     const ModelConst* mc;      // [R]
     const double* y;           // [T]
     const double* z;           // [T] or null
+    double y_now, z_now;       // step API: the observation and covariate of THIS call travel in the kernel arguments (by_value = 1)
+    int32_t by_value;          // 1: use y_now / z_now instead of y[yi] / z[yi] (no upload, no memory read)
+    double* ll_host;           // step API: host-mapped buffer that receives the R log conditional likelihoods from the accounting kernel, or null
     double* per_step;          // [R][Tcap] or null
     const double* gam;         // [nT][R][B] Gamma(n_b) draws          (multinomial)
     const double* pgam;        // [nT][R][B] exclusive prefixes of gam
@@ -513,8 +516,8 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     const uint32_t key0 = a.keyp[0], key1 = a.keyp[1];
     const size_t rowoff = (size_t)r * a.Npad;
     const ModelConst mc = a.mc[r];
-    const double y = a.y[a.yi];
-    const double zcov = a.z ? a.z[a.yi] : 0.0;
+    const double y = a.by_value ? a.y_now : a.y[a.yi];
+    const double zcov = a.by_value ? a.z_now : (a.z ? a.z[a.yi] : 0.0);
     const int rsm = HOT ? RS : a.resampler;
     const bool first_step = !HOT && a.t == 0;
     const bool resampled = HOT ? true : ((a.t > 0) && (a.t % a.resamp_sched == 0));
@@ -926,6 +929,7 @@ __global__ __launch_bounds__(kThreads) void kf_finalize(const StepArgs a) {
         sc->loglik = sc->loglik + ll;
         sc->prev = resample_now ? a.logN : lse;
         if (a.per_step) a.per_step[(size_t)r * a.Tcap + a.t] = ll;
+        if (a.ll_host) a.ll_host[r] = ll;
     }
 }
 
@@ -1018,6 +1022,7 @@ __global__ __launch_bounds__(1024) void k_level2_plan(const StepArgs a, int plan
             sc->loglik = sc->loglik + ll;
             sc->prev = resampled ? a.logN : lse;
             if (a.per_step) a.per_step[(size_t)r * a.Tcap + (a.t - 1)] = ll;
+            if (a.ll_host) a.ll_host[r] = ll;
         }
     }
 }

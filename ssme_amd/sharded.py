@@ -201,6 +201,9 @@ class ShardedParticleFilter:
         torch.cuda.synchronize(self.device)
 
     def close(self):
+        if getattr(self, "_comm", None) is not None:
+            capi.lib().ssme_shard_comm_destroy(self._comm)
+            self._comm = None
         if getattr(self, "_h", None) is not None and self._h.value:
             capi.lib().ssme_pf_destroy(self._h)
             self._h = C.c_void_p()
@@ -210,7 +213,7 @@ class ShardedParticleFilter:
     def _chk(self, status):
         if status != capi.OK:
             msg = capi.lib().ssme_pf_strerror(status).decode()
-            if status == capi.ERR_HIP:
+            if status in (capi.ERR_HIP, capi.ERR_STATE, capi.ERR_UNSUPPORTED):
                 msg += " (" + capi.lib().ssme_pf_last_error(self._h).decode() + ")"
             raise SsmeError(status, msg)
 
@@ -293,6 +296,45 @@ class ShardedParticleFilter:
 
     def local_cdf(self):
         return self._hc[self._cur].own().reshape(-1).cpu().numpy()
+
+    # ---- the same loop in C++ over RCCL (ssme_pf_shard_run_series): no Python, no host synchronisation per step ----
+    def _native_comm(self):
+        """An RCCL communicator for the C++ driver: rank 0 makes the unique id, torch.distributed ships its 128 bytes."""
+        if getattr(self, "_comm", None) is None:
+            import torch.distributed as dist
+            L = capi.lib()
+            buf = (C.c_ubyte * 128)()
+            if self.rank == 0:
+                self._chk(L.ssme_shard_comm_get_unique_id(buf))
+            box = [bytes(buf)]
+            if self.world > 1:
+                dist.broadcast_object_list(box, src=0 if self.group is None else dist.get_global_rank(self.group, 0), group=self.group)
+            idbuf = (C.c_ubyte * 128).from_buffer_copy(box[0])
+            comm = C.c_void_p()
+            self._chk(L.ssme_shard_comm_init(idbuf, self.rank, self.world, self.device.index or 0, C.byref(comm)))
+            self._comm = comm
+        return self._comm
+
+    def run_series_native(self, y, z=None, mode=0):
+        """log p(y_{1:T}) through the C++ driver.  mode 0: fixed-halo fast path with an exact rerun if a window ever left
+        the halo; 1: fast path only; 2: exact (host-planned) path.  Needs one GPU per rank (RCCL)."""
+        import torch
+        yv = capi.as_f64(y)
+        zv = None if z is None else capi.as_f64(z)
+        comm = self._native_comm()
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+        out = np.empty(1)
+        self._chk(capi.lib().ssme_pf_shard_run_series(self._h, comm, capi.dptr(yv), capi.dptr(zv), yv.size, int(mode), capi.dptr(out)))
+        self._T = yv.size
+        return float(out[0])
+
+    def native_state(self):
+        """(particles, integer cdf, path, tiles received) of this rank after run_series_native."""
+        n = self.Bl * TILE
+        x, cdf = np.empty(n), np.empty(n, dtype=np.uint64)
+        path, ex = C.c_int32(), C.c_int64()
+        self._chk(capi.lib().ssme_pf_shard_download(self._h, capi.dptr(x), capi.u64ptr(cdf), C.byref(path), C.byref(ex)))
+        return x, cdf, path.value, ex.value
 
 
 class ShardedLiuWest:

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     src = open(os.path.join(ROOT, "include", "ssme_pf.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(ssme_(?:pf|lw)_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(ssme_(?:pf|lw|shard)_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_builds_and_exports_header_symbols():

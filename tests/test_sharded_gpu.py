@@ -121,3 +121,33 @@ def test_sharded_liu_west_is_bit_identical_to_unsharded(tmp_path, spy, world, n,
     assert np.array_equal(x.view(np.uint64), st["x"].view(np.uint64))
     assert np.array_equal(th.view(np.uint64), st["theta"].view(np.uint64))
     assert sum(int(r["exchanged"]) for r in res) > 0
+
+
+@pytest.mark.parametrize("model,n,rs,T,mode", [(0, 65536, 0, 16, 0), (1, 32768, 1, 12, 2), (0, 600 * 2048, 0, 5, 0), (0, 600 * 2048, 0, 4, 2),
+                                               (2, 16384, 2, 10, 1)])
+def test_native_rccl_driver_matches_unsharded(tmp_path, spy, model, n, rs, T, mode):
+    """ssme_pf_shard_run_series (C++ over RCCL, resolved from the process at run time) with one rank per GPU == the
+    unsharded filter, on the fixed-halo path (modes 0 / 1) and on the exact host-planned path (mode 2); the Python-driven
+    loop on the same handle gives the same log-likelihood.  (Multi-rank exchange needs one GPU per rank: bench.py.)"""
+    import ssme_amd
+    seed = 99
+    out = str(tmp_path / "native.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shard_worker_native.py"), out, str(model), str(n), str(T), str(rs),
+                        str(seed), str(mode)], env=env, timeout=300)
+    assert p.returncode == 0
+    r = np.load(out)
+    y = spy[:T]
+    z = np.concatenate([[0.0], y[:-1]]) if model == 1 else None
+    ref = ssme_amd.ParticleFilterBank(model, n, 1, seed, rs, tile=2048)
+    ref.set_params(TH[model])
+    ll = ref.run_series(y, z)[0]
+    per = ref.per_step()[0]
+    st = ref.state(0, logw=False)
+    ref.close()
+    assert float(r["ll"]) == ll and float(r["ll_py"]) == ll
+    assert np.array_equal(r["per_step"].view(np.uint64), per.view(np.uint64))
+    assert np.array_equal(r["x"].view(np.uint64), st["x"].view(np.uint64))
+    assert np.array_equal(r["cdf"], st["cdf"])
+    assert int(r["path"]) == (2 if mode == 2 else 1)

@@ -1,0 +1,39 @@
+// step_latency.cpp -- latency of the unchanged-caller path, mod.filter(y); ll += mod.getLogCondLike()
+// (example/estimate_univ_svol.h:121-127), through the C++ adaptor, without any Python in the loop.
+//   g++ -std=c++17 -O2 tools/step_latency.cpp -o tools/step_latency ssme_amd/libssme_pf.so -Wl,-rpath,$PWD/ssme_amd
+//   ./tools/step_latency tests/golden/spy_returns.csv
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <vector>
+
+#include "../include/ssme_gpu/bsfilter_gpu.hpp"
+
+struct vec1 { double v; double operator()(int) const { return v; } };
+
+template <std::size_t N>
+static void run(const std::vector<vec1>& data, const char* label) {
+    ssme_gpu::gpu_options o;
+    o.seed = 1;
+    ssme_gpu::svol_bs_gpu<N, double> mod(0.95, 1.0, 0.25, o, 0);
+    double ll = 0.0;
+    for (int t = 0; t < 64; ++t) { mod.filter(data[t]); ll += mod.getLogCondLike(); }
+    const int K = 1000;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < K; ++t) { mod.filter(data[64 + t]); ll += mod.getLogCondLike(); }
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / K;
+    std::printf("filter() N=%s: %.1f us per call (loglik %.6f)\n", label, us, ll);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    std::vector<vec1> data;
+    std::ifstream f(argv[1]);
+    double v;
+    while (f >> v) data.push_back(vec1{v});
+    run<500>(data, "500");
+    run<4096>(data, "4096");
+    run<65536>(data, "2^16");
+    run<1048576>(data, "2^20");
+    return 0;
+}
