@@ -154,7 +154,7 @@ double o_log(double x) {
     return dk * LN2_HI - ((hfsq - std::fma(s, hfsq + R, dk * LN2_LO)) - f);
 }
 
-// log of a uniform strictly inside (0,1): table + degree-6 series, no division (mirror of ssme_math.h: dlog_u).
+// log of a uniform strictly inside (0,1): 64-entry table + degree-7 series, no division (mirror of ssme_math.h: dlog_u).
 // The bootstrap filter's hot-loop draws (exponential spacings, Box-Muller radius) use it; absolute error < 2^-51.
 #include "ssme_log_table.h"
 struct LogTabEntry { double c, l; };
@@ -164,10 +164,11 @@ double o_log_u(double x) {
     const uint64_t ux = double_to_bits(x);
     const uint32_t hx = (uint32_t)(ux >> 32);
     const int k = (int)(hx >> 20) - 1023;
-    const LogTabEntry e = LOG_TABLE[(hx >> 13) & 127u];
+    const LogTabEntry e = LOG_TABLE[(hx >> 14) & 63u];
     const double m = bits_to_double((ux & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
     const double r = std::fma(m, e.c, -1.0);
-    double q = std::fma(r, -1.6666666666666666e-01, 2.0000000000000001e-01);
+    double q = std::fma(r, 1.4285714285714285e-01, -1.6666666666666666e-01);
+    q = std::fma(q, r, 2.0000000000000001e-01);
     q = std::fma(q, r, -2.5000000000000000e-01);
     q = std::fma(q, r, 3.3333333333333331e-01);
     q = std::fma(q, r, -5.0000000000000000e-01);
@@ -175,25 +176,26 @@ double o_log_u(double x) {
     const double dk = (double)k;
     return std::fma(dk, LN2_HI, e.l) + std::fma(dk, LN2_LO, p);
 }
-// The bootstrap filter's exp (mirror of ssme_math.h: dexp_scaled_t): 256-entry double-double table of 2^(j/256) + degree-5 series
+// The bootstrap filter's exp (mirror of ssme_math.h: dexp_scaled_t): 64-entry double-double table of 2^(j/64) + degree-6 series
 struct ExpTabEntry { double hi, lo; };
 static const ExpTabEntry EXP_TABLE[SSME_EXP_TABLE_SIZE] = {SSME_EXP_TABLE_ROWS};
 double o_exp_scaled_t(double x, int sc) {
-    const double INV = 369.3299304675746;
-    const double C_HI = 6.93147180369123816490e-01 * 0.00390625, C_LO = 1.90821492927058770002e-10 * 0.00390625;
+    const double INV = 92.33248261689366;
+    const double C_HI = 6.93147180369123816490e-01 * 0.015625, C_LO = 1.90821492927058770002e-10 * 0.015625;
     const double SH = 6755399441055744.0;
     const double xc = std::fmin(std::fmax(x, -746.0), 710.0);
     const double kf = std::fma(xc, INV, SH) - SH;
     const int n = (int)kf;
     double r = std::fma(-kf, C_HI, xc);
     r = std::fma(-kf, C_LO, r);
-    const ExpTabEntry e = EXP_TABLE[n & 255];
-    double q = std::fma(r, 0.008333333333333333, 0.041666666666666664);
+    const ExpTabEntry e = EXP_TABLE[n & 63];
+    double q = std::fma(r, 0.001388888888888889, 0.008333333333333333);
+    q = std::fma(q, r, 0.041666666666666664);
     q = std::fma(q, r, 0.16666666666666666);
     q = std::fma(q, r, 0.5);
     const double p = std::fma(r * r, q, r);
     const double res = e.hi + std::fma(e.hi, p, e.lo);
-    return std::ldexp(res, (n >> 8) + sc);
+    return std::ldexp(res, (n >> 6) + sc);
 }
 double o_exp_t(double x) { return o_exp_scaled_t(x, 0); }
 

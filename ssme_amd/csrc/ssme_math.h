@@ -105,26 +105,32 @@ SSME_HD double dexp_scaled(double x, int sc) {
 SSME_HD double dexp(double x) { return dexp_scaled(x, 0); }
 
 // The bootstrap filter's exp (its hot loop spends a third of its fp64 instructions here: logG's exp(-x) and the weight
-// quantisation, per particle): exp(x) = 2^k 2^(j/256) e^r with n = rint(x 256/ln2) = 256 k + j, 2^(j/256) from a
-// 256-entry double-double table and a degree-5 series for e^r, |r| <= ln2/512 (truncation < 2^-66).  14 fp64
+// quantisation, per particle): exp(x) = 2^k 2^(j/64) e^r with n = rint(x 64/ln2) = 64 k + j, 2^(j/64) from a
+// 64-entry double-double table and a degree-6 series for e^r, |r| <= ln2/128 (truncation < 2^-65).  15 fp64
 // instructions against 22 for the Taylor-13 form above; <= 1 ulp.  Same clamp / NaN behaviour as dexp_scaled.
+// (64 entries, not more: the table lives in LDS, see tools/gen_log_table.py.)
 struct ExpTabEntry { double hi, lo; };
 SSME_HD double dexp_scaled_t(double x, int sc, const ExpTabEntry* tab) {
-    const double INV = 369.3299304675746;                    // 256 / ln 2
-    const double C_HI = 6.93147180369123816490e-01 * 0.00390625, C_LO = 1.90821492927058770002e-10 * 0.00390625;   // ln2 / 256, hi + lo (exact scalings)
+#ifdef SSME_AB_TAYLOR_EXP          // timing A/B only (tools/ab_build.py): results differ from the specification
+    (void)tab;
+    return dexp_scaled(x, sc);
+#endif
+    const double INV = 92.33248261689366;                    // 64 / ln 2
+    const double C_HI = 6.93147180369123816490e-01 * 0.015625, C_LO = 1.90821492927058770002e-10 * 0.015625;   // ln2 / 64, hi + lo (exact scalings)
     const double SH = 6755399441055744.0;                    // 1.5 * 2^52
     const double xc = dminnum(dmaxnum(x, -746.0), 710.0);
     const double kf = dfma_c(xc, INV, SH) - SH;
     const int n = (int)kf;
     double r = dfma(-kf, C_HI, xc);
     r = dfma(-kf, C_LO, r);
-    const ExpTabEntry e = tab[n & 255];
-    double q = dfma_c(r, 0.008333333333333333, 0.041666666666666664);
+    const ExpTabEntry e = tab[n & 63];
+    double q = dfma_c(r, 0.001388888888888889, 0.008333333333333333);
+    q = dfma_c(q, r, 0.041666666666666664);
     q = dfma_c(q, r, 0.16666666666666666);
     q = dfma_c(q, r, 0.5);
     const double p = dfma(r * r, q, r);
     const double res = e.hi + dfma(e.hi, p, e.lo);
-    return dldexp(res, (n >> 8) + sc);
+    return dldexp(res, (n >> 6) + sc);
 }
 
 // round-to-nearest-even of v in [0, 2^52) to an integer, by the 2^52 trick
@@ -176,8 +182,8 @@ SSME_HD double dlog(double x) {
 // ---- log of a uniform: table + short series, no division ------------------------------------------------------------
 // The draws of the bootstrap filter's hot loop (exponential spacings, Box-Muller radius) take -log(u) of uniforms that lie
 // strictly inside (0,1).  fdlibm's log spends half its instructions on the IEEE division s = f/(2+f); this one takes
-// c_i ~ 1/m and l_i = -log(c_i) from a 128-entry table indexed by the top 7 mantissa bits, so that r = fma(m, c_i, -1)
-// has |r| < 2^-8 and log(x) = k ln2 + l_i + log1p(r) with log1p a degree-6 series (truncation < 2^-58).
+// c_i ~ 1/m and l_i = -log(c_i) from a 64-entry table indexed by the top 6 mantissa bits, so that r = fma(m, c_i, -1)
+// has |r| < 2^-7 and log(x) = k ln2 + l_i + log1p(r) with log1p a degree-7 series (truncation < 2^-59).
 // ABSOLUTE error < 2^-51 for any positive normal x (the relative error is unbounded next to x = 1, which the callers
 // never need: u <= 1 - 2^-41).  Same operation sequence in oracle/ssme_oracle.cpp.
 struct LogTabEntry { double c, l; };
@@ -186,10 +192,11 @@ SSME_HD double dlog_u(double x, const LogTabEntry* tab) {
     const uint64_t ux = d2bits(x);
     const uint32_t hx = (uint32_t)(ux >> 32);
     const int k = (int)(hx >> 20) - 1023;
-    const LogTabEntry e = tab[(hx >> 13) & 127u];
+    const LogTabEntry e = tab[(hx >> 14) & 63u];
     const double m = bits2d((ux & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
     const double r = dfma(m, e.c, -1.0);
-    double q = dfma_c(r, -1.6666666666666666e-01, 2.0000000000000001e-01);
+    double q = dfma_c(r, 1.4285714285714285e-01, -1.6666666666666666e-01);
+    q = dfma_c(q, r, 2.0000000000000001e-01);
     q = dfma_c(q, r, -2.5000000000000000e-01);
     q = dfma_c(q, r, 3.3333333333333331e-01);
     q = dfma_c(q, r, -5.0000000000000000e-01);
