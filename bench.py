@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--lw", action="store_true", help="Liu-West filter (BASELINE.json configs[4]); implies --mode sharded")
     ap.add_argument("--lw-steps", type=int, default=256, help="time steps of the series per Liu-West pass")
     ap.add_argument("--rehearse", action="store_true", help="gloo ranks sharing cuda:0 when the box has fewer GPUs than --gpus")
+    ap.add_argument("--driver", choices=["native", "python"], default="native",
+                    help="sharded bootstrap filter: the C++ loop over RCCL (ssme_pf_shard_run_series) or the Python loop over torch.distributed")
     ap.add_argument("--particles", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--resampler", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
@@ -251,7 +253,8 @@ def main():
         else:
             filt = sharded.ShardedParticleFilter(ssme_amd.MODEL_SVOL, n, SEED, args.resampler)
             filt.set_params(THETA)
-            run = lambda: filt.run_series(y)
+            native = args.driver == "native" and not rehearse       # RCCL needs one GPU per rank
+            run = (lambda: filt.run_series_native(y)) if native else (lambda: filt.run_series(y))
 
     for _ in range(args.warmup):
         run()
@@ -273,6 +276,9 @@ def main():
         lme = ll                                                  # one filter: identical on every rank
         psteps_per_pass = float(n) * T
 
+    short_ll = None
+    if args.mode == "sharded" and not args.lw:
+        short_ll = filt.run_series_native(y[:12]) if native else filt.run_series(y[:12])       # every rank takes part
     if rank == 0:
         value = psteps_per_pass * args.steps / dt
         if args.lw:
@@ -325,7 +331,25 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "sharded step (kernels + all_gather + tile exchange)", "achieved": achieved,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                "includes_exchange": True, "algorithmic_bytes_per_rank_step": bpp * (n / world),
-                               "mean_step_us": step_us, "exchanged_tiles_last_pass_rank0": int(filt.exchanged_tiles)}
+                               "mean_step_us": step_us}
+            if not args.lw:
+                if native:
+                    _, _, path, exch = filt.native_state()
+                    out["config"]["driver"] = "C++ over RCCL (ssme_pf_shard_run_series)"
+                    out["roofline"]["path_last_pass"] = {1: "fixed halo, no host sync in the time loop", 2: "exact (host-planned) exchange"}.get(path, path)
+                    out["roofline"]["tiles_received_last_pass_rank0"] = int(exch)
+                else:
+                    out["config"]["driver"] = "Python over torch.distributed"
+                    out["roofline"]["tiles_received_last_pass_rank0"] = int(filt.exchanged_tiles)
+                # the sharded filter must reproduce the unsharded oracle bit for bit: first 12 steps at full N
+                from oracle import oracle as O
+                lo = O.Filter(O.MODEL_SVOL, n, THETA, SEED, rep=0, resampler=args.resampler, tile=2048).run_series(y[:12])[0]
+                out["loglik_delta_vs_oracle"] = {"abs_delta": abs(short_ll - lo), "gpu": short_ll, "oracle": lo,
+                                                 "sample": "first 12 steps, full N, oracle Philox mode (bit-matched), unsharded oracle"}
+            else:
+                out["config"]["driver"] = "Python over torch.distributed"
+                out["roofline"]["tiles_received_last_pass_rank0"] = int(filt.exchanged_tiles)
+                lo = None
         if not args.no_cpu_baseline and world == 1 and args.mode == "replicas":
             out["cpu_baseline"] = cpu_baseline(np.loadtxt(os.path.join(ROOT, "tests", "golden", "spy_returns.csv")), args.cpu_steps)
         print(json.dumps(out), flush=True)
