@@ -18,7 +18,8 @@
 //   k_lw_mid    : one block per filter: theta-bar, V, Cholesky factor of (1 - a^2) V; log-sum-exp of stage 1
 //   k_lw_stage2 : k ~ Categorical(first-stage weights) (cdf A) -> shrink + jitter theta -> fSamp ->
 //                 second-stage weight -> cdf B
-// Layout: x[R][Npad], theta[R][4][Npad] (transformed space, structure of arrays), fp64.
+// Layout: x[R][Npad] fp64; theta[R][Npad][4] (transformed space): ONE 32-byte record per particle, so that the resampling
+// gather of a particle's parameters is one 32-byte access instead of four scattered 8-byte ones.
 #pragma once
 #include "pf_kernels.h"
 
@@ -63,9 +64,8 @@ struct LwArgs {
     int32_t resamp_sched;                       // m_rs: resample when (t + 1) % m_rs == 0
     // particle-sharded filter (all zero / Npad otherwise): this launch computes tiles tile0 .. tile0 + gridDim.x - 1 and
     // stores them at local offsets; the arrays a stage READS (stage 1: xB, thB, cdfB; stage 2: xr, thr, lw1, cdfA) are
-    // windows starting at tile win_tile0 with parameter planes th_src_stride apart; written planes are th_dst_stride apart
+    // windows starting at tile win_tile0 (the parameter records travel with their particles: [tiles][2048][4])
     int32_t tile0, win_tile0;
-    int64_t th_src_stride, th_dst_stride;
     // split level-2 (k_level2_plan; filters of more than 2048 tiles or by policy): per draw T', A/A', source ranges, (m, S)
     const double *l2B_T, *l2B_R, *l2A_T, *l2A_R;      // [R][Bs]
     const int32_t *l2B_lo, *l2B_hi, *l2A_lo, *l2A_hi;
@@ -94,6 +94,17 @@ __device__ __forceinline__ double tr_fwd(int kind, double p) {
         case TR_LOGIT: return dlog(p) - dlog(1.0 - p);
         default: return dlog(p);
     }
+}
+// theta records: [Npad][4] doubles per filter; a pair of particles is 64 contiguous bytes
+__device__ __forceinline__ void th_load(const double* th, size_t idx, double (&t)[kDP]) {
+    const double2* p = reinterpret_cast<const double2*>(th + idx * kDP);
+    const double2 a = p[0], b = p[1];
+    t[0] = a.x; t[1] = a.y; t[2] = b.x; t[3] = b.y;
+}
+__device__ __forceinline__ void th_store_pair(double* th, size_t idx0, const double (&t)[kDP][2]) {
+    double2* p = reinterpret_cast<double2*>(th + idx0 * kDP);
+    p[0] = make_double2(t[0][0], t[1][0]); p[1] = make_double2(t[2][0], t[3][0]);
+    p[2] = make_double2(t[0][1], t[1][1]); p[3] = make_double2(t[2][1], t[3][1]);
 }
 // model callbacks of svol_lw_1_par
 __device__ __forceinline__ double lw_logg(double y, double x) {                // test_liu_west.cpp:132-136, kernel form
@@ -371,9 +382,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_init(const LwArgs a) {
         }
         *reinterpret_cast<double2*>(a.xB + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
         if (a.lwB) *reinterpret_cast<double2*>(a.lwB + rowoff + (i0 - out0)) = make_double2(lg[k][0], lg[k][1]);
-#pragma unroll
-        for (int d = 0; d < kDP; ++d)
-            *reinterpret_cast<double2*>(a.thB + ((size_t)r * kDP + d) * a.th_dst_stride + (i0 - out0)) = make_double2(tho[d][0], tho[d][1]);
+        th_store_pair(a.thB, rowoff + (size_t)(i0 - out0), tho);
     }
     lw_store_cdf(lg, a.N, i_first, a.cdfB + rowoff, a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, a.tile0);
 }
@@ -443,8 +452,12 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
         for (int c = 0; c < 2; ++c) {
             const int j = anc[k][c];
             xo[c] = xB[j - win0];
+            {
+                double trec[kDP];
+                th_load(a.thB, rowoff + (size_t)(j - win0), trec);
 #pragma unroll
-            for (int d = 0; d < kDP; ++d) tt[d][c] = a.thB[((size_t)r * kDP + d) * a.th_src_stride + (j - win0)];
+                for (int d = 0; d < kDP; ++d) tt[d][c] = trec[d];
+            }
             if (a.anc && i0 + c < a.N) a.anc[rowoff + (i0 - out0) + c] = (uint32_t)j;
         }
 #pragma unroll
@@ -472,9 +485,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
         }
         *reinterpret_cast<double2*>(a.xr + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
         *reinterpret_cast<double2*>(a.lw1 + rowoff + (i0 - out0)) = make_double2(g1[0], g1[1]);
-#pragma unroll
-        for (int d = 0; d < kDP; ++d)
-            *reinterpret_cast<double2*>(a.thr + ((size_t)r * kDP + d) * a.th_dst_stride + (i0 - out0)) = make_double2(tt[d][0], tt[d][1]);
+        th_store_pair(a.thr, rowoff + (size_t)(i0 - out0), tt);
     }
     // wave tree per 128-element segment of the folded half tile, then the 8 segments in order
 #pragma unroll
@@ -636,11 +647,12 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
                 dsincos2pi(u01_co(o2.v2, o2.v3), &sn, &cs);
                 e[2] = rad2 * cs; e[3] = rad2 * sn;
             }
-            double tu[kDP];
+            double tu[kDP], thrk[kDP];
+            th_load(a.thr, rowoff + (size_t)(j - win0), thrk);
             int q = kDP;
 #pragma unroll
             for (int d = 0; d < kDP; ++d) {
-                const double thk = a.thr[((size_t)r * kDP + d) * a.th_src_stride + (j - win0)];
+                const double thk = thrk[d];
                 const double mm = a.a_shrink * thk + (1.0 - a.a_shrink) * prop[d];      // :1024
                 double acc = 0.0;
 #pragma unroll
@@ -658,9 +670,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
         }
         *reinterpret_cast<double2*>(a.xB + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
         if (a.lwB) *reinterpret_cast<double2*>(a.lwB + rowoff + (i0 - out0)) = make_double2(lg[k][0], lg[k][1]);
-#pragma unroll
-        for (int d = 0; d < kDP; ++d)
-            *reinterpret_cast<double2*>(a.thB + ((size_t)r * kDP + d) * a.th_dst_stride + (i0 - out0)) = make_double2(tho[d][0], tho[d][1]);
+        th_store_pair(a.thB, rowoff + (size_t)(i0 - out0), tho);
     }
     lw_store_cdf(lg, a.N, i_first, a.cdfB + rowoff, a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, a.tile0);
 }
@@ -714,7 +724,9 @@ __global__ __launch_bounds__(kThreads) void k_lw_param_partials(const LwArgs a) 
         const double w = (c1 - c0) * scale;
         const double xv = a.xB[(size_t)r * a.Npad + i];
         acc[kDP] += w;
-        for (int d = 0; d < kDP; ++d) acc[d] += w * tr_inv(a.trans[d], a.thB[((size_t)r * kDP + d) * a.Npad + i]);
+        double trec[kDP];
+        th_load(a.thB, (size_t)r * a.Npad + i, trec);
+        for (int d = 0; d < kDP; ++d) acc[d] += w * tr_inv(a.trans[d], trec[d]);
         acc[5] += w * xv;
         acc[6] += w * (xv * xv);
         acc[7] += w * dexp(0.5 * xv);
@@ -754,7 +766,9 @@ __global__ __launch_bounds__(kThreads) void k_lw_weights(const LwArgs a, int r, 
         const double c1 = a.cdfB[(size_t)r * a.Npad + i];
         const double c0 = j ? a.cdfB[(size_t)r * a.Npad + i - 1] : 0.0;
         out[i] = (c1 - c0) * sc;
-        for (int d = 0; d < kDP; ++d) out[(size_t)(1 + d) * a.Npad + i] = tr_inv(a.trans[d], a.thB[((size_t)r * kDP + d) * a.Npad + i]);
+        double trec[kDP];
+        th_load(a.thB, (size_t)r * a.Npad + i, trec);
+        for (int d = 0; d < kDP; ++d) out[(size_t)(1 + d) * a.Npad + i] = tr_inv(a.trans[d], trec[d]);
     }
 }
 

@@ -555,14 +555,17 @@ static StepArgs shard_args(ssme_pf_handle h, int t, const double* tsum_all, cons
 
 // the plan of step t on the device: every rank's window into h->plan_dev (up to 512 tiles) or every tile's range into
 // l2_lo / l2_hi (split level-2, which also accounts log p(y_{t-1} | .))
-static void shard_plan_device(ssme_pf_handle h, int t, const double* tsum_all, const double* tmax_all) {
+static void shard_plan_device(ssme_pf_handle h, int t, const double* tsum_all, const double* tmax_all, int margin = 0,
+                              int32_t* flag = nullptr) {
     StepArgs a = shard_args(h, t, tsum_all, tmax_all);
     if (h->split_l2) {
         a.finalize_prev = 1;
         hipLaunchKernelGGL(k_level2_plan, dim3(1), dim3(1024), h->lds_bytes_plan, h->stream, a, 1);
+        if (flag) hipLaunchKernelGGL(k_shard_window_check, dim3(1), dim3(64), 0, h->stream, (const int32_t*)nullptr, (const int32_t*)h->l2_lo,
+                                     (const int32_t*)h->l2_hi, h->shard_world, h->B / h->shard_world, margin, flag, flag + 1);
     } else {
         hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(512), sizeof(double) * (h->Bpow2 < 2 ? 2 : h->Bpow2), h->stream, a,
-                           h->shard_world, h->plan_dev);
+                           h->shard_world, h->plan_dev, margin, flag);
     }
 }
 
@@ -687,11 +690,13 @@ static int shard_alloc(ssme_pf_handle h, bool exact) {
     return SSME_OK;
 }
 
+// tile sums and tile maxima of all ranks, each straight into its final [B] array: two all-gathers in one group (one launch)
 static int shard_gather(ssme_pf_handle h, ncclComm_t comm) {
     const int world = h->shard_world, Bl = h->B / world;
-    NCCLCHK(rccl().AllGather(h->sh_loc, h->sh_raw, (size_t)2 * Bl, ncclDouble, comm, h->stream));
-    hipLaunchKernelGGL(k_shard_repack, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, (const double*)h->sh_raw, world, Bl, h->sh_tsum, h->sh_tmax);
-    HIPCHK(hipGetLastError());
+    NCCLCHK(rccl().GroupStart());
+    NCCLCHK(rccl().AllGather(h->sh_loc, h->sh_tsum, (size_t)Bl, ncclDouble, comm, h->stream));
+    NCCLCHK(rccl().AllGather(h->sh_loc + Bl, h->sh_tmax, (size_t)Bl, ncclDouble, comm, h->stream));
+    NCCLCHK(rccl().GroupEnd());
     return SSME_OK;
 }
 
@@ -714,9 +719,7 @@ static int shard_series(ssme_pf_handle h, ncclComm_t comm, const double* y, cons
             rc = shard_gather(h, comm);
             if (rc != SSME_OK) return rc;
             if (fast) {
-                shard_plan_device(h, t, h->sh_tsum, h->sh_tmax);
-                hipLaunchKernelGGL(k_shard_window_check, dim3(1), dim3(64), 0, h->stream, h->split_l2 ? (const int32_t*)nullptr : (const int32_t*)h->plan_dev,
-                                   (const int32_t*)h->l2_lo, (const int32_t*)h->l2_hi, world, Bl, m, h->sh_flag, h->sh_flag + 1);
+                shard_plan_device(h, t, h->sh_tsum, h->sh_tmax, m, h->sh_flag);       // plan + "does every window fit its halo?"
                 HIPCHK(hipGetLastError());
                 if (world > 1) {
                     // fixed halo: my first m tiles are the left neighbour's right halo, my last m tiles the right neighbour's left halo
@@ -1429,7 +1432,7 @@ static LwArgs lw_args(ssme_lw_handle h) {
     a.key0 = (uint32_t)h->cfg.seed; a.key1 = (uint32_t)(h->cfg.seed >> 32); a.first_filter = h->cfg.first_filter_id;
     a.logN = dlog((double)h->N);
     a.a_shrink = (3.0 * h->cfg.delta - 1.0) / (2.0 * h->cfg.delta);          // liu_west_filter.h:960
-    a.tile0 = 0; a.win_tile0 = 0; a.th_src_stride = h->Npad; a.th_dst_stride = h->Npad;
+    a.tile0 = 0; a.win_tile0 = 0;
     a.l2B_T = h->l2T[0]; a.l2B_R = h->l2R[0]; a.l2B_lo = h->l2lo[0]; a.l2B_hi = h->l2hi[0]; a.l2B_s = h->l2s[0];
     a.l2A_T = h->l2T[1]; a.l2A_R = h->l2R[1]; a.l2A_lo = h->l2lo[1]; a.l2A_hi = h->l2hi[1]; a.l2A_s = h->l2s[1];
     for (int d = 0; d < kDP; ++d) { a.trans[d] = h->cfg.transforms[d]; a.lo[d] = h->cfg.prior_lo[d]; a.hi[d] = h->cfg.prior_hi[d]; }
@@ -1698,7 +1701,6 @@ static LwArgs lw_shard_args(ssme_lw_handle h, int t) {
     a.t = t; a.yi = t; a.gi = t; a.finalize_prev = t > 1 || t == 1 ? 1 : 0;
     a.per_step = h->per_step;
     a.tile0 = h->shard_rank * Bl;
-    a.th_dst_stride = (int64_t)h->th_plane_tiles * kTile;
     a.anc = nullptr; a.kidx = nullptr;
     return a;
 }
@@ -1760,7 +1762,7 @@ int ssme_lw_shard_stage1(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t
     LwArgs a = lw_shard_args(h, t);
     a.xB = const_cast<double*>(w_xB); a.thB = const_cast<double*>(w_thB); a.cdfB = const_cast<double*>(w_cdfB);
     a.tsumB = const_cast<double*>(tsumB_all); a.tmaxB = const_cast<double*>(tmaxB_all);
-    a.win_tile0 = win_tile0; a.th_src_stride = (int64_t)win_tiles * kTile;
+    a.win_tile0 = win_tile0; (void)win_tiles;
     a.xr = xr; a.thr = thr; a.lw1 = lw1; a.cdfA = cdfA; a.tsumA = tsumA; a.tmaxA = tmaxA; a.mom = mom;
     a.anc = anc;
     if (h->split_l2) hipLaunchKernelGGL(k_lw_stage1<true>, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes_big, h->stream, a);
@@ -1793,7 +1795,7 @@ int ssme_lw_shard_stage2(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t
     LwArgs a = lw_shard_args(h, t);
     a.xr = const_cast<double*>(w_xr); a.thr = const_cast<double*>(w_thr); a.lw1 = const_cast<double*>(w_lw1);
     a.cdfA = const_cast<double*>(w_cdfA); a.tsumA = const_cast<double*>(tsumA_all); a.tmaxA = const_cast<double*>(tmaxA_all);
-    a.win_tile0 = win_tile0; a.th_src_stride = (int64_t)win_tiles * kTile;
+    a.win_tile0 = win_tile0; (void)win_tiles;
     a.xB = xB; a.thB = thB; a.cdfB = cdfB; a.tsumB = tsumB; a.tmaxB = tmaxB;
     a.kidx = kidx;
     if (h->split_l2) hipLaunchKernelGGL(k_lw_stage2<true>, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes_big, h->stream, a);
@@ -1978,8 +1980,11 @@ int ssme_lw_download_state(ssme_lw_handle h, int32_t f, double* x, double* theta
     LWCHK(hipSetDevice(h->cfg.device));
     const size_t off = (size_t)f * h->Npad;
     if (x) LWCHK(hipMemcpyAsync(x, h->xB + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
-    if (theta) for (int d = 0; d < kDP; ++d)
-        LWCHK(hipMemcpyAsync(theta + (size_t)d * h->N, h->thB + ((size_t)f * kDP + d) * h->Npad, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> rec;                       // the device keeps one [4]-record per particle; callers get parameter planes
+    if (theta) {
+        rec.resize((size_t)h->N * kDP);
+        LWCHK(hipMemcpyAsync(rec.data(), h->thB + (size_t)f * h->Npad * kDP, sizeof(double) * rec.size(), hipMemcpyDeviceToHost, h->stream));
+    }
     if (kidx || anc) {
         if (!h->anc) return SSME_ERR_STATE;
         if (kidx) LWCHK(hipMemcpyAsync(kidx, h->kidx + off, sizeof(uint32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
@@ -1988,6 +1993,7 @@ int ssme_lw_download_state(ssme_lw_handle h, int32_t f, double* x, double* theta
     double p[16];
     LWCHK(hipMemcpyAsync(p, h->prop + (size_t)f * 16, sizeof(p), hipMemcpyDeviceToHost, h->stream));
     LWCHK(hipStreamSynchronize(h->stream));
+    if (theta) for (int i = 0; i < h->N; ++i) for (int d = 0; d < kDP; ++d) theta[(size_t)d * h->N + i] = rec[(size_t)i * kDP + d];
     if (thetabar) for (int d = 0; d < kDP; ++d) thetabar[d] = p[d];
     if (chol) { int q = kDP; for (int d = 0; d < kDP; ++d) for (int e = 0; e < kDP; ++e) chol[d * kDP + e] = (e <= d) ? p[q++] : 0.0; }
     return SSME_OK;

@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(1024) void k_level2_plan(const StepArgs a, int plan
 // Runs the same level-2 and the same target bounds as k_filter_step, so the ranges are exact.
 // grid = 1, block = 512, dynamic LDS = max(Bpow2, 2) doubles.  lo_hi: [world][2] ints.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_shard_plan(const StepArgs a, int world, int32_t* lo_hi) {
+__global__ __launch_bounds__(512) void k_shard_plan(const StepArgs a, int world, int32_t* lo_hi, int margin = 0, int32_t* flag = nullptr) {
     constexpr int NT = 512, NE = 2048 / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_plan[];
     double* lds_T = reinterpret_cast<double*>(smem_plan);
@@ -1077,6 +1077,14 @@ __global__ __launch_bounds__(512) void k_shard_plan(const StepArgs a, int world,
         }
         lo_hi[2 * tid] = lo;
         lo_hi[2 * tid + 1] = hi;
+        if (flag) {
+            // C++ shard driver: does this rank's window stay inside its fixed halo?  flag[0]: some window left it;
+            // flag[1] / flag[2]: widest reach left / right of the own tiles seen so far
+            const int left = bF - lo, right = hi - bL;
+            if (left > margin || right > margin) atomicOr(&flag[0], 1);
+            if (left > 0) atomicMax(&flag[1], left);
+            if (right > 0) atomicMax(&flag[2], right);
+        }
     }
 }
 

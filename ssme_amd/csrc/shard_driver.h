@@ -4,9 +4,9 @@
 // extern-"C" ABI ... one RCCL [collective] over xGMI per time step for the global log-weight sum and an all-to-all for
 // particle redistribution".  One process per GPU; rank g owns B/world consecutive 2048-particle tiles.  Per time step,
 // everything on ONE HIP stream and -- on the fast path -- without any host synchronisation:
-//     ncclAllGather of the tile sums / maxima (16 bytes per tile)  ->  k_shard_repack
-//     k_shard_plan / k_level2_plan: every rank's source-tile window [lo, hi]; k_shard_window_check raises a device flag
-//         if a window leaves the fixed halo
+//     two grouped ncclAllGather (tile sums, tile maxima: 16 bytes per tile), each straight into its final array
+//     k_shard_plan (or k_level2_plan + k_shard_window_check above 512 tiles): every rank's source-tile window [lo, hi] and
+//         a device flag if a window leaves the fixed halo
 //     grouped ncclSend / ncclRecv of the halo tiles (integer cdf + particles) with the two neighbouring ranks
 //     k_filter_step on the rank's tiles, reading its window in place from the halo buffer
 // The flag is read once, after the series: if a window ever left the halo (very unbalanced weights), the series is run
@@ -59,15 +59,6 @@ static const RcclApi& rccl() {
         return a;
     }();
     return api;
-}
-
-// gathered [world][2][Bl] (rank g: its Bl tile sums, then its Bl tile maxima) -> tsum_all[B], tmax_all[B]
-__global__ void k_shard_repack(const double* raw, int world, int Bl, double* tsum_all, double* tmax_all) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= world * Bl) return;
-    const int g = j / Bl, i = j - g * Bl;
-    tsum_all[j] = raw[(size_t)g * 2 * Bl + i];
-    tmax_all[j] = raw[(size_t)g * 2 * Bl + Bl + i];
 }
 
 // Does every rank's window [lo, hi] stay inside [first own tile - margin, last own tile + margin]?  lo_hi: [world][2]

@@ -374,15 +374,13 @@ class ShardedLiuWest:
         f64 = dict(dtype=torch.float64, device=self.device)
         Bl = self.Bl
         margin = min(self.B - Bl, max(2, Bl // 2)) if self.world > 1 else 0
-        self._rows = Bl + 2 * margin                                   # rows per theta plane, halos included
-        self._chk(capi.lib().ssme_lw_shard_set_plane_tiles(self._h, self._rows))
+        self._rows = Bl + 2 * margin
         mk = lambda: HaloBuffer(Bl, TILE, margin, self.device, torch.float64)
-        # stage-2 outputs / stage-1 sources, and stage-1 outputs / stage-2 sources; theta: 4 planes in one tensor
+        # stage-2 outputs / stage-1 sources, and stage-1 outputs / stage-2 sources; theta: one 32-byte record per particle,
+        # i.e. rows of 2048 x 4 doubles that travel with their tile
         self.xB, self.cdfB, self.xr, self.lw1, self.cdfA = mk(), mk(), mk(), mk(), mk()
-        self._thB4 = torch.zeros((4, self._rows, TILE), **f64)
-        self._thr4 = torch.zeros((4, self._rows, TILE), **f64)
-        self.thB = [HaloBuffer(Bl, TILE, margin, self.device, torch.float64, storage=self._thB4[d]) for d in range(4)]
-        self.thr = [HaloBuffer(Bl, TILE, margin, self.device, torch.float64, storage=self._thr4[d]) for d in range(4)]
+        self.thB = HaloBuffer(Bl, TILE * 4, margin, self.device, torch.float64)
+        self.thr = HaloBuffer(Bl, TILE * 4, margin, self.device, torch.float64)
         self.tilesB = torch.zeros((2, Bl), **f64)            # rows: tile sums, tile maxima (second-stage weights)
         self._locA = torch.zeros(18 * Bl, **f64)             # stage-1 outputs in one buffer: tile sums | tile maxima | 16 moments per tile
         self.tilesA = self._locA[:2 * Bl].view(2, Bl)
@@ -424,24 +422,24 @@ class ShardedLiuWest:
         self.allA[1].view(self.world, Bl).copy_(G[:, Bl:2 * Bl])
         self.mom_all.view(self.world, Bl * 16).copy_(G[:, 2 * Bl:])
 
-    def _windows(self, which, t, tiles_all, halos2d, halos4):
-        """plan + exchange for one draw.  Returns (win_tile0, theta rows per source plane, [2-D source windows], theta source
-        window (pointer to plane 0)).  Own tiles stay where they are; only halo tiles travel."""
+    def _windows(self, which, t, tiles_all, halos2d, halo_th):
+        """plan + exchange for one draw.  Returns (win_tile0, window tiles, [2-D source windows], theta source window).
+        Own tiles stay where they are; only halo tiles travel."""
         import torch
         lo_hi = (C.c_int32 * (2 * self.world))()
         self._chk(capi.lib().ssme_lw_shard_plan(self._h, which, t, self._ptr(tiles_all[0]), self._ptr(tiles_all[1]), lo_hi))
         plan = [(lo_hi[2 * g], lo_hi[2 * g + 1]) for g in range(self.world)]
         lo_r, hi_r = plan[self.rank]
         self.exchanged_tiles += max(0, min(hi_r + 1, self.tile0) - lo_r) + max(0, hi_r - max(lo_r - 1, self.tile0 + self.Bl - 1))
-        got = exchange_halos(halos2d + halos4, self.tile0, plan, self.Bl, self.rank, self.group, self.stage)
+        got = exchange_halos(halos2d + [halo_th], self.tile0, plan, self.Bl, self.rank, self.group, self.stage)
         if got is not None:
             w0, wt = got
-            return w0, self._rows, [hb.rows(w0, wt, self.tile0) for hb in halos2d], halos4[0].rows(w0, wt, self.tile0)
+            return w0, wt, [hb.rows(w0, wt, self.tile0) for hb in halos2d], halo_th.rows(w0, wt, self.tile0)
         sends, recvs = exchange_plan(plan, self.Bl, self.rank)             # window wider than the margins: assemble it
         wins = [exchange_tiles(hb.own(), self.tile0, sends, recvs, self.rank, self.group, self.stage) for hb in halos2d]
-        w4 = torch.stack([exchange_tiles(hb.own(), self.tile0, sends, recvs, self.rank, self.group, self.stage) for hb in halos4])
-        self._keep = w4                                                    # keep the assembled window alive until the launch
-        return lo_r, hi_r - lo_r + 1, wins, w4
+        wth = exchange_tiles(halo_th.own(), self.tile0, sends, recvs, self.rank, self.group, self.stage)
+        self._keep = (wins, wth)                                           # keep the assembled windows alive until the launch
+        return lo_r, hi_r - lo_r + 1, wins, wth
 
     def run_series(self, y, z=None):
         import torch
@@ -456,7 +454,7 @@ class ShardedLiuWest:
         T = yv.size
         self._chk(L.ssme_lw_shard_prepare(self._h, capi.dptr(yv), capi.dptr(zv), T))
         self.exchanged_tiles = 0
-        thB_own, thr_own = p(self.thB[0].own()), p(self.thr[0].own())       # plane 0 of the own rows; planes are _rows apart
+        thB_own, thr_own = p(self.thB.own()), p(self.thr.own())
         self._chk(L.ssme_lw_shard_init(self._h, p(self.xB.own()), thB_own, p(self.cdfB.own()), p(self.tilesB[0]), p(self.tilesB[1])))
         for t in range(1, T):
             self._gather_B()
@@ -487,4 +485,5 @@ class ShardedLiuWest:
         return self.xB.own().reshape(-1).cpu().numpy()
 
     def local_theta(self):
-        return np.stack([hb.own().reshape(-1).cpu().numpy() for hb in self.thB])
+        """[4, N / world]: transformed parameters of this rank's particles (the device keeps [particle][4] records)."""
+        return self.thB.own().reshape(-1, 4).t().contiguous().cpu().numpy()
