@@ -200,6 +200,12 @@ def main():
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to run\n")
         sys.exit(2)
 
+    # stdout carries ONE JSON line and nothing else: libraries that print banners on fd 1 (RCCL's version block) are sent
+    # to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     n = args.particles or (N_PARTICLES_LW if args.lw else N_PARTICLES)
     # --- in-run HBM traffic of the dominant kernel (rank 0 at N = 1 only), before this process initialises the GPU ---
     traffic, traffic_note = None, "measured at --gpus 1, replicas mode, default N only"
@@ -352,7 +358,8 @@ def main():
                 lo = None
         if not args.no_cpu_baseline and world == 1 and args.mode == "replicas":
             out["cpu_baseline"] = cpu_baseline(np.loadtxt(os.path.join(ROOT, "tests", "golden", "spy_returns.csv")), args.cpu_steps)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     (bank if args.mode == "replicas" else filt).close()
     if dist.is_initialized():
         dist.barrier(device_ids=[dev_index]) if not rehearse else dist.barrier()
