@@ -255,7 +255,8 @@ def main():
         from ssme_amd import sharded
         if args.lw:
             filt = sharded.ShardedLiuWest(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, seed=SEED)
-            run = lambda: filt.run_series(y, z)
+            native = args.driver == "native" and not rehearse       # RCCL needs one GPU per rank
+            run = (lambda: filt.run_series_native(y, z)) if native else (lambda: filt.run_series(y, z))
         else:
             filt = sharded.ShardedParticleFilter(ssme_amd.MODEL_SVOL, n, SEED, args.resampler)
             filt.set_params(THETA)
@@ -353,9 +354,8 @@ def main():
                 out["loglik_delta_vs_oracle"] = {"abs_delta": abs(short_ll - lo), "gpu": short_ll, "oracle": lo,
                                                  "sample": "first 12 steps, full N, oracle Philox mode (bit-matched), unsharded oracle"}
             else:
-                out["config"]["driver"] = "Python over torch.distributed"
-                out["roofline"]["tiles_received_last_pass_rank0"] = int(filt.exchanged_tiles)
-                lo = None
+                out["config"]["driver"] = ("C++ over RCCL (ssme_lw_shard_run_series): " + getattr(filt, "native_path", "?")) if native else "Python over torch.distributed"
+                out["roofline"]["tiles_received_last_pass_rank0"] = int(filt.native_state()[2] if native else filt.exchanged_tiles)
         if not args.no_cpu_baseline and world == 1 and args.mode == "replicas":
             out["cpu_baseline"] = cpu_baseline(np.loadtxt(os.path.join(ROOT, "tests", "golden", "spy_returns.csv")), args.cpu_steps)
         sys.stdout.flush()

@@ -319,6 +319,13 @@ int ssme_lw_shard_stage2(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t
                          double* thB, double* cdfB, double* tsumB, double* tmaxB, uint32_t* kidx);
 /* accounts the last step t from its gathered second-stage tile sums; then ssme_lw_get_loglik / get_per_step */
 int ssme_lw_shard_finalize(ssme_lw_handle h, int32_t t, const double* tsumB_all, const double* tmaxB_all);
+/* The same loop in C++ over RCCL (see ssme_pf_shard_run_series; comm from ssme_shard_comm_init or the caller's own
+ * ncclComm_t): fixed-halo exchange with the two neighbouring ranks, no host synchronisation inside the time loop.  The
+ * stage kernels verify their own source tiles against the exchanged window; if one ever left it the call returns
+ * SSME_ERR_STATE and the caller runs the exact host-planned loop over the step-wise entry points above.  loglik_out: 1. */
+int ssme_lw_shard_run_series(ssme_lw_handle h, void* nccl_comm, const double* y, const double* z, int32_t T, double* loglik_out);
+/* after ssme_lw_shard_run_series: this rank's N / world particles, transformed parameters theta[d * n + i], tiles received */
+int ssme_lw_shard_download(ssme_lw_handle h, double* x_local, double* theta_local, int64_t* exchanged_tiles);
 int ssme_lw_get_loglik(ssme_lw_handle h, double* out);
 
 

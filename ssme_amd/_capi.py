@@ -33,7 +33,7 @@ EXPORTS = [
     "ssme_lw_get_param_means", "ssme_lw_get_expectations", "ssme_lw_download_weights", "ssme_lw_download_state", "ssme_lw_set_debug", "ssme_lw_last_elapsed_ms",
     "ssme_lw_last_error",
     "ssme_lw_shard_create", "ssme_lw_set_stream", "ssme_lw_shard_set_plane_tiles", "ssme_lw_shard_prepare", "ssme_lw_shard_init", "ssme_lw_shard_plan",
-    "ssme_lw_shard_stage1", "ssme_lw_shard_mid", "ssme_lw_shard_stage2", "ssme_lw_shard_finalize", "ssme_lw_get_loglik",
+    "ssme_lw_shard_stage1", "ssme_lw_shard_mid", "ssme_lw_shard_stage2", "ssme_lw_shard_finalize", "ssme_lw_get_loglik", "ssme_lw_shard_run_series", "ssme_lw_shard_download",
 ]
 
 
@@ -151,6 +151,8 @@ def lib():
         L.ssme_lw_shard_stage2.argtypes = [H, C.c_int32, C.c_int32, C.c_int32] + [vp] * 12
         L.ssme_lw_shard_finalize.argtypes = [H, C.c_int32, vp, vp]
         L.ssme_lw_get_loglik.argtypes = [H, dp]
+        L.ssme_lw_shard_run_series.argtypes = [H, vp, dp, dp, C.c_int32, dp]
+        L.ssme_lw_shard_download.argtypes = [H, dp, dp, C.POINTER(C.c_int64)]
         L.ssme_lw_last_error.restype = C.c_char_p
         L.ssme_lw_last_error.argtypes = [H]
         L.ssme_pf_strerror.restype = C.c_char_p

@@ -66,6 +66,8 @@ struct LwArgs {
     // stores them at local offsets; the arrays a stage READS (stage 1: xB, thB, cdfB; stage 2: xr, thr, lw1, cdfA) are
     // windows starting at tile win_tile0 (the parameter records travel with their particles: [tiles][2048][4])
     int32_t tile0, win_tile0;
+    int32_t win_tiles;                          // C++ shard driver, fixed-halo path: tiles held in the source windows (0: unchecked)
+    int32_t* win_flag;                          // ... and where to record that an output tile's sources left them, or null
     // split level-2 (k_level2_plan; filters of more than 2048 tiles or by policy): per draw T', A/A', source ranges, (m, S)
     const double *l2B_T, *l2B_R, *l2A_T, *l2A_R;      // [R][Bs]
     const int32_t *l2B_lo, *l2B_hi, *l2A_lo, *l2A_hi;
@@ -136,7 +138,8 @@ template <bool BIG>
 __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax, const double* cdf, int B, int Bpow2, int rshift,
                                           int N, int b, double gam, double pgam, double pgam_next, double G, int spacing_stream,
                                           uint32_t t, uint32_t rep, uint32_t k0, uint32_t k1, const LwLds& L, int (&idx)[2][2],
-                                          double& m_out, double& S_out, int win_tile0, const L2View& v) {
+                                          double& m_out, double& S_out, int win_tile0, const L2View& v, int win_tiles = 0,
+                                          int32_t* win_flag = nullptr) {
     constexpr int NT = kLwNT, NK = 2, NE = 4;
     const int tid = threadIdx.x;
     const int i_first = b * kTile;
@@ -175,8 +178,17 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
     }
     lo = lo < B - 1 ? lo : B - 1;
     hi = hi < B - 1 ? hi : B - 1;
-    const int bb_min = __builtin_amdgcn_readfirstlane(lo);
-    const int span = __builtin_amdgcn_readfirstlane(hi) - bb_min + 1;
+    int bb_min = __builtin_amdgcn_readfirstlane(lo);
+    int span = __builtin_amdgcn_readfirstlane(hi) - bb_min + 1;
+    if (win_flag) {
+        // fixed-halo sharding (see k_filter_step): sources outside the exchanged window are reported; this launch stays in bounds
+        const int first = win_tile0 > 0 ? win_tile0 : 0, last = win_tile0 + win_tiles - 1 < B - 1 ? win_tile0 + win_tiles - 1 : B - 1;
+        if (bb_min < first || bb_min + span - 1 > last) {
+            if (tid == 0) atomicOr(win_flag, 1);
+            bb_min = bb_min < first ? first : (bb_min > last ? last : bb_min);
+            span = 1;
+        }
+    }
     double2 stg0[NK], stg1[NK], stg2[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) { stg0[k] = make_double2(0.0, 0.0); stg1[k] = stg0[k]; stg2[k] = stg0[k]; }
@@ -421,7 +433,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
     if (resampled) {
         lw_select<BIG>(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.cdfB + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
                        a.gamB[gidx], a.pgamB[gidx], pgam_next, G, STREAM_RESAMP, (uint32_t)a.t, rep, a.key0, a.key1, L, anc, mB, SB,
-                       a.win_tile0, vB);
+                       a.win_tile0, vB, a.win_tiles, a.win_flag);
     } else {
         lw_level2_only<BIG>(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.B, a.rshift, L, mB, SB, vB);
 #pragma unroll
@@ -614,7 +626,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
     if (a.form == 0) {
         lw_select<BIG>(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.cdfA + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
                        a.gamA[gidx], a.pgamA[gidx], pgam_next, G, STREAM_LW_K, (uint32_t)a.t, rep, a.key0, a.key1, L, kk, mA, SA,
-                       a.win_tile0, vA);
+                       a.win_tile0, vA, a.win_tiles, a.win_flag);
     } else {
 #pragma unroll
         for (int k = 0; k < NK; ++k) {

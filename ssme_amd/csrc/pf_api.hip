@@ -47,6 +47,7 @@ struct ssme_pf_s {
     double *sh_x[2], *sh_c[2], *sh_loc, *sh_raw, *sh_tsum, *sh_tmax, *sh_winx, *sh_winc;
     int32_t* sh_flag;        // [0] a window left the halo, [1] / [2] widest reach left / right of the own tiles (in tiles)
     int sh_margin, sh_rows, sh_path;   // sh_path: path of the last native series (1 fixed halo, 2 exact)
+    int sh_check;            // 1 while the driver's fixed-halo path launches a step: the kernel verifies its source tiles
     long sh_exchanged;       // tiles received from other ranks during the last native series
     hipStream_t stream;
     hipEvent_t ev0, ev1;
@@ -155,6 +156,8 @@ static StepArgs step_args(ssme_pf_handle h) {
         // two 512-thread workgroups fit a CU (LDS): is the whole grid resident at once?
         const long blocks = (long)(h->shard_world > 0 ? h->B / h->shard_world : h->B) * h->R;
         a.prio_mode = (blocks <= 2L * h->num_cus) ? 1 : 2;
+        static const char* force = getenv("SSME_PRIO_MODE");         // measurement aid: 0 none, 1 / 2 the two schedules, 3.. experimental
+        if (force) a.prio_mode = atoi(force);
     }
 #ifdef SSME_ABLATE
     { const char* e = getenv("SSME_ABLATE_MASK"); a.ablate = e ? atoi(e) : 0; }
@@ -599,12 +602,14 @@ int ssme_pf_shard_step(ssme_pf_handle h, int32_t t, const double* x_win, const d
                        const double* tsum_all, const double* tmax_all, double* x_out, double* cdf_out, double* tsum_out,
                        double* tmax_out, uint32_t* anc_out) {
     if (!h || !x_out || !cdf_out || !tsum_out || !tmax_out || t < 0) return SSME_ERR_INVALID_ARG;
-    if (t > 0 && (!x_win || !cdf_win || !tsum_all || !tmax_all || win_tile0 < 0)) return SSME_ERR_INVALID_ARG;
+    // win_tile0 may be negative on the C++ driver's fixed-halo path: rank 0's halo buffer starts `margin` (never-read) rows before tile 0
+    if (t > 0 && (!x_win || !cdf_win || !tsum_all || !tmax_all || win_tile0 < -h->sh_margin)) return SSME_ERR_INVALID_ARG;
     if (h->shard_world < 1 || !h->params_set) return SSME_ERR_STATE;
     if (t >= h->tcap) return SSME_ERR_STATE;            // ssme_pf_shard_prepare sizes the series
     HIPCHK(hipSetDevice(h->cfg.device));
     StepArgs a = shard_args(h, t, tsum_all, tmax_all);
     a.x_in = x_win; a.cdf_in = cdf_win; a.win_tile0 = win_tile0;
+    if (h->sh_check) { a.win_tiles = h->sh_rows; a.win_flag = h->sh_flag; }
     a.x_out = x_out; a.cdf_out = cdf_out; a.tsum_out = tsum_out; a.tmax_out = tmax_out;
     a.anc = anc_out;
     a.finalize_prev = t > 0 ? 1 : 0;
@@ -719,8 +724,12 @@ static int shard_series(ssme_pf_handle h, ncclComm_t comm, const double* y, cons
             rc = shard_gather(h, comm);
             if (rc != SSME_OK) return rc;
             if (fast) {
-                shard_plan_device(h, t, h->sh_tsum, h->sh_tmax, m, h->sh_flag);       // plan + "does every window fit its halo?"
-                HIPCHK(hipGetLastError());
+                // up to 512 tiles the step kernel runs level-2 itself and checks its own source tiles against the fixed
+                // halo (StepArgs::win_flag): no plan launch at all; above, k_level2_plan is needed anyway and a small check follows it
+                if (h->split_l2) {
+                    shard_plan_device(h, t, h->sh_tsum, h->sh_tmax, m, h->sh_flag);
+                    HIPCHK(hipGetLastError());
+                }
                 if (world > 1) {
                     // fixed halo: my first m tiles are the left neighbour's right halo, my last m tiles the right neighbour's left halo
                     NCCLCHK(rccl().GroupStart());
@@ -766,7 +775,9 @@ static int shard_series(ssme_pf_handle h, ncclComm_t comm, const double* y, cons
                 xw = h->sh_winx; cw = h->sh_winc; win0 = lo;
             }
         }
+        h->sh_check = (fast && t > 0) ? 1 : 0;                                         // the step kernel checks its sources against the halo
         rc = ssme_pf_shard_step(h, t, xw, cw, win0, h->sh_tsum, h->sh_tmax, xo, co, h->sh_loc, h->sh_loc + Bl, nullptr);
+        h->sh_check = 0;
         if (rc != SSME_OK) return rc;
         cur ^= 1;
     }
@@ -1401,6 +1412,13 @@ struct ssme_lw_s {
     int32_t* plan_dev;
     int32_t* plan_pin;               // pinned staging of the plan download
     double *pin, *pin_dev;           // step API: device-mapped pinned buffer for the R log conditional likelihoods
+    // C++ shard driver (ssme_lw_shard_run_series): halo buffers ([margin | own | margin] rows of 2048 doubles; theta rows of 8192),
+    // this rank's stage outputs for the gathers, the gathered arrays, flag
+    double *sh_xB, *sh_thB, *sh_cdfB, *sh_xr, *sh_thr, *sh_g1, *sh_cdfA;
+    double *sh_locB, *sh_locA, *sh_allB_s, *sh_allB_m, *sh_allA_s, *sh_allA_m, *sh_mom_all;
+    int32_t* sh_flag;
+    int sh_margin, sh_rows, sh_check;
+    long sh_exchanged;
     int gamma_t0, gamma_rows;        // step API: the Gamma tables hold time indices gamma_t0 .. gamma_t0 + gamma_rows - 1
     int split_l2;                    // level-2 of both draws by k_level2_plan (more than 512 tiles)
     double *l2T[2], *l2R[2];         // [draw: 0 resampling (B), 1 k draw (A)][R][Bs]
@@ -1555,7 +1573,9 @@ int ssme_lw_destroy(ssme_lw_handle h) {
     void* bufs[] = {h->xB, h->thB, h->xr, h->thr, h->lw1, h->cdfA, h->tsumA, h->tmaxA, h->cdfB, h->tsumB, h->tmaxB, h->mom, h->prop,
                     h->ybuf, h->zbuf, h->per_step, h->scratch, h->gamA, h->pgamA, h->gtotA, h->gamB, h->pgamB, h->gtotB, h->anc,
                     h->kidx, h->scal, h->keybuf, h->plan_dev, h->l2T[0], h->l2T[1], h->l2R[0], h->l2R[1], h->l2lo[0], h->l2lo[1],
-                    h->l2hi[0], h->l2hi[1], h->l2s[0], h->l2s[1], h->lwB, h->wscratch};
+                    h->l2hi[0], h->l2hi[1], h->l2s[0], h->l2s[1], h->lwB, h->wscratch,
+                    h->sh_xB, h->sh_thB, h->sh_cdfB, h->sh_xr, h->sh_thr, h->sh_g1, h->sh_cdfA, h->sh_locB, h->sh_locA, h->sh_allB_s, h->sh_allB_m,
+                    h->sh_allA_s, h->sh_allA_m, h->sh_mom_all, h->sh_flag};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->plan_pin) hipHostFree(h->plan_pin);
     if (h->pin) hipHostFree(h->pin);
@@ -1702,6 +1722,7 @@ static LwArgs lw_shard_args(ssme_lw_handle h, int t) {
     a.per_step = h->per_step;
     a.tile0 = h->shard_rank * Bl;
     a.anc = nullptr; a.kidx = nullptr;
+    if (h->sh_check) { a.win_tiles = h->sh_rows; a.win_flag = h->sh_flag; }
     return a;
 }
 
@@ -1753,7 +1774,7 @@ int ssme_lw_shard_plan(ssme_lw_handle h, int32_t which, int32_t t, const double*
 int ssme_lw_shard_stage1(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t win_tiles, const double* w_xB, const double* w_thB,
                          const double* w_cdfB, const double* tsumB_all, const double* tmaxB_all, double* xr, double* thr, double* lw1,
                          double* cdfA, double* tsumA, double* tmaxA, double* mom, uint32_t* anc) {
-    if (!h || t < 1 || win_tile0 < 0 || win_tiles < 1 || !w_xB || !w_thB || !w_cdfB || !tsumB_all || !tmaxB_all || !xr || !thr || !lw1 ||
+    if (!h || t < 1 || win_tile0 < -h->sh_margin || win_tiles < 1 || !w_xB || !w_thB || !w_cdfB || !tsumB_all || !tmaxB_all || !xr || !thr || !lw1 ||
         !cdfA || !tsumA || !tmaxA || !mom)
         return SSME_ERR_INVALID_ARG;
     if (h->shard_world < 1) return SSME_ERR_STATE;
@@ -1787,7 +1808,7 @@ int ssme_lw_shard_mid(ssme_lw_handle h, int32_t t, const double* tsumA_all, cons
 int ssme_lw_shard_stage2(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t win_tiles, const double* w_xr, const double* w_thr,
                          const double* w_lw1, const double* w_cdfA, const double* tsumA_all, const double* tmaxA_all, double* xB,
                          double* thB, double* cdfB, double* tsumB, double* tmaxB, uint32_t* kidx) {
-    if (!h || t < 1 || win_tile0 < 0 || win_tiles < 1 || !w_xr || !w_thr || !w_lw1 || !w_cdfA || !tsumA_all || !tmaxA_all || !xB || !thB ||
+    if (!h || t < 1 || win_tile0 < -h->sh_margin || win_tiles < 1 || !w_xr || !w_thr || !w_lw1 || !w_cdfA || !tsumA_all || !tmaxA_all || !xB || !thB ||
         !cdfB || !tsumB || !tmaxB)
         return SSME_ERR_INVALID_ARG;
     if (h->shard_world < 1) return SSME_ERR_STATE;
@@ -1818,6 +1839,142 @@ int ssme_lw_shard_finalize(ssme_lw_handle h, int32_t t, const double* tsumB_all,
         hipLaunchKernelGGL(k_lw_finalize<false>, dim3(1), dim3(kThreads), 0, h->stream, a);
     LWCHK(hipGetLastError());
     LWCHK(hipStreamSynchronize(h->stream));
+    return SSME_OK;
+}
+
+// ---- C++ driver of the sharded Liu-West filter over RCCL (BASELINE.json configs[4]; fixed-halo path) ------------------------
+// Per step, on one HIP stream, no host synchronisation inside the time loop:
+//   grouped all-gather (tsumB, tmaxB)  [-> plan(0) above 512 tiles]  -> halo exchange of (xB, theta B, cdfB)  -> stage 1
+//   grouped all-gather (tsumA, tmaxA, 16 moment slots per tile)  [-> plan(1)]  -> mid  -> halo exchange of (xr, theta r, g1, cdfA)  -> stage 2
+// The stage kernels check their own source tiles against the exchanged window and raise a flag (read once, after the
+// series): SSME_ERR_STATE then tells the caller to run the exact, host-planned loop (ssme_amd/sharded.py: ShardedLiuWest).
+#define LWNCCL(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
+    h->err = std::string(#call) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r_) : "RCCL error"); return SSME_ERR_HIP; } } while (0)
+
+static int lw_shard_alloc(ssme_lw_handle h) {
+    if (h->sh_xB) return SSME_OK;
+    const int world = h->shard_world, Bl = h->B / world;
+    int m = Bl / 64 > 4 ? Bl / 64 : 4;
+    if (m > Bl) m = Bl;
+    if (world == 1) m = 0;
+    h->sh_margin = m; h->sh_rows = Bl + 2 * m;
+    const size_t row = sizeof(double) * kTile, rows = (size_t)h->sh_rows;
+    double** one[] = {&h->sh_xB, &h->sh_cdfB, &h->sh_xr, &h->sh_g1, &h->sh_cdfA};
+    for (auto p : one) { LWCHK(hipMalloc(p, row * rows)); LWCHK(hipMemset(*p, 0, row * rows)); }
+    double** four[] = {&h->sh_thB, &h->sh_thr};
+    for (auto p : four) { LWCHK(hipMalloc(p, row * rows * kDP)); LWCHK(hipMemset(*p, 0, row * rows * kDP)); }
+    LWCHK(hipMalloc(&h->sh_locB, sizeof(double) * 2 * Bl));
+    LWCHK(hipMalloc(&h->sh_locA, sizeof(double) * 18 * Bl));                 // tile sums | tile maxima | 16 moment slots per tile
+    LWCHK(hipMemset(h->sh_locA, 0, sizeof(double) * 18 * Bl));
+    double** all[] = {&h->sh_allB_s, &h->sh_allB_m, &h->sh_allA_s, &h->sh_allA_m};
+    for (auto p : all) LWCHK(hipMalloc(p, sizeof(double) * h->Bs));
+    LWCHK(hipMalloc(&h->sh_mom_all, sizeof(double) * (size_t)h->B * 16));
+    LWCHK(hipMalloc(&h->sh_flag, sizeof(int32_t) * 4));
+    return SSME_OK;
+}
+
+// halo exchange with the two neighbouring ranks for a list of buffers (rows of `width` doubles per tile)
+static int lw_halo_exchange(ssme_lw_handle h, ncclComm_t comm, std::initializer_list<std::pair<double*, size_t>> bufs) {
+    const int world = h->shard_world, rank = h->shard_rank, Bl = h->B / world, m = h->sh_margin;
+    if (world == 1 || m == 0) return SSME_OK;
+    LWNCCL(rccl().GroupStart());
+    for (auto& bw : bufs) {
+        double* buf = bw.first;
+        const size_t w = bw.second;
+        if (rank > 0) {
+            LWNCCL(rccl().Send(buf + (size_t)m * w, (size_t)m * w, ncclDouble, rank - 1, comm, h->stream));
+            LWNCCL(rccl().Recv(buf, (size_t)m * w, ncclDouble, rank - 1, comm, h->stream));
+        }
+        if (rank + 1 < world) {
+            LWNCCL(rccl().Send(buf + (size_t)Bl * w, (size_t)m * w, ncclDouble, rank + 1, comm, h->stream));
+            LWNCCL(rccl().Recv(buf + (size_t)(m + Bl) * w, (size_t)m * w, ncclDouble, rank + 1, comm, h->stream));
+        }
+    }
+    LWNCCL(rccl().GroupEnd());
+    h->sh_exchanged += (long)m * ((rank > 0) + (rank + 1 < world));
+    return SSME_OK;
+}
+
+int ssme_lw_shard_run_series(ssme_lw_handle h, void* nccl_comm, const double* y, const double* z, int32_t T, double* loglik_out) {
+    if (!h || !nccl_comm || !y) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1) return SSME_ERR_STATE;
+    if (T < 1) return SSME_ERR_LENGTH;
+    if (!rccl().ok) { h->err = "RCCL (librccl.so) not found in this process"; return SSME_ERR_UNSUPPORTED; }
+    LWCHK(hipSetDevice(h->cfg.device));
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+    int rc = lw_shard_alloc(h);
+    if (rc != SSME_OK) return rc;
+    const int world = h->shard_world, Bl = h->B / world, m = h->sh_margin, tile0 = h->shard_rank * Bl;
+    const size_t TL = kTile, off = (size_t)m * TL;
+    rc = ssme_lw_shard_set_plane_tiles(h, h->sh_rows);
+    if (rc != SSME_OK) return rc;
+    rc = ssme_lw_shard_prepare(h, y, z, T);
+    if (rc != SSME_OK) return rc;
+    LWCHK(hipMemsetAsync(h->sh_flag, 0, sizeof(int32_t) * 4, h->stream));
+    h->sh_exchanged = 0;
+    double *tsB = h->sh_locB, *tmB = h->sh_locB + Bl;
+    double *tsA = h->sh_locA, *tmA = h->sh_locA + Bl, *momL = h->sh_locA + 2 * Bl;
+    auto gatherB = [&]() -> int {
+        LWNCCL(rccl().GroupStart());
+        LWNCCL(rccl().AllGather(tsB, h->sh_allB_s, (size_t)Bl, ncclDouble, comm, h->stream));
+        LWNCCL(rccl().AllGather(tmB, h->sh_allB_m, (size_t)Bl, ncclDouble, comm, h->stream));
+        LWNCCL(rccl().GroupEnd());
+        return SSME_OK;
+    };
+    rc = ssme_lw_shard_init(h, h->sh_xB + off, h->sh_thB + off * kDP, h->sh_cdfB + off, tsB, tmB);
+    if (rc != SSME_OK) return rc;
+    for (int t = 1; t < T; ++t) {
+        rc = gatherB();
+        if (rc != SSME_OK) return rc;
+        if (h->split_l2) { lw_launch_plan(h, 0, t, t, h->sh_allB_s, h->sh_allB_m, true); LWCHK(hipGetLastError()); }
+        rc = lw_halo_exchange(h, comm, {{h->sh_xB, TL}, {h->sh_thB, TL * kDP}, {h->sh_cdfB, TL}});
+        if (rc != SSME_OK) return rc;
+        h->sh_check = 1;
+        rc = ssme_lw_shard_stage1(h, t, tile0 - m, h->sh_rows, h->sh_xB, h->sh_thB, h->sh_cdfB, h->sh_allB_s, h->sh_allB_m,
+                                  h->sh_xr + off, h->sh_thr + off * kDP, h->sh_g1 + off, h->sh_cdfA + off, tsA, tmA, momL, nullptr);
+        h->sh_check = 0;
+        if (rc != SSME_OK) return rc;
+        LWNCCL(rccl().GroupStart());
+        LWNCCL(rccl().AllGather(tsA, h->sh_allA_s, (size_t)Bl, ncclDouble, comm, h->stream));
+        LWNCCL(rccl().AllGather(tmA, h->sh_allA_m, (size_t)Bl, ncclDouble, comm, h->stream));
+        LWNCCL(rccl().AllGather(momL, h->sh_mom_all, (size_t)Bl * 16, ncclDouble, comm, h->stream));
+        LWNCCL(rccl().GroupEnd());
+        // the plan of the k draw first: above 512 tiles it provides the (m, S) that mid turns into the first-stage log-sum-exp
+        if (h->split_l2) { lw_launch_plan(h, 1, t, t, h->sh_allA_s, h->sh_allA_m, true); LWCHK(hipGetLastError()); }
+        rc = ssme_lw_shard_mid(h, t, h->sh_allA_s, h->sh_allA_m, h->sh_mom_all);
+        if (rc != SSME_OK) return rc;
+        rc = lw_halo_exchange(h, comm, {{h->sh_xr, TL}, {h->sh_thr, TL * kDP}, {h->sh_g1, TL}, {h->sh_cdfA, TL}});
+        if (rc != SSME_OK) return rc;
+        h->sh_check = 1;
+        rc = ssme_lw_shard_stage2(h, t, tile0 - m, h->sh_rows, h->sh_xr, h->sh_thr, h->sh_g1, h->sh_cdfA, h->sh_allA_s, h->sh_allA_m,
+                                  h->sh_xB + off, h->sh_thB + off * kDP, h->sh_cdfB + off, tsB, tmB, nullptr);
+        h->sh_check = 0;
+        if (rc != SSME_OK) return rc;
+    }
+    rc = gatherB();
+    if (rc != SSME_OK) return rc;
+    rc = ssme_lw_shard_finalize(h, T - 1, h->sh_allB_s, h->sh_allB_m);           // synchronises
+    if (rc != SSME_OK) return rc;
+    int32_t flag[4] = {0, 0, 0, 0};
+    LWCHK(hipMemcpy(flag, h->sh_flag, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag[0]) { h->err = "a resampling window left the fixed halo: run the exact host-planned loop"; return SSME_ERR_STATE; }
+    if (loglik_out) return ssme_lw_get_loglik(h, loglik_out);
+    return SSME_OK;
+}
+
+// this rank's particles and transformed parameters (theta[d * n + i]) after ssme_lw_shard_run_series
+int ssme_lw_shard_download(ssme_lw_handle h, double* x_local, double* theta_local, int64_t* exchanged_tiles) {
+    if (!h) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1 || !h->sh_xB) return SSME_ERR_STATE;
+    LWCHK(hipSetDevice(h->cfg.device));
+    const size_t n = (size_t)(h->B / h->shard_world) * kTile, off = (size_t)h->sh_margin * kTile;
+    if (x_local) LWCHK(hipMemcpy(x_local, h->sh_xB + off, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (theta_local) {
+        std::vector<double> rec(n * kDP);
+        LWCHK(hipMemcpy(rec.data(), h->sh_thB + off * kDP, sizeof(double) * rec.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) for (int d = 0; d < kDP; ++d) theta_local[(size_t)d * n + i] = rec[i * kDP + d];
+    }
+    if (exchanged_tiles) *exchanged_tiles = h->sh_exchanged;
     return SSME_OK;
 }
 

@@ -101,6 +101,8 @@ struct StepArgs {
     int32_t tile0;             // particle-sharded filter: global id of this launch's first OUTPUT tile (0 otherwise); outputs
                                // are stored at local offsets (tile - tile0)
     int32_t win_tile0;         // global id of the first SOURCE tile held in x_in / cdf_in (0 otherwise)
+    int32_t win_tiles;         // C++ shard driver, fixed-halo path: tiles held in the source window (0: unchecked)
+    int32_t* win_flag;         // ... and where to record that some output tile's sources left it ([0] flag), or null
     // split level-2 (filters of more than 2048 tiles, or forced for tests): written by k_level2_plan, read by k_filter_step<..,true>
     double* l2_T;              // [R][Bs] inclusive prefixes T'_b of the rescaled tile sums
     double* l2_R;              // [R][Bs] A_b / A'_b
@@ -469,6 +471,14 @@ __device__ __forceinline__ void prio_at(int mode, int idx) {
     } else if (mode == 2) {
         if (idx == 0) __builtin_amdgcn_s_setprio(3); else if (idx == 3) __builtin_amdgcn_s_setprio(2);
         else if (idx == 5) __builtin_amdgcn_s_setprio(1); else if (idx == 6) __builtin_amdgcn_s_setprio(0);
+    } else if (mode == 3) {          // experimental schedules (SSME_PRIO_MODE): later drops
+        if (idx == 0) __builtin_amdgcn_s_setprio(3); else if (idx == 4) __builtin_amdgcn_s_setprio(2);
+        else if (idx == 7) __builtin_amdgcn_s_setprio(1); else if (idx == 9) __builtin_amdgcn_s_setprio(0);
+    } else if (mode == 4) {          // earlier drops
+        if (idx == 0) __builtin_amdgcn_s_setprio(3); else if (idx == 2) __builtin_amdgcn_s_setprio(2);
+        else if (idx == 4) __builtin_amdgcn_s_setprio(1); else if (idx == 6) __builtin_amdgcn_s_setprio(0);
+    } else if (mode == 5) {          // two levels only
+        if (idx == 0) __builtin_amdgcn_s_setprio(1); else if (idx == 6) __builtin_amdgcn_s_setprio(0);
     }
 }
 #define PRIO_AT(i) prio_at(a.prio_mode, i)
@@ -624,6 +634,16 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             hi = hi < a.B - 1 ? hi : a.B - 1;
             bb_min = __builtin_amdgcn_readfirstlane(lo);
             span = __builtin_amdgcn_readfirstlane(hi) - bb_min + 1;
+        }
+        if (a.win_flag) {
+            // fixed-halo sharding: the window this rank holds was exchanged BEFORE anyone knew the plan.  If my sources
+            // leave it, say so (the host reruns the series on the exact path) and stay inside the buffer for this launch.
+            const int first = a.win_tile0 > 0 ? a.win_tile0 : 0, last = a.win_tile0 + a.win_tiles - 1 < a.B - 1 ? a.win_tile0 + a.win_tiles - 1 : a.B - 1;
+            if (bb_min < first || bb_min + span - 1 > last) {
+                if (tid == 0) atomicOr(a.win_flag, 1);
+                bb_min = bb_min < first ? first : (bb_min > last ? last : bb_min);
+                span = 1;
+            }
         }
         if (!BIG) {
             // A_b / A'_b (maps a global target into its tile's fixed point).  Only the staged tiles' ratios are needed, so the

@@ -102,6 +102,22 @@ def gather_flat(local_flat, world, group=None, stage_through_host=False):
     return out.to(local_flat.device) if stage_through_host else out
 
 
+def make_native_comm(rank, world, device_index, group=None):
+    """An RCCL communicator for the C++ drivers: rank 0 makes the unique id, torch.distributed ships its 128 bytes."""
+    import torch.distributed as dist
+    L = capi.lib()
+    buf = (C.c_ubyte * 128)()
+    if rank == 0:
+        capi.check(L.ssme_shard_comm_get_unique_id(buf))
+    box = [bytes(buf)]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+    idbuf = (C.c_ubyte * 128).from_buffer_copy(box[0])
+    comm = C.c_void_p()
+    capi.check(L.ssme_shard_comm_init(idbuf, rank, world, device_index, C.byref(comm)))
+    return comm
+
+
 class HaloBuffer:
     """This rank's tiles with room for neighbours' tiles on both sides: [margin | own tiles | margin] rows of W doubles.
 
@@ -301,18 +317,7 @@ class ShardedParticleFilter:
     def _native_comm(self):
         """An RCCL communicator for the C++ driver: rank 0 makes the unique id, torch.distributed ships its 128 bytes."""
         if getattr(self, "_comm", None) is None:
-            import torch.distributed as dist
-            L = capi.lib()
-            buf = (C.c_ubyte * 128)()
-            if self.rank == 0:
-                self._chk(L.ssme_shard_comm_get_unique_id(buf))
-            box = [bytes(buf)]
-            if self.world > 1:
-                dist.broadcast_object_list(box, src=0 if self.group is None else dist.get_global_rank(self.group, 0), group=self.group)
-            idbuf = (C.c_ubyte * 128).from_buffer_copy(box[0])
-            comm = C.c_void_p()
-            self._chk(L.ssme_shard_comm_init(idbuf, self.rank, self.world, self.device.index or 0, C.byref(comm)))
-            self._comm = comm
+            self._comm = make_native_comm(self.rank, self.world, self.device.index or 0, self.group)
         return self._comm
 
     def run_series_native(self, y, z=None, mode=0):
@@ -393,6 +398,9 @@ class ShardedLiuWest:
         torch.cuda.synchronize(self.device)
 
     def close(self):
+        if getattr(self, "_comm", None) is not None:
+            capi.lib().ssme_shard_comm_destroy(self._comm)
+            self._comm = None
         if getattr(self, "_h", None) is not None and self._h.value:
             capi.lib().ssme_lw_destroy(self._h)
             self._h = C.c_void_p()
@@ -487,3 +495,30 @@ class ShardedLiuWest:
     def local_theta(self):
         """[4, N / world]: transformed parameters of this rank's particles (the device keeps [particle][4] records)."""
         return self.thB.own().reshape(-1, 4).t().contiguous().cpu().numpy()
+
+    # ---- the same loop in C++ over RCCL (ssme_lw_shard_run_series) ----
+    def run_series_native(self, y, z=None):
+        """log p(y_{1:T}) through the C++ driver (fixed-halo exchange, no host synchronisation per step).  If a resampling
+        window ever leaves the halo the driver says so and the exact Python-driven loop runs instead.  One GPU per rank."""
+        import torch
+        yv = capi.as_f64(y)
+        zv = None if z is None else capi.as_f64(z)
+        if getattr(self, "_comm", None) is None:
+            self._comm = make_native_comm(self.rank, self.world, self.device.index or 0, self.group)
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+        out = np.empty(1)
+        st = capi.lib().ssme_lw_shard_run_series(self._h, self._comm, capi.dptr(yv), capi.dptr(zv), yv.size, capi.dptr(out))
+        self.native_path = "fixed halo"
+        if st == capi.ERR_STATE:
+            self.native_path = "exact (Python-driven) after a window left the halo"
+            return self.run_series(y, z)
+        self._chk(st)
+        self._T = yv.size
+        return float(out[0])
+
+    def native_state(self):
+        n = self.Bl * TILE
+        x, th = np.empty(n), np.empty((4, n))
+        ex = C.c_int64()
+        self._chk(capi.lib().ssme_lw_shard_download(self._h, capi.dptr(x), capi.dptr(th), C.byref(ex)))
+        return x, th, ex.value

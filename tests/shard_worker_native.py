@@ -2,7 +2,7 @@
 rank per GPU.  On the one-GPU test box that is world = 1 (RCCL refuses two ranks on one device); the driver's bench
 exercises the real multi-GPU exchange (bench.py --mode sharded --gpus N).
 
-usage: shard_worker_native.py OUT.npz MODEL N T RESAMPLER SEED MODE
+usage: shard_worker_native.py OUT.npz MODEL N T RESAMPLER SEED MODE      (MODEL = -1: the Liu-West filter, RESAMPLER = delta x 1000)
 """
 import os
 import sys
@@ -24,7 +24,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    from ssme_amd.sharded import ShardedParticleFilter
+    from ssme_amd.sharded import ShardedLiuWest, ShardedParticleFilter
+    if model < 0:
+        y = np.loadtxt(os.path.join(ROOT, "tests", "golden", "spy_returns.csv"))[:T]
+        z = np.concatenate([[0.0], y[:-1]])
+        f = ShardedLiuWest(rs / 1000.0, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, seed=seed)
+        ll = f.run_series_native(y, z)
+        per = f.per_step()
+        x, th, exchanged = f.native_state()
+        ll_py = f.run_series(y, z)
+        np.savez(out, ll=ll, per_step=per, x=x, theta=th, path=f.native_path, exchanged=exchanged, ll_py=ll_py)
+        f.close()
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+        return
     th = {0: [1.0, 0.95, 0.25], 1: [0.9, 0.0, 1.0, -0.1], 2: [0.9, 0.5, 0.7]}[model]
     y = np.loadtxt(os.path.join(ROOT, "tests", "golden", "spy_returns.csv"))[:T]
     z = np.concatenate([[0.0], y[:-1]]) if model == 1 else None

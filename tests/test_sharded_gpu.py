@@ -151,3 +151,30 @@ def test_native_rccl_driver_matches_unsharded(tmp_path, spy, model, n, rs, T, mo
     assert np.array_equal(r["x"].view(np.uint64), st["x"].view(np.uint64))
     assert np.array_equal(r["cdf"], st["cdf"])
     assert int(r["path"]) == (2 if mode == 2 else 1)
+
+
+@pytest.mark.parametrize("n,delta,T", [(16384, 0.99, 10), (600 * 2048, 0.95, 4)])
+def test_native_rccl_driver_liu_west_matches_unsharded(tmp_path, spy, n, delta, T):
+    """ssme_lw_shard_run_series (C++ over RCCL, one rank per GPU) == the unsharded Liu-West filter: log-likelihoods,
+    particles, transformed parameters; the Python-driven loop on the same handle gives the same log-likelihood."""
+    import ssme_amd
+    seed = 123
+    out = str(tmp_path / "native_lw.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shard_worker_native.py"), out, "-1", str(n), str(T), str(int(delta * 1000)),
+                        str(seed), "0"], env=env, timeout=300)
+    assert p.returncode == 0
+    r = np.load(out)
+    y = spy[:T]
+    z = np.concatenate([[0.0], y[:-1]])
+    ref = ssme_amd.svol_lw_1_par(delta, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, seed=seed)
+    ll = ref.run_series(y, z)[0]
+    per = ref.per_step()[0]
+    st = ref.state(0)
+    ref.close()
+    assert str(r["path"]) == "fixed halo"
+    assert float(r["ll"]) == ll and float(r["ll_py"]) == ll
+    assert np.array_equal(r["per_step"].view(np.uint64), per.view(np.uint64))
+    assert np.array_equal(r["x"].view(np.uint64), st["x"].view(np.uint64))
+    assert np.array_equal(r["theta"].view(np.uint64), st["theta"].view(np.uint64))
