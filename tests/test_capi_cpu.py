@@ -121,3 +121,15 @@ def test_sharded_python_class_requires_process_group():
     from ssme_amd.sharded import ShardedParticleFilter
     with pytest.raises(AssertionError):
         ShardedParticleFilter(0, 4096)
+
+
+def test_mock_rccl_and_thread_harness_compile():
+    """The test-only RCCL stand-in (ranks = host threads on one GPU) and the multi-rank harness build against the C ABI."""
+    import subprocess
+    from ssme_amd import build
+    so = build.build()
+    cpp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    mock = os.path.join(cpp, "libmock_rccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wno-unused-result", os.path.join(cpp, "mock_rccl.cpp"), "-o", mock])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(cpp, "test_shard_threads.cpp"), "-o", os.path.join(cpp, "test_shard_threads"),
+                           mock, so, "-Wl,-rpath," + cpp, "-Wl,-rpath," + os.path.dirname(so)])

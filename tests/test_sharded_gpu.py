@@ -178,3 +178,44 @@ def test_native_rccl_driver_liu_west_matches_unsharded(tmp_path, spy, n, delta, 
     assert np.array_equal(r["per_step"].view(np.uint64), per.view(np.uint64))
     assert np.array_equal(r["x"].view(np.uint64), st["x"].view(np.uint64))
     assert np.array_equal(r["theta"].view(np.uint64), st["theta"].view(np.uint64))
+
+
+def _build_thread_harness():
+    from ssme_amd import build
+    so = build.build()
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    mock = os.path.join(cpp, "libmock_rccl.so")
+    exe = os.path.join(cpp, "test_shard_threads")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wno-unused-result", os.path.join(cpp, "mock_rccl.cpp"), "-o", mock])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(cpp, "test_shard_threads.cpp"), "-o", exe, mock, so,
+                           "-Wl,-rpath," + cpp, "-Wl,-rpath," + os.path.dirname(so)])
+    return exe
+
+
+@pytest.mark.parametrize("world,n,T,model,rs,mode", [
+    (2, 16384, 16, 0, 0, 1), (4, 65536, 12, 0, 0, 0), (4, 65536, 10, 1, 1, 1), (3, 3 * 4 * 2048, 10, 2, 2, 0), (6, 6 * 8 * 2048, 8, 0, 0, 2),
+    (4, 16384, 8, 1, 1, 0),                       # two tiles per rank, heavy-tailed leverage weights: windows may leave the halo -> exact rerun
+    (2, 2 * 300 * 2048, 4, 0, 0, 1), (4, 4 * 160 * 2048, 4, 0, 1, 0),      # more than 512 tiles: split level-2 plans + window check kernel
+    (2, 16384, 10, -1, 990, 0), (4, 65536, 8, -1, 950, 0), (2, 2 * 300 * 2048, 3, -1, 990, 0)])      # Liu-West
+def test_native_drivers_with_several_ranks_on_one_gpu(world, n, T, model, rs, mode):
+    """The C++ shard drivers with 2-6 ranks: the ranks are host threads sharing the GPU and RCCL is replaced by
+    tests/cpp/mock_rccl.cpp (same stream ordering and send/recv matching; RCCL itself refuses two ranks per device).
+    Every rank's log-likelihood and particles == the unsharded filter's, on the fixed-halo path, on the exact path and
+    through the automatic fallback."""
+    exe = _build_thread_harness()
+    out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "spy_returns.csv"), str(world), str(n), str(T), str(model), str(rs),
+                                   str(mode), "4242"], text=True, timeout=600)
+    lines = out.strip().splitlines()
+    ref = float(lines[0].split()[1])
+    ranks = [l.split() for l in lines if l.startswith("rank")]
+    assert len(ranks) == world
+    paths = {int(r[5]) for r in ranks}
+    assert len(paths) == 1                                   # every rank takes the same path
+    if model >= 0 or paths == {1}:
+        for r in ranks:
+            assert float(r[3]) == ref, (r, ref)
+        assert lines[-1] == "particle_mismatches 0"
+    if mode == 2:
+        assert paths == {2}
+    if mode == 1:
+        assert paths == {1}
