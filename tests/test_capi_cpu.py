@@ -132,4 +132,4 @@ def test_mock_rccl_and_thread_harness_compile():
     mock = os.path.join(cpp, "libmock_rccl.so")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wno-unused-result", os.path.join(cpp, "mock_rccl.cpp"), "-o", mock])
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(cpp, "test_shard_threads.cpp"), "-o", os.path.join(cpp, "test_shard_threads"),
-                           mock, so, "-Wl,-rpath," + cpp, "-Wl,-rpath," + os.path.dirname(so)])
+                           "-Wl,--no-as-needed", mock, "-Wl,--as-needed", so, "-Wl,-rpath," + cpp, "-Wl,-rpath," + os.path.dirname(so)])

@@ -187,7 +187,7 @@ def _build_thread_harness():
     mock = os.path.join(cpp, "libmock_rccl.so")
     exe = os.path.join(cpp, "test_shard_threads")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wno-unused-result", os.path.join(cpp, "mock_rccl.cpp"), "-o", mock])
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(cpp, "test_shard_threads.cpp"), "-o", exe, mock, so,
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(cpp, "test_shard_threads.cpp"), "-o", exe, "-Wl,--no-as-needed", mock, "-Wl,--as-needed", so,
                            "-Wl,-rpath," + cpp, "-Wl,-rpath," + os.path.dirname(so)])
     return exe
 
