@@ -75,9 +75,10 @@ typedef struct ssme_pf_config {
     int32_t  device;           /* HIP device ordinal                                         */
     uint32_t first_filter_id;  /* global id of filter 0 of this handle; enters the Philox
                                   counter, so sharding R over GPUs keeps every stream        */
-    int32_t  tile_particles;   /* particles per tile: 2048 or 512, or 0 = chosen from (N, n_filters):
-                                  512 for 2048 < N <= 2^18 when n_filters * ceil(N / 2048) < 512 (a
-                                  mid-size handle then spreads over the chip), else 2048.
+    int32_t  tile_particles;   /* particles per tile: 2048, 1024 or 512, or 0 = chosen from (N, n_filters):
+                                  2048 for N <= 2048; else 512 while n_filters * ceil(N / 512) <= 256,
+                                  else 1024 while n_filters * ceil(N / 1024) <= 512, else 2048 (a
+                                  mid-size handle then spreads over the chip).
                                   Part of the arithmetic specification:
                                   weights are fixed point relative to their tile's maximum and
                                   the resampler draws one Gamma variate per tile */
@@ -142,7 +143,7 @@ int ssme_pf_log_mean_exp(ssme_pf_handle h, double* out);
  * ancestors: N indices used by the last step (requires set_debug(flags & 1)). */
 int ssme_pf_download_state(ssme_pf_handle h, int32_t filter, double* x, double* logw, uint64_t* cdf,
                            uint32_t* ancestors);
-/* The tile decomposition in use: particles per tile (2048 or 512) and tiles per filter. */
+/* The tile decomposition in use: particles per tile (2048, 1024 or 512) and tiles per filter. */
 int ssme_pf_get_layout(ssme_pf_handle h, int32_t* tile_particles, int32_t* n_tiles);
 /* max_logw: max log-weight of the last step; sum_q: exact integer sum of the rescaled tile sums;
  * tile_sums / tile_max: one integer weight sum and one max log-weight per tile;

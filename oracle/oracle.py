@@ -199,11 +199,15 @@ def quantize(x, sc):
 
 
 def default_tile(n, n_filters=1):
-    """The device's rule when the caller does not choose a tile size (pf_api.hip: default_tile): 512-particle tiles
-    for 2048 < N <= 2^18 when the handle's filters would fill fewer than 512 workgroups with 2048-particle tiles."""
-    if n <= 2048 or n > (1 << 18):
+    """The device's rule when the caller does not choose a tile size (pf_api.hip: default_tile): the smallest of
+    512 / 1024 / 2048 particles per tile that leaves at most 256 / 512 workgroups; 2048 for N <= 2048 and beyond."""
+    if n <= 2048:
         return 2048
-    return 512 if n_filters * ((n + 2047) // 2048) < 512 else 2048
+    if n_filters * ((n + 511) // 512) <= 256:
+        return 512
+    if n_filters * ((n + 1023) // 1024) <= 512:
+        return 1024
+    return 2048
 
 
 class Filter:

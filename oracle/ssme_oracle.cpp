@@ -382,7 +382,7 @@ struct Filter {
     // STREAM_PROP): words 0-1 -> Box-Muller (radius uniform 40 bits, angle 24 bits), words 2-3 -> the pair's two
     // exponential spacings (32 bits each); logs by o_log_u.  false: the Liu-West filter's streams (52-bit uniforms, o_log).
     bool bootstrap_draws = false;
-    // particles per tile (2048 or 512): weights are fixed point relative to their TILE's maximum and the multinomial
+    // particles per tile (2048, 1024 or 512): weights are fixed point relative to their TILE's maximum and the multinomial
     // resampler draws one Gamma variate per tile, so the tile size is part of the specification.  The device's rule when
     // the caller does not choose (pf_api.hip: default_tile): 2048 for N <= 2048 and N > 2^18, 512 in between.
     int tile = 2048;

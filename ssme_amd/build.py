@@ -17,7 +17,7 @@ def deps():
         os.path.join(os.path.dirname(HERE), "include", "ssme_pf.h")]
 
 # -ffp-contract=off: the libm-free math is a fixed IEEE operation sequence (explicit fma only)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,-soname,libssme_pf.so", "-ffp-contract=off", "-mfma",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 

@@ -22,7 +22,7 @@ using namespace ssme;
 struct ssme_pf_s {
     ssme_pf_config cfg;
     int N, R, Npad, B, Bs, Bpow2, rshift;
-    int tile;                // particles per tile: 2048 or 512 (cfg.tile_particles, or by N: default_tile)
+    int tile;                // particles per tile: 2048, 1024 or 512 (cfg.tile_particles, or by N: default_tile)
     size_t lds_bytes;
     int t;                   // next time index
     bool params_set;
@@ -180,15 +180,19 @@ static StepArgs step_args(ssme_pf_handle h) {
 }
 
 // Tile size when the caller does not choose (part of the arithmetic specification: the oracle applies the same rule).
-// 2048-particle tiles are the efficient shape (fewer, fatter workgroups; N <= 2048 is the whole-series kernel).  A handle
-// whose filters would occupy fewer than 512 workgroups that way (two per CU) and whose N lies in (2048, 2^18] gets
-// 512-particle tiles instead, so that mid-size filters spread over the chip (one filter of 2^16: 128 workgroups
-// instead of 32, 10.2 -> 7.3 us per step).  The rule reads the handle's (N, n_filters): callers that shard filters over
-// GPUs and want results independent of the sharding pass tile_particles explicitly.
+// 2048-particle tiles are the efficient shape at full occupancy (fewer, fatter workgroups; N <= 2048 is the whole-series
+// kernel).  Smaller handles get the smallest tile that still leaves every workgroup resident at once, so that mid-size
+// filters spread over the 256 CUs: 512-particle tiles while they make at most 256 workgroups (one filter of 2^16: 128
+// workgroups instead of 32, 10.3 -> 7.4 us per step), 1024-particle tiles while those make at most 512 (one filter of
+// 2^18: 10.7 -> 8.4 us; 2^19: 11.5 -> 10.8 us), 2048 beyond (profiles/r02_tile_sweep.txt).  The rule reads the
+// handle's (N, n_filters): callers that shard filters over GPUs and want results independent of the sharding pass
+// tile_particles explicitly.
 static int default_tile(int n_particles, int n_filters) {
-    if (n_particles <= kTile || n_particles > (1 << 18)) return kTile;
-    const long big_tiles = (long)n_filters * ((n_particles + kTile - 1) / kTile);
-    return big_tiles < 512 ? kTileSmall : kTile;
+    if (n_particles <= kTile) return kTile;
+    const long R = n_filters;
+    if (R * ((n_particles + kTileSmall - 1) / kTileSmall) <= 256) return kTileSmall;   // at most one 256-thread block per CU
+    if (R * ((n_particles + kTileMid - 1) / kTileMid) <= 512) return kTileMid;          // at most two 512-thread blocks per CU
+    return kTile;
 }
 
 // One launcher per instantiation of the step kernel.  The dynamic-LDS ceiling of a kernel is process-wide state: it is
@@ -227,6 +231,11 @@ static void launch_step_grid(ssme_pf_handle h, const StepArgs& a, dim3 grid) {
     if (h->tile == kTileSmall) {
         if (h->split_l2) launch_rs<MODEL, 256, true, kTileSmall>(h, a, grid, h->lds_bytes_big, rs);
         else launch_rs<MODEL, 256, false, kTileSmall>(h, a, grid, h->lds_bytes, rs);
+        return;
+    }
+    if (h->tile == kTileMid) {      // 1024-particle tiles: 512 threads, one particle pair each
+        if (h->split_l2) launch_rs<MODEL, 512, true, kTileMid>(h, a, grid, h->lds_bytes_big, rs);
+        else launch_rs<MODEL, 512, false, kTileMid>(h, a, grid, h->lds_bytes, rs);
         return;
     }
     if (h->split_l2) { launch_rs<MODEL, 512, true, kTile>(h, a, grid, h->lds_bytes_big, rs); return; }
@@ -415,7 +424,7 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     if (cfg->resampler < 0 || cfg->resampler > SSME_RESAMP_MULTINOMIAL_IID) return SSME_ERR_INVALID_ARG;
     if (cfg->resamp_sched < 1) return SSME_ERR_INVALID_ARG;
     if (cfg->dtype != SSME_F64) return SSME_ERR_UNSUPPORTED;
-    if (cfg->tile_particles != 0 && cfg->tile_particles != kTile && cfg->tile_particles != kTileSmall) return SSME_ERR_INVALID_ARG;
+    if (cfg->tile_particles != 0 && cfg->tile_particles != kTile && cfg->tile_particles != kTileSmall && cfg->tile_particles != kTileMid) return SSME_ERR_INVALID_ARG;
     const int tile = shard_world > 0 ? kTile : (cfg->tile_particles ? cfg->tile_particles : default_tile(cfg->n_particles, cfg->n_filters));
     const int B = (cfg->n_particles + tile - 1) / tile;
     if (B > kMaxTilesSplit) return SSME_ERR_UNSUPPORTED;   // at most 16384 tiles per filter (N <= 2^25 with 2048-particle tiles)
@@ -893,6 +902,7 @@ int ssme_pf_set_tuning(ssme_pf_handle h, int32_t threads_per_tile) {
     if (!h) return SSME_ERR_INVALID_ARG;
     if (threads_per_tile != 256 && threads_per_tile != 512 && threads_per_tile != 1024) return SSME_ERR_INVALID_ARG;
     if (h->tile == kTileSmall && threads_per_tile != 256) return SSME_ERR_UNSUPPORTED;     // 512-particle tiles run 256 threads
+    if (h->tile == kTileMid && threads_per_tile != 512) return SSME_ERR_UNSUPPORTED;       // 1024-particle tiles run 512 threads
     h->nt = threads_per_tile;
     return SSME_OK;
 }

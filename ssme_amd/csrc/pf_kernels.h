@@ -30,7 +30,8 @@ constexpr int kThreads = 256;            // helper kernels; KA/KR are templated 
 constexpr int kWave = 64;
 constexpr int kRow = 512;
 constexpr int kTile = 2048;                // large tile: N <= 2048 (one-tile series kernel), N > 2^18, Liu-West, sharded filters
-constexpr int kTileSmall = 512;            // small tile: 2048 < N <= 2^18, so that a mid-size filter spreads over the chip (N = 2^16: 128 workgroups)
+constexpr int kTileSmall = 512;
+constexpr int kTileMid = 1024;            // small tile: 2048 < N <= 2^18, so that a mid-size filter spreads over the chip (N = 2^16: 128 workgroups)
 constexpr int kMaxTilesPerFilter = 2048;   // in-kernel level-2 (one entry per thread at NT = 512 .. four at 512 threads)
 constexpr int kSplitLevel2Above = 512;     // measured: with more than one tile sum per thread the split level-2 wins (N = 3 2^20: 81 -> 49 us)
 constexpr int kMaxTilesSplit = 16384;      // split level-2 (k_level2_plan + k_filter_step<.., true>): N <= 2^25
@@ -92,7 +93,7 @@ struct StepArgs {
     const double* pgam;        // [nT][R][B] exclusive prefixes of gam
     const double* gtot;        // [nT][R]    sum(gam) + E_{N+1}
     int32_t N, Npad, B, Bs, Bpow2, rshift, R;
-    int32_t tile;              // particles per tile (2048 or 512): part of the arithmetic specification
+    int32_t tile;              // particles per tile (2048, 1024 or 512): part of the arithmetic specification
     int32_t exp_table;         // 1: the bootstrap filter's table exp in the level-2 rescale (k_level2_plan / k_shard_plan serve
                                // the Liu-West filter too, whose weight arithmetic uses the Taylor exp: 0)
     int32_t t, yi, gi, Tcap;   // t: time index (RNG counter, schedule); yi / gi: rows of y / gamma tables

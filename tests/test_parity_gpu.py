@@ -222,7 +222,7 @@ def test_block_size_tuning_is_result_invariant(sa, oracle, spy):
     bank.close()
 
 
-@pytest.mark.parametrize("tile", [512, 2048])
+@pytest.mark.parametrize("tile", [512, 1024, 2048])
 @pytest.mark.parametrize("n,rs,model", [(2049, 0, 0), (5000, 0, 0), (5000, 1, 1), (40000, 0, 0), (40000, 2, 2), (70000, 3, 0), (300000, 0, 1)])
 def test_tile_sizes_against_oracle(sa, oracle, spy, tile, n, rs, model):
     """Both tile sizes, chosen explicitly (the default is by N): particles, integer cdf, ancestors, tile sums and per-step
@@ -249,6 +249,28 @@ def test_tile_sizes_against_oracle(sa, oracle, spy, tile, n, rs, model):
     per_steps = None
     ll = bank.run_series(y, z)
     assert_bits_equal(bank.per_step()[1], oracle.Filter(model, n, th, 9, rep=1, resampler=rs, tile=tile).run_series(y, z)[1], "series")
+    bank.close()
+
+
+def test_default_tile_rule_matches_the_oracle(sa, oracle):
+    """The tile size is part of the arithmetic specification, so the rule that picks it from (N, n_filters) is too."""
+    seen = set()
+    for n, R in [(500, 1), (2048, 4), (2049, 1), (65536, 1), (131072, 1), (131073, 1), (262144, 1), (524288, 1), (524289, 1),
+                 (1 << 20, 1), (65536, 2), (65536, 8), (65536, 9), (16384, 512), (16384, 8), (16384, 32), (3000, 43), (3000, 86), (3000, 200)]:
+        bank = sa.ParticleFilterBank(sa.MODEL_SVOL, n, R, 1)
+        assert bank.tile == oracle.default_tile(n, R), (n, R)
+        seen.add(bank.tile)
+        bank.close()
+    assert seen == {512, 1024, 2048}
+
+
+def test_split_level2_with_1024_particle_tiles(sa, oracle, spy):
+    """More than 2048 tiles of 1024 particles: the level-2 plan kernel path of the middle tile size."""
+    n, th = 2100000, [1.0, 0.95, 0.25]
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, 5, tile=1024)
+    bank.set_params(th)
+    assert bank.n_tiles > 2048
+    assert_bits_equal(bank.run_series(spy[:4]), [oracle.Filter(oracle.MODEL_SVOL, n, th, 5, tile=1024).run_series(spy[:4])[0]], "loglik")
     bank.close()
 
 

@@ -19,7 +19,7 @@ ap.add_argument("--filters", type=int, default=1)
 ap.add_argument("--model", type=int, default=0)
 ap.add_argument("--eager", action="store_true")
 ap.add_argument("--nt", type=int, default=0)
-ap.add_argument("--tile", type=int, default=0, help="particles per tile: 0 = by N, 512 or 2048")
+ap.add_argument("--tile", type=int, default=0, help="particles per tile: 0 = by N, 512, 1024 or 2048")
 ap.add_argument("--sweep", action="store_true")
 ap.add_argument("--split", type=int, default=-1, help="1: force the split level-2 (k_level2_plan), 0: force the in-kernel one")
 ap.add_argument("--lw", action="store_true", help="Liu-West filter instead of the bootstrap filter")
