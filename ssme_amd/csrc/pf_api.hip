@@ -36,6 +36,7 @@ struct ssme_pf_s {
     int32_t *l2_lo, *l2_hi;
     size_t lds_bytes_big, lds_bytes_plan;
     double* yz_step;         // device [2]: y and z of the step API, uploaded by ONE copy
+    int32_t* ticket;         // device [R]: arrival counters of the step API's in-kernel accounting (zero between launches)
     double* pin;             // pinned, device-mapped host staging: [2 .. 2+R) log conditional likelihoods of the step API (written by the accounting kernel)
     double* pin_dev;         // the same memory as the device sees it
     int gamma_t0, gamma_rows;   // step API: the Gamma tables hold time indices gamma_t0 .. gamma_t0 + gamma_rows - 1
@@ -83,6 +84,8 @@ static int fail(ssme_pf_handle h, int code, const char* what, hipError_t e) {
 // Wait for a stream with the latency of a poll: hipStreamSynchronize spins only briefly and then sleeps on an interrupt,
 // which adds ~200 us to a filter() call whose kernels take longer than that window (measured: 512 filters x 2^14
 // particles, 146 vs 420 us per call).  Poll for up to ~5 ms, then fall back to the blocking wait.
+constexpr uint64_t kStepPending = 0x7ff8a5a5c3c3e1e1ull;     // "result not written yet" in the step API's mapped result buffer
+
 static hipError_t wait_stream_low_latency(hipStream_t s) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -90,6 +93,25 @@ static hipError_t wait_stream_low_latency(hipStream_t s) {
         if (q != hipErrorNotReady) return q;
         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) return hipStreamSynchronize(s);
     }
+}
+
+// Step APIs: the R results are awaited where they land.  The host marks the mapped result slots kStepPending (a NaN
+// payload no computation produces) before the launch and polls them instead of the stream's completion signal, which
+// trails the kernel's last store by its end-of-kernel cache write-back.  The stream stays ordered: the next call
+// queues behind this one.  A launch that takes longer than 5 ms falls back to the stream (and reports its errors).
+static void mark_results_pending(double* slots, int R) {
+    volatile uint64_t* res = reinterpret_cast<volatile uint64_t*>(slots);
+    for (int r = 0; r < R; ++r) res[r] = kStepPending;
+}
+static hipError_t wait_results(hipStream_t s, const double* slots, int R) {
+    const volatile uint64_t* res = reinterpret_cast<const volatile uint64_t*>(slots);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (int r = 0; r < R;) {
+        if (res[r] != kStepPending) { ++r; continue; }
+        if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) return hipStreamSynchronize(s);
+    }
+    return hipSuccess;
 }
 
 static int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
@@ -214,7 +236,7 @@ static void launch_k(ssme_pf_handle h, const StepArgs& a, dim3 grid, size_t lds)
 // outputs) have their own instantiations; returns the RS template argument or -1 for the general kernel
 static int hot_config(ssme_pf_handle h, const StepArgs& a) {
     if (g_grant_only) return g_grant_only - 2;                       // 1 -> -1 (general), 2 -> 0, 3 -> 1
-    if (h->cfg.resamp_sched != 1 || a.t <= 0 || a.anc || a.logw) return -1;
+    if (h->cfg.resamp_sched != 1 || a.t <= 0 || a.anc || a.logw || a.ticket) return -1;
     return h->cfg.resampler == SSME_RESAMP_MULTINOMIAL ? 0 : (h->cfg.resampler == SSME_RESAMP_SYSTEMATIC ? 1 : -1);
 }
 
@@ -303,7 +325,10 @@ static void enqueue_step(ssme_pf_handle h, int t, int yi, int gi, bool has_z, bo
                          bool from_step_staging = false) {
     StepArgs a = step_args(h);
     a.z = has_z ? h->zbuf : nullptr;
-    if (from_step_staging) { a.by_value = 1; a.y_now = h->pin[0]; a.z_now = has_z ? h->pin[1] : 0.0; }
+    if (from_step_staging) {
+        a.by_value = 1; a.y_now = h->pin[0]; a.z_now = has_z ? h->pin[1] : 0.0;
+        if (!h->split_l2) { a.ticket = h->ticket; a.ll_host = h->pin_dev + 2; }     // accounting inside the step kernel (its last workgroup)
+    }
     a.per_step = record_per_step ? h->per_step : nullptr;
     a.t = t; a.yi = yi; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
     if (h->split_l2 && t > 0) launch_plan(h, t, gi, true, finalize_prev, record_per_step);
@@ -484,6 +509,8 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
         HIPCHK(hipMalloc(&h->exp_out, sizeof(double) * ((size_t)(kMaxFunctionals + 1) * h->R + kMaxFunctionals + 1)));
         HIPCHK(hipMalloc(&h->keybuf, sizeof(uint32_t) * 2));
         HIPCHK(hipMalloc(&h->yz_step, sizeof(double) * 2));
+        HIPCHK(hipMalloc(&h->ticket, sizeof(int32_t) * h->R));
+        HIPCHK(hipMemsetAsync(h->ticket, 0, sizeof(int32_t) * h->R, h->stream));
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pin), sizeof(double) * (2 + (size_t)h->R + 64 + 8), hipHostMallocMapped));   // + 128 ints for the shard plan + 8 swarm aggregates
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_dev), h->pin, 0));
         int rc2 = upload_key(h);
@@ -505,7 +532,7 @@ int ssme_pf_destroy(ssme_pf_handle h) {
     h->stream = h->own_stream;
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     void* bufs[] = {h->x[0], h->x[1], h->cdf[0], h->cdf[1], h->tsum[0], h->tsum[1], h->tmax[0], h->tmax[1], h->logw,
-                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_lo, h->l2_hi, h->yz_step, h->exp_part, h->exp_out, h->wscratch,
+                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_lo, h->l2_hi, h->yz_step, h->ticket, h->exp_part, h->exp_out, h->wscratch,
                     h->sh_x[0], h->sh_x[1], h->sh_c[0], h->sh_c[1], h->sh_loc, h->sh_raw, h->sh_tsum, h->sh_tmax, h->sh_winx, h->sh_winc, h->sh_flag};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->pin) hipHostFree(h->pin);
@@ -929,7 +956,8 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
         if (rc != SSME_OK) return rc;
     }
     // y and z travel in the kernel arguments; the R results come back through device-mapped pinned memory, written by the
-    // accounting kernel itself: a filter() call is two launches and a poll, no copy operation in either direction
+    // last workgroup of the step kernel itself: a filter() call is one launch and a poll (two launches with the split
+    // level-2 of very large filters), no copy operation in either direction
     h->pin[0] = *y; h->pin[1] = z ? *z : 0.0;
     // Gamma tables are drawn kStepGammaChunk time steps at a time (data independent), so that the two table launches are paid
     // once per chunk and not once per filter() call
@@ -941,11 +969,12 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
         }
         gi = h->t - h->gamma_t0;
     }
+    mark_results_pending(h->pin + 2, h->R);
     enqueue_step(h, h->t, 0, gi, z != nullptr, /*finalize_prev=*/false, /*per_step=*/false, /*from_step_staging=*/true);
-    launch_kf(h, h->t, false, h->pin_dev + 2);
+    if (h->split_l2) launch_kf(h, h->t, false, h->pin_dev + 2);
     HIPCHK(hipGetLastError());
     h->t += 1;
-    HIPCHK(wait_stream_low_latency(h->stream));
+    HIPCHK(wait_results(h->stream, h->pin + 2, h->R));
     if (out) for (int r = 0; r < h->R; ++r) out[r] = h->pin[2 + r];
     return SSME_OK;
 }
@@ -2039,10 +2068,11 @@ int ssme_lw_step(ssme_lw_handle h, const double* y, const double* z, double* out
         }
         gi = h->t - h->gamma_t0;
     }
+    mark_results_pending(h->pin, h->R);
     lw_enqueue_step(h, h->t, 0, gi, false, /*finalize_prev=*/false, yz);
     lw_enqueue_finalize(h, h->t, false, h->pin_dev);          // the step API accounts each step right away
     LWCHK(hipGetLastError());
-    LWCHK(wait_stream_low_latency(h->stream));
+    LWCHK(wait_results(h->stream, h->pin, h->R));
     if (out) for (int r = 0; r < h->R; ++r) out[r] = h->pin[r];
     h->t += 1;
     return SSME_OK;

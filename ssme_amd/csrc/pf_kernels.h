@@ -104,6 +104,7 @@ struct StepArgs {
     int32_t win_tile0;         // global id of the first SOURCE tile held in x_in / cdf_in (0 otherwise)
     int32_t win_tiles;         // C++ shard driver, fixed-halo path: tiles held in the source window (0: unchecked)
     int32_t* win_flag;         // ... and where to record that some output tile's sources left it ([0] flag), or null
+    int32_t* ticket;           // step API: [R] arrival counters; the last workgroup of a filter accounts the step in the same launch (null: kf_finalize does)
     // split level-2 (filters of more than 2048 tiles, or forced for tests): written by k_level2_plan, read by k_filter_step<..,true>
     double* l2_T;              // [R][Bs] inclusive prefixes T'_b of the rescaled tile sums
     double* l2_R;              // [R][Bs] A_b / A'_b
@@ -915,9 +916,62 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     }
     STAMP(a, 10);
     PRIO_AT(10);
+    bool fused_accounting = false;
+    if constexpr (!HOT && !BIG) fused_accounting = a.ticket != nullptr;
     if (tid == 0) {
-        a.tsum_out[(size_t)r * a.Bs + (b - a.tile0)] = total;
-        a.tmax_out[(size_t)r * a.Bs + (b - a.tile0)] = mb;
+        double* ts = a.tsum_out + (size_t)r * a.Bs + (b - a.tile0);
+        double* tm = a.tmax_out + (size_t)r * a.Bs + (b - a.tile0);
+        if (fused_accounting) {      // device-coherent stores: another workgroup (another XCD, another L2) reads them in this launch
+            __hip_atomic_store(ts, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tm, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else { *ts = total; *tm = mb; }
+    }
+    if constexpr (!HOT && !BIG) {
+        if (fused_accounting) {
+            // Step API (mod.filter(y); mod.getLogCondLike()): the workgroup that arrives last at its filter's counter does
+            // what kf_finalize does in a second launch -- level-2 of the weights just written, log p(y_t | y_{1:t-1}) --
+            // so that a filter() call is ONE launch.  Only the tile sums / maxima cross workgroups: they are written and read
+            // with device-scope accesses and ordered by the counter, so no cache write-back of the particle arrays is needed.
+            __shared__ int lds_last;
+            if (tid == 0) {
+                int last = 1;
+                if (gridDim.x > 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the two stores above have completed
+                    last = __hip_atomic_fetch_add(a.ticket + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+                }
+                lds_last = last;
+            }
+            __syncthreads();
+            if (lds_last) {
+                constexpr int NE2 = 2048 / NT;
+                double A2[NE2], M2[NE2], Ap2[NE2], Tinc2[NE2], S2, m2;
+#pragma unroll
+                for (int e = 0; e < NE2; ++e) {
+                    const int j = e * NT + tid;
+                    A2[e] = 0.0; M2[e] = 0.0;
+                    if (j < a.B) {
+                        A2[e] = __hip_atomic_load(a.tsum_out + (size_t)r * a.Bs + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        M2[e] = __hip_atomic_load(a.tmax_out + (size_t)r * a.Bs + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                level2_scan<NT, true>(A2, M2, a.B, a.rshift, m2, Ap2, Tinc2, S2, lds_d1, lds_seg_l2, lds_etab);
+                if (tid == 0) {
+                    FilterScalars* sc = a.scal + r;
+                    const bool resample_now = ((a.t + 1) % a.resamp_sched == 0);
+                    const double Sd = (S2 > 0.0) ? dldexp(S2, -a.rshift) : dnan();
+                    const double lse = m2 + dlog(Sd);
+                    const double ll = lse - sc->prev;
+                    sc->m = m2;
+                    sc->S = S2;
+                    sc->last_ll = ll;
+                    sc->loglik = sc->loglik + ll;
+                    sc->prev = resample_now ? a.logN : lse;
+                    if (a.per_step) a.per_step[(size_t)r * a.Tcap + a.t] = ll;
+                    if (gridDim.x > 1) a.ticket[r] = 0;
+                    if (a.ll_host) a.ll_host[r] = ll;
+                }
+            }
+        }
     }
 #ifdef SSME_ABLATE
     __syncthreads();

@@ -25,6 +25,20 @@ static void run(const std::vector<vec1>& data, const char* label) {
     std::printf("filter() N=%s: %.1f us per call (loglik %.6f)\n", label, us, ll);
 }
 
+template <std::size_t N>
+static void run_lw(const std::vector<vec1>& data, const char* label) {
+    ssme_gpu::gpu_options o;
+    o.seed = 1;
+    ssme_gpu::svol_lw_1_par_gpu<N> mod(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, 0, o, 0);   // test/test_liu_west.cpp:160-200
+    double ll = 0.0;
+    for (int t = 0; t < 64; ++t) { mod.filter(data[t], vec1{t ? data[t - 1].v : 0.0}); ll += mod.getLogCondLike(); }
+    const int K = 500;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < K; ++t) { mod.filter(data[64 + t], data[63 + t]); ll += mod.getLogCondLike(); }
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / K;
+    std::printf("Liu-West filter() N=%s: %.1f us per call (loglik %.6f)\n", label, us, ll);
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::vector<vec1> data;
@@ -35,5 +49,7 @@ int main(int argc, char** argv) {
     run<4096>(data, "4096");
     run<65536>(data, "2^16");
     run<1048576>(data, "2^20");
+    run_lw<500>(data, "500");
+    run_lw<65536>(data, "2^16");
     return 0;
 }
