@@ -180,6 +180,11 @@ static StepArgs step_args(ssme_pf_handle h) {
         a.prio_mode = (blocks <= 2L * h->num_cus) ? 1 : 2;
         static const char* force = getenv("SSME_PRIO_MODE");         // measurement aid: 0 none, 1 / 2 the two schedules, 3.. experimental
         if (force) a.prio_mode = atoi(force);
+        // measured (profiles/r02_stream_stores.txt): 2048-particle tiles gain 7-10 % up to 3 workgroups per CU, nothing
+        // or -3 % beyond; the smaller tiles (mid-size handles, latency bound) are indifferent
+        a.stream_stores = (h->tile == kTile && blocks <= 3L * h->num_cus) ? 1 : 0;
+        static const char* force_ss = getenv("SSME_STREAM_STORES");  // measurement aid: 0 / 1
+        if (force_ss) a.stream_stores = atoi(force_ss);
     }
 #ifdef SSME_ABLATE
     { const char* e = getenv("SSME_ABLATE_MASK"); a.ablate = e ? atoi(e) : 0; }

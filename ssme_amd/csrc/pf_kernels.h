@@ -111,6 +111,7 @@ struct StepArgs {
     int32_t* l2_lo;            // [R][Bs] first / last source tile of every output tile's targets
     int32_t* l2_hi;
     int32_t prio_mode;         // wave-priority schedule of k_filter_step (prio_at): 0 none, 1 single residency wave, 2 several
+    int32_t stream_stores;     // 1: particles and cdf are stored non-temporally (grids that are resident all at once)
     const uint32_t* keyp;      // [2] Philox key (the seed), device resident so that a captured graph survives ssme_pf_set_seed
     uint32_t first_filter;
     double logN;
@@ -496,6 +497,17 @@ __device__ __forceinline__ void prio_at(int mode, int idx) {
 // then the Box-Muller radii are computed while they arrive; the ancestor states are requested,
 // then the Box-Muller angles are computed while they arrive.
 // ---------------------------------------------------------------------------------------
+// 16-byte store of a particle pair.  stream = 1: non-temporal, the lines leave the XCD's L2 as they are written.  A launch
+// whose workgroups are all resident at once ends with every L2 full of dirty lines (2 MB per XCD at N = 2^20), and the
+// write-back at the end of the kernel is then serial time: 15.9 -> 14.3 us per step at N = 2^20.  Grids of several
+// residency waves overlap that write-back with the next workgroups' arithmetic and lose 3 % with streaming stores.
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_pair(double* p, double v0, double v1, int stream) {
+    if (stream) {
+        f64x2_t v = {v0, v1};
+        __builtin_nontemporal_store(v, reinterpret_cast<f64x2_t*>(p));
+    } else *reinterpret_cast<double2*>(p) = make_double2(v0, v1);
+}
 template <int MODEL, int NT, bool BIG = false, int TILE = kTile, int RS = -1>
 __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     constexpr int NK = TILE / 2 / NT;
@@ -882,7 +894,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             if (valid) { nan = nan || (l != l); mx = (l > mx) ? l : mx; }
         }
         const size_t idx = rowoff + (size_t)(i0 - out0);
-        *reinterpret_cast<double2*>(a.x_out + idx) = make_double2(xo[0], xo[1]);
+        store_pair(a.x_out + idx, xo[0], xo[1], a.stream_stores);
         if (logw_p) *reinterpret_cast<double2*>(logw_p + idx) = make_double2(lg[k][0], lg[k][1]);
     }
     STAMP(a, 8);
@@ -912,7 +924,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int i0 = i_first + (k * NT + tid) * 2;
-        *reinterpret_cast<double2*>(a.cdf_out + rowoff + (i0 - out0)) = make_double2(inc[k][0], inc[k][1]);
+        store_pair(a.cdf_out + rowoff + (i0 - out0), inc[k][0], inc[k][1], a.stream_stores);
     }
     STAMP(a, 10);
     PRIO_AT(10);

@@ -1,7 +1,9 @@
 set -e
 mkdir -p gpurun_out
-python -m pytest tests -x -q -m gpu > gpurun_out/r2_t9.log 2>&1 || true
-tail -4 gpurun_out/r2_t9.log
-g++ -O2 -std=c++17 -Iinclude tools/step_latency.cpp -Lssme_amd -l:libssme_pf.so -Wl,-rpath,$PWD/ssme_amd -o tools/step_latency
-./tools/step_latency tests/golden/spy_returns.csv > gpurun_out/r2_lat9.txt 2>&1
-cat gpurun_out/r2_lat9.txt
+for n in 1048576 2097152; do
+  for ss in 0 1 0 1; do
+    echo "LW n=$n stream=$ss" >> gpurun_out/r2_ss_lw2.log
+    SSME_LW_STREAM_STORES=$ss python tools/prof_run.py --lw --T 64 --passes 3 --n $n >> gpurun_out/r2_ss_lw2.log 2>&1
+  done
+done
+grep -v amdgpu.ids gpurun_out/r2_ss_lw2.log | cut -c1-90
