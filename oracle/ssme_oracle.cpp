@@ -380,8 +380,11 @@ struct Filter {
     uint64_t Sint;
     // Bootstrap filter (k_filter_step): ONE Philox call per particle pair and time step, counter (pair, t, filter,
     // STREAM_PROP): words 0-1 -> Box-Muller (radius uniform 40 bits, angle 24 bits), words 2-3 -> the pair's two
-    // exponential spacings (32 bits each); logs by o_log_u.  false: the Liu-West filter's streams (52-bit uniforms, o_log).
+    // exponential spacings (32 bits each); logs by o_log_u, weight exps by the table form.  The Liu-West filter's two draws
+    // use the same construction on their own counter streams (pair_stream).  false: 52-bit uniforms, o_log, Taylor exp
+    // (the round-1 arithmetic; kept for the accuracy comparisons of tests/test_oracle_cpu.py).
     bool bootstrap_draws = false;
+    int pair_stream = STREAM_PROP;     // the counter's stream word of that one call (the Liu-West draws use their own)
     // particles per tile (2048, 1024 or 512): weights are fixed point relative to their TILE's maximum and the multinomial
     // resampler draws one Gamma variate per tile, so the tile size is part of the specification.  The device's rule when
     // the caller does not choose (pf_api.hip: default_tile): 2048 for N <= 2048 and N > 2^18, 512 in between.
@@ -402,7 +405,7 @@ struct Filter {
 
     // standard normal for particle i at time tt (Box-Muller on the pair i>>1)
     double normal(int i, int tt) const {
-        const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, STREAM_PROP};
+        const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, (uint32_t)(bootstrap_draws ? pair_stream : STREAM_PROP)};
         uint32_t o[4]; philox4x32_10(ctr, key, o);
         if (bootstrap_draws) {
             const double rad = std::sqrt(-2.0 * o_log_u(u01_mid40(o[0], o[1])));
@@ -417,7 +420,7 @@ struct Filter {
     // exponential spacing E_i of the multinomial resampler at time tt
     double spacing(int i, int tt, int stream) const {
         if (bootstrap_draws) {
-            const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, STREAM_PROP};
+            const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, (uint32_t)pair_stream};
             uint32_t o[4]; philox4x32_10(ctr, key, o);
             return -o_log_u(u01_mid32(o[2 + (i & 1)]));
         }
@@ -686,9 +689,9 @@ enum { STREAM_LW_PRIOR = 3 /* and 4 */, STREAM_LW_JIT = 5 /* and 6 */, STREAM_LW
 inline double tr_inv(int kind, double tp) {                 // parameters.h inv_trans
     switch (kind) {
         case TR_NULL: return tp;
-        case TR_TWICE_FISHER: return (tp >= 0.0) ? 2.0 / (1.0 + o_exp(-tp)) - 1.0 : 1.0 - 2.0 / (1.0 + o_exp(tp));
-        case TR_LOGIT: return (tp >= 0.0) ? 1.0 / (1.0 + o_exp(-tp)) : o_exp(tp) / (1.0 + o_exp(tp));
-        default: return o_exp(tp);
+        case TR_TWICE_FISHER: return (tp >= 0.0) ? 2.0 / (1.0 + o_exp_t(-tp)) - 1.0 : 1.0 - 2.0 / (1.0 + o_exp_t(tp));
+        case TR_LOGIT: return (tp >= 0.0) ? 1.0 / (1.0 + o_exp_t(-tp)) : o_exp_t(tp) / (1.0 + o_exp_t(tp));
+        default: return o_exp_t(tp);
     }
 }
 inline double tr_fwd(int kind, double p) {                  // parameters.h trans
@@ -704,11 +707,11 @@ inline double tr_fwd(int kind, double p) {                  // parameters.h tran
 inline double lw_logg(double y, double x) {
     const double hl = 0.5 * x;
     if (hl < -745.1332191019412) return NEG_INF;
-    return (-hl - HALF_LOG_2PI) - 0.5 * ((y * y) * o_exp(-x));
+    return (-hl - HALF_LOG_2PI) - 0.5 * ((y * y) * o_exp_t(-x));
 }
 inline double lw_propmu(double x, double z, const double* tu) {           // test_liu_west.cpp:93-101
     double xt = tu[1] + tu[0] * (x - tu[1]);
-    xt = xt + ((z * tu[3]) * tu[2]) * o_exp(-0.5 * x);
+    xt = xt + ((z * tu[3]) * tu[2]) * o_exp_t(-0.5 * x);
     return xt;
 }
 
@@ -774,6 +777,10 @@ struct LWFilter {
         N = N_; rep = rep_;
         key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32);
         double dummy[3] = {1.0, 0.5, 0.1};
+        // exact-cdf machinery with the table exp; spacings = words 2-3 of ONE call per particle pair: the resampling draw's
+        // counter stream is STREAM_RESAMP, the k draw's STREAM_LW_K (whose words 0-1 are the pair's state normals of fSamp)
+        cdfA.bootstrap_draws = true; cdfA.pair_stream = STREAM_LW_K;
+        cdfB.bootstrap_draws = true; cdfB.pair_stream = STREAM_RESAMP;
         cdfA.init(MODEL_SVOL, N, RESAMP_MULTINOMIAL, 1, seed, rep, dummy);
         cdfB.init(MODEL_SVOL, N, RESAMP_MULTINOMIAL, 1, seed, rep, dummy);
         B = cdfA.B; Npad = cdfA.Npad;
@@ -794,7 +801,21 @@ struct LWFilter {
         double sn, cs; o_sincos2pi(u01_co(o[2], o[3]), &sn, &cs);
         *z0 = rad * cs; *z1 = rad * sn;
     }
-    double state_normal(int i, int tt) const { double z0, z1; normal2(i >> 1, tt, STREAM_PROP, &z0, &z1); return (i & 1) ? z1 : z0; }
+    // t = 0 (k_lw_init): 52-bit Box-Muller on (pair, 0, filter, STREAM_PROP).  t >= 1: words 0-1 of the pair's STREAM_LW_K call
+    double state_normal(int i, int tt) const {
+        if (tt > 0) return cdfA.normal(i, tt);
+        double z0, z1; normal2(i >> 1, tt, STREAM_PROP, &z0, &z1); return (i & 1) ? z1 : z0;
+    }
+    // the four jitter normals of particle i from ONE call: Box-Muller on (words 0-1) and on (words 2-3), 40-bit radius
+    // uniform and 24-bit angle each, table log
+    void jitter4(int i, int tt, double* e) const {
+        uint32_t o[4]; words(i, tt, STREAM_LW_JIT, o);
+        for (int h = 0; h < 2; ++h) {
+            const double rad = std::sqrt(-2.0 * o_log_u(u01_mid40(o[2 * h], o[2 * h + 1])));
+            double sn, cs; o_sincos2pi(u01_lo24(o[2 * h + 1]), &sn, &cs);
+            e[2 * h] = rad * cs; e[2 * h + 1] = rad * sn;
+        }
+    }
 
     double step(double y, double z) {
         const double logN = o_log((double)N);
@@ -880,8 +901,7 @@ struct LWFilter {
             for (int i = 0; i < N; ++i) {
                 const int k = (int)kidx[i];
                 double e[DP];
-                normal2(i, t, STREAM_LW_JIT, &e[0], &e[1]);
-                normal2(i, t, STREAM_LW_JIT + 1, &e[2], &e[3]);
+                jitter4(i, t, e);
                 double tn[DP], tu[DP];
                 for (int d = 0; d < DP; ++d) {
                     const double mm = a_shrink * thr[d][k] + (1.0 - a_shrink) * thetabar[d];
@@ -891,7 +911,7 @@ struct LWFilter {
                     tu[d] = tr_inv(trans[d], tn[d]);
                 }
                 const double xk = xr[k];
-                const double mean = (tu[1] + tu[0] * (xk - tu[1])) + ((z * tu[3]) * tu[2]) * o_exp(-0.5 * xk);     // fSamp :114-121
+                const double mean = (tu[1] + tu[0] * (xk - tu[1])) + ((z * tu[3]) * tu[2]) * o_exp_t(-0.5 * xk);     // fSamp :114-121
                 const double xn = mean + state_normal(i, t) * (tu[2] * std::sqrt(1.0 - tu[3] * tu[3]));
                 x[i] = xn;
                 for (int d = 0; d < DP; ++d) th[d][i] = tn[d];

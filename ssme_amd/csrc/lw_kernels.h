@@ -80,10 +80,10 @@ struct LwArgs {
 
 // ---- parameter transforms (parameters.h inv_trans / trans), libm-free ------------------------------------
 // `kind` is uniform (a kernel argument), so the switch is a scalar branch; exp(-|tp|) serves both signs.
-__device__ __forceinline__ double tr_inv(int kind, double tp) {
+__device__ __forceinline__ double tr_inv(int kind, double tp, const ExpTabEntry* etab) {
     if (kind == TR_NULL) return tp;
-    if (kind == TR_LOG) return dexp(tp);
-    const double t = dexp((tp >= 0.0) ? -tp : tp);
+    if (kind == TR_LOG) return dexp_scaled_t(tp, 0, etab);
+    const double t = dexp_scaled_t((tp >= 0.0) ? -tp : tp, 0, etab);
     const double den = 1.0 + t;
     if (kind == TR_LOGIT) return ((tp >= 0.0) ? 1.0 : t) / den;       // one division: the numerator is selected first
     const double q = 2.0 / den;
@@ -109,15 +109,15 @@ __device__ __forceinline__ void th_store_pair(double* th, size_t idx0, const dou
     p[2] = make_double2(t[0][1], t[1][1]); p[3] = make_double2(t[2][1], t[3][1]);
 }
 // model callbacks of svol_lw_1_par
-__device__ __forceinline__ double lw_logg(double y, double x) {                // test_liu_west.cpp:132-136, kernel form
+__device__ __forceinline__ double lw_logg(double y, double x, const ExpTabEntry* etab) {      // test_liu_west.cpp:132-136, kernel form
     const double hl = 0.5 * x;
-    double v = (-hl - SSME_HALF_LOG_2PI) - 0.5 * ((y * y) * dexp(-x));
+    double v = (-hl - SSME_HALF_LOG_2PI) - 0.5 * ((y * y) * dexp_scaled_t(-x, 0, etab));
     if (hl < -745.1332191019412) v = -dinf();
     return v;
 }
-__device__ __forceinline__ double lw_propmu(double x, double z, const double (&tu)[kDP]) {    // :93-101
+__device__ __forceinline__ double lw_propmu(double x, double z, const double (&tu)[kDP], const ExpTabEntry* etab) {    // :93-101
     double xt = tu[1] + tu[0] * (x - tu[1]);
-    xt = xt + ((z * tu[3]) * tu[2]) * dexp(-0.5 * x);
+    xt = xt + ((z * tu[3]) * tu[2]) * dexp_scaled_t(-0.5 * x, 0, etab);
     return xt;
 }
 
@@ -129,6 +129,7 @@ __device__ __forceinline__ double lw_propmu(double x, double z, const double (&t
 struct LwLds {
     double* lds_T; double* lds_R; double* lds_stage;     // dynamic LDS
     double* seg_a; double* seg_l2; double* d1; int* cnt;
+    const LogTabEntry* ltab; const ExpTabEntry* etab;    // dlog_u / dexp_scaled_t tables in LDS
 };
 
 // level-2 results of one draw as k_level2_plan left them (split level-2)
@@ -136,8 +137,8 @@ struct L2View { const double* T; const double* R; const int32_t* lo; const int32
 
 template <bool BIG>
 __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax, const double* cdf, int B, int Bpow2, int rshift,
-                                          int N, int b, double gam, double pgam, double pgam_next, double G, int spacing_stream,
-                                          uint32_t t, uint32_t rep, uint32_t k0, uint32_t k1, const LwLds& L, int (&idx)[2][2],
+                                          int N, int b, double gam, double pgam, double pgam_next, double G,
+                                          const u32x4 (&draw)[2], const LwLds& L, int (&idx)[2][2],
                                           double& m_out, double& S_out, int win_tile0, const L2View& v, int win_tiles = 0,
                                           int32_t* win_flag = nullptr) {
     constexpr int NT = kLwNT, NK = 2, NE = 4;
@@ -155,7 +156,7 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
         level2_load<NT>(tsum, tmax, B, A2, M2);
         if (tid == 0) { L.cnt[0] = 0; L.cnt[1] = 0; }
         double Ap[NE], Tinc[NE], m, S;
-        level2_scan<NT>(A2, M2, B, rshift, m, Ap, Tinc, S, L.d1, L.seg_l2);
+        level2_scan<NT, true>(A2, M2, B, rshift, m, Ap, Tinc, S, L.d1, L.seg_l2, L.etab);
         m_out = m; S_out = S;
         t_scale = S / G;
         const double t_lo = __builtin_ceil(pgam * t_scale);
@@ -211,8 +212,8 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int i0 = i_first + (k * NT + tid) * 2;
-        const u32x4 o = philox4x32_10((uint32_t)(i0 >> 1), t, rep, (uint32_t)spacing_stream, k0, k1);
-        const double e0 = -dlog_pn(u01_oc(o.v0, o.v1)), e1 = -dlog_pn(u01_oc(o.v2, o.v3));
+        double e0, e1;
+        pair_spacings(draw[k], L.ltab, &e0, &e1);          // words 2-3 of the pair's draw (32-bit uniforms, table log)
         qe[k][0] = (i0 < N) ? __builtin_rint(e0 * 34359738368.0) : 0.0;
         qe[k][1] = (i0 + 1 < N) ? __builtin_rint(e1 * 34359738368.0) : 0.0;
     }
@@ -309,13 +310,13 @@ __device__ __forceinline__ void lw_level2_only(const double* tsum, const double*
         constexpr int NT = kLwNT, NE = 4;
         double A2[NE], M2[NE], Ap[NE], Tinc[NE];
         level2_load<NT>(tsum, tmax, B, A2, M2);
-        level2_scan<NT>(A2, M2, B, rshift, m_out, Ap, Tinc, S_out, L.d1, L.seg_l2);
+        level2_scan<NT, true>(A2, M2, B, rshift, m_out, Ap, Tinc, S_out, L.d1, L.seg_l2, L.etab);
     }
 }
 
 // log-weights lg[k][c] of this tile -> tile max, fixed-point weights, exact tile scan; stores cdf / tile sum / tile max
 __device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int N, int i_first, double* cdf_row, double* tsum_row,
-                                             double* tmax_row, int b, double* lds_d, double* lds_seg, int tile0 = 0) {
+                                             double* tmax_row, int b, double* lds_d, double* lds_seg, const ExpTabEntry* etab, int tile0 = 0) {
     constexpr int NT = kLwNT, NK = 2;
     const int tid = threadIdx.x;
     __builtin_amdgcn_s_setprio(0);
@@ -334,8 +335,8 @@ __device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int N, in
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int i0 = i_first + (k * NT + tid) * 2;
-        q[k][0] = (i0 < N) ? __builtin_rint(dexp_scaled(lg[k][0] - mb, kTileShift)) : 0.0;
-        q[k][1] = (i0 + 1 < N) ? __builtin_rint(dexp_scaled(lg[k][1] - mb, kTileShift)) : 0.0;
+        q[k][0] = (i0 < N) ? __builtin_rint(dexp_scaled_t(lg[k][0] - mb, kTileShift, etab)) : 0.0;
+        q[k][1] = (i0 + 1 < N) ? __builtin_rint(dexp_scaled_t(lg[k][1] - mb, kTileShift, etab)) : 0.0;
     }
     block_scan_f64<NT, NK>(q, inc, total, lds_seg);
 #pragma unroll
@@ -353,9 +354,15 @@ __device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int N, in
     __shared__ double lds_d1[16];                                                                         \
     __shared__ double lds_d2[16];                                                                         \
     __shared__ int lds_cnt[2];                                                                            \
+    __shared__ LogTabEntry lds_ltab[SSME_LOG_TABLE_SIZE];                                                 \
+    __shared__ ExpTabEntry lds_etab[SSME_EXP_TABLE_SIZE];                                                 \
+    load_log_table<kLwNT>(lds_ltab);                                                                      \
+    load_exp_table<kLwNT>(lds_etab);                                                                      \
     LwLds L;                                                                                              \
     L.lds_T = reinterpret_cast<double*>(smem); L.lds_R = L.lds_T + nT2; L.lds_stage = L.lds_T + 2 * nT2;  \
-    L.seg_a = lds_seg_a; L.seg_l2 = lds_seg_l2; L.d1 = lds_d1; L.cnt = lds_cnt;
+    L.seg_a = lds_seg_a; L.seg_l2 = lds_seg_l2; L.d1 = lds_d1; L.cnt = lds_cnt;                           \
+    L.ltab = lds_ltab; L.etab = lds_etab;                                                                 \
+    __syncthreads();
 
 // ---------------------------------------------------------------------------------------
 // t = 0: prior draws, q1Samp, weights (liu_west_filter.h:1103-1122).  grid = (B, R), block = 512
@@ -364,6 +371,9 @@ __global__ __launch_bounds__(kLwNT) void k_lw_init(const LwArgs a) {
     constexpr int NT = kLwNT, NK = 2;
     __shared__ double lds_seg_c[16];
     __shared__ double lds_d2[16];
+    __shared__ ExpTabEntry lds_etab[SSME_EXP_TABLE_SIZE];
+    load_exp_table<kLwNT>(lds_etab);
+    __syncthreads();
     const int tid = threadIdx.x;
     const int gtile = xcd_tile_of_block((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
     const int r = gtile / (int)gridDim.x, b = (gtile - r * (int)gridDim.x) + a.tile0;      // XCD-contiguous (filter, tile) map; global tile id
@@ -389,14 +399,14 @@ __global__ __launch_bounds__(kLwNT) void k_lw_init(const LwArgs a) {
 #pragma unroll
             for (int d = 0; d < kDP; ++d) { tu[d] = a.lo[d] + u[d] * (a.hi[d] - a.lo[d]); tho[d][c] = tr_fwd(a.trans[d], tu[d]); }
             xo[c] = zn[c] * (tu[2] / dsqrt(1.0 - tu[0] * tu[0]));
-            lg[k][c] = lw_logg(y, xo[c]);
+            lg[k][c] = lw_logg(y, xo[c], lds_etab);
             if (i >= a.N) { xo[c] = 0.0; lg[k][c] = -dinf(); for (int d = 0; d < kDP; ++d) tho[d][c] = 0.0; }
         }
         *reinterpret_cast<double2*>(a.xB + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
         if (a.lwB) *reinterpret_cast<double2*>(a.lwB + rowoff + (i0 - out0)) = make_double2(lg[k][0], lg[k][1]);
         th_store_pair(a.thB, rowoff + (size_t)(i0 - out0), tho);
     }
-    lw_store_cdf(lg, a.N, i_first, a.cdfB + rowoff, a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, a.tile0);
+    lw_store_cdf(lg, a.N, i_first, a.cdfB + rowoff, a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, lds_etab, a.tile0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -431,8 +441,13 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
         vB.hi = a.l2B_hi + (size_t)r * a.Bs; vB.m = a.l2B_s[r].m; vB.S = a.l2B_s[r].S;
     }
     if (resampled) {
+        // one Philox call per particle pair: words 2-3 are the pair's exponential spacings (words 0-1 unused in this draw)
+        u32x4 draw[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+            draw[k] = philox4x32_10((uint32_t)(b * (kTile / 2) + k * NT + tid), (uint32_t)a.t, rep, STREAM_RESAMP, a.key0, a.key1);
         lw_select<BIG>(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.cdfB + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
-                       a.gamB[gidx], a.pgamB[gidx], pgam_next, G, STREAM_RESAMP, (uint32_t)a.t, rep, a.key0, a.key1, L, anc, mB, SB,
+                       a.gamB[gidx], a.pgamB[gidx], pgam_next, G, draw, L, anc, mB, SB,
                        a.win_tile0, vB, a.win_tiles, a.win_flag);
     } else {
         lw_level2_only<BIG>(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.B, a.rshift, L, mB, SB, vB);
@@ -476,13 +491,13 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
         for (int c = 0; c < 2; ++c) {
             double tu[kDP];
 #pragma unroll
-            for (int d = 0; d < kDP; ++d) tu[d] = tr_inv(a.trans[d], tt[d][c]);
+            for (int d = 0; d < kDP; ++d) tu[d] = tr_inv(a.trans[d], tt[d][c], lds_etab);
             // the log-weight this particle starts the step with: 0 after a resampling, else the carried second-stage weight
             const bool valid = (i0 + c) < a.N;
             const double lw_old = (resampled || !valid) ? 0.0 : a.lwB[rowoff + (i0 - out0) + c];
             // form 0: first-stage weight :985-991 = carried weight + logG(y | propMu); g1 alone is what stage 2 subtracts (:1041-1043)
             // form 1: no first stage; the carried weight travels to stage 2 in the same buffer
-            g1[c] = (a.form == 0) ? lw_logg(y, lw_propmu(xo[c], z, tu)) : lw_old;
+            g1[c] = (a.form == 0) ? lw_logg(y, lw_propmu(xo[c], z, tu, lds_etab), lds_etab) : lw_old;
             lg[k][c] = (a.form == 0) ? lw_old + g1[c] : lw_old;
             if (!valid) { xo[c] = 0.0; lg[k][c] = -dinf(); g1[c] = -dinf(); }
             // moments of the transformed parameters (:1189-1193); canonical tree: fold the tile halves (k), then the pair (c)
@@ -505,7 +520,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
         const double s = wave_incl_scan_f64(fold[q][0] + fold[q][1]);
         if ((tid & 63) == 63) lds_mom[tid >> 6][q] = s;
     }
-    if (a.form == 0) lw_store_cdf(lg, a.N, i_first, a.cdfA + rowoff, a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, a.tile0);
+    if (a.form == 0) lw_store_cdf(lg, a.N, i_first, a.cdfA + rowoff, a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, lds_etab, a.tile0);
     else __syncthreads();
     // (a barrier after the lds_mom writes either way)
     if (tid < kNMom) {
@@ -561,7 +576,7 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid(const LwArgs a) {
     m = 0.0; S = 0.0;
     if (aux) {
         if (BIG) { m = a.l2A_s[r].m; S = a.l2A_s[r].S; }
-        else level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
+        else level2_scan<kThreads, true>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
     }
     __syncthreads();
     if (tid == 0) {
@@ -623,9 +638,15 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
         vA.T = a.l2A_T + (size_t)r * a.Bs; vA.R = a.l2A_R + (size_t)r * a.Bs; vA.lo = a.l2A_lo + (size_t)r * a.Bs;
         vA.hi = a.l2A_hi + (size_t)r * a.Bs; vA.m = a.l2A_s[r].m; vA.S = a.l2A_s[r].S;
     }
+    // one Philox call per particle pair (counter (pair, t, filter, STREAM_LW_K)): words 0-1 -> the pair's two state normals of
+    // fSamp (Box-Muller as in the bootstrap kernel: 40-bit radius uniform, 24-bit angle), words 2-3 -> the k draw's spacings
+    u32x4 draw[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+        draw[k] = philox4x32_10((uint32_t)(b * (kTile / 2) + k * NT + tid), (uint32_t)a.t, rep, STREAM_LW_K, a.key0, a.key1);
     if (a.form == 0) {
         lw_select<BIG>(a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, a.cdfA + rowoff, a.B, a.Bpow2, a.rshift, a.N, b,
-                       a.gamA[gidx], a.pgamA[gidx], pgam_next, G, STREAM_LW_K, (uint32_t)a.t, rep, a.key0, a.key1, L, kk, mA, SA,
+                       a.gamA[gidx], a.pgamA[gidx], pgam_next, G, draw, L, kk, mA, SA,
                        a.win_tile0, vA, a.win_tiles, a.win_flag);
     } else {
 #pragma unroll
@@ -639,7 +660,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
     for (int k = 0; k < NK; ++k) {
         const int i0 = i_first + (k * NT + tid) * 2;
         double zs[2];
-        normal_pair((uint32_t)(i0 >> 1), (uint32_t)a.t, rep, a.key0, a.key1, &zs[0], &zs[1]);
+        pair_normals(draw[k].v0, draw[k].v1, lds_ltab, &zs[0], &zs[1]);
         double xo[2], tho[kDP][2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -649,15 +670,10 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
             const double lw1k = a.lw1[rowoff + (j - win0)];
             double e[kDP];
             {
+                // the four jitter normals of a particle from ONE call: two Box-Muller pairs, (words 0-1) and (words 2-3)
                 const u32x4 o1 = philox4x32_10((uint32_t)i, (uint32_t)a.t, rep, STREAM_LW_JIT, a.key0, a.key1);
-                const double rad1 = dsqrt(-2.0 * dlog_pn(u01_oc(o1.v0, o1.v1)));
-                double sn, cs;
-                dsincos2pi(u01_co(o1.v2, o1.v3), &sn, &cs);
-                e[0] = rad1 * cs; e[1] = rad1 * sn;
-                const u32x4 o2 = philox4x32_10((uint32_t)i, (uint32_t)a.t, rep, STREAM_LW_JIT + 1, a.key0, a.key1);
-                const double rad2 = dsqrt(-2.0 * dlog_pn(u01_oc(o2.v0, o2.v1)));
-                dsincos2pi(u01_co(o2.v2, o2.v3), &sn, &cs);
-                e[2] = rad2 * cs; e[3] = rad2 * sn;
+                pair_normals(o1.v0, o1.v1, lds_ltab, &e[0], &e[1]);
+                pair_normals(o1.v2, o1.v3, lds_ltab, &e[2], &e[3]);
             }
             double tu[kDP], thrk[kDP];
             th_load(a.thr, rowoff + (size_t)(j - win0), thrk);
@@ -670,13 +686,13 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
 #pragma unroll
                 for (int w = 0; w <= d; ++w) { acc = acc + prop[q] * e[w]; ++q; }
                 tho[d][c] = mm + acc;                                                    // MVN draw, :1026-1027
-                tu[d] = tr_inv(a.trans[d], tho[d][c]);
+                tu[d] = tr_inv(a.trans[d], tho[d][c], lds_etab);
             }
-            const double mean = (tu[1] + tu[0] * (xk - tu[1])) + ((z * tu[3]) * tu[2]) * dexp(-0.5 * xk);       // fSamp :114-121
+            const double mean = (tu[1] + tu[0] * (xk - tu[1])) + ((z * tu[3]) * tu[2]) * dexp_scaled_t(-0.5 * xk, 0, lds_etab);       // fSamp :114-121
             xo[c] = mean + zs[c] * (tu[2] * dsqrt(1.0 - tu[3] * tu[3]));
             // form 0: logG(y | x', theta') - logG(y | propMu_k, m_k)  (:1041-1043);  form 1: carried weight + logG  (:2223-2225,
             // where logFEv - logQEv vanishes: svol_lw_2_par proposes from the transition)
-            lg[k][c] = (a.form == 0) ? lw_logg(y, xo[c]) - lw1k : lw1k + lw_logg(y, xo[c]);
+            lg[k][c] = (a.form == 0) ? lw_logg(y, xo[c], lds_etab) - lw1k : lw1k + lw_logg(y, xo[c], lds_etab);
             if (a.kidx && i < a.N) a.kidx[rowoff + (i - out0)] = (uint32_t)j;
             if (i >= a.N) { xo[c] = 0.0; lg[k][c] = -dinf(); }
         }
@@ -684,7 +700,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
         if (a.lwB) *reinterpret_cast<double2*>(a.lwB + rowoff + (i0 - out0)) = make_double2(lg[k][0], lg[k][1]);
         th_store_pair(a.thB, rowoff + (size_t)(i0 - out0), tho);
     }
-    lw_store_cdf(lg, a.N, i_first, a.cdfB + rowoff, a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, a.tile0);
+    lw_store_cdf(lg, a.N, i_first, a.cdfB + rowoff, a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, lds_etab, a.tile0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -699,7 +715,7 @@ __global__ __launch_bounds__(kThreads) void k_lw_finalize(const LwArgs a) {
     if (BIG) { m = a.l2B_s[r].m; S = a.l2B_s[r].S; }
     else {
         level2_load<kThreads>(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.B, A2, M2);
-        level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
+        level2_scan<kThreads, true>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
     }
     if (tid == 0) {
         LwScalars* sc = a.scal + r;
@@ -738,7 +754,7 @@ __global__ __launch_bounds__(kThreads) void k_lw_param_partials(const LwArgs a) 
         acc[kDP] += w;
         double trec[kDP];
         th_load(a.thB, (size_t)r * a.Npad + i, trec);
-        for (int d = 0; d < kDP; ++d) acc[d] += w * tr_inv(a.trans[d], trec[d]);
+        for (int d = 0; d < kDP; ++d) acc[d] += w * tr_inv(a.trans[d], trec[d], kExpTable);
         acc[5] += w * xv;
         acc[6] += w * (xv * xv);
         acc[7] += w * dexp(0.5 * xv);
@@ -780,7 +796,7 @@ __global__ __launch_bounds__(kThreads) void k_lw_weights(const LwArgs a, int r, 
         out[i] = (c1 - c0) * sc;
         double trec[kDP];
         th_load(a.thB, (size_t)r * a.Npad + i, trec);
-        for (int d = 0; d < kDP; ++d) out[(size_t)(1 + d) * a.Npad + i] = tr_inv(a.trans[d], trec[d]);
+        for (int d = 0; d < kDP; ++d) out[(size_t)(1 + d) * a.Npad + i] = tr_inv(a.trans[d], trec[d], kExpTable);
     }
 }
 

@@ -168,7 +168,7 @@ static StepArgs step_args(ssme_pf_handle h) {
     a.scal = h->scal; a.mc = h->mc; a.y = h->ybuf; a.z = nullptr; a.per_step = nullptr;
     a.gam = h->gam; a.pgam = h->pgam; a.gtot = h->gtot;
     a.N = h->N; a.Npad = h->Npad; a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = h->R;
-    a.tile = h->tile; a.exp_table = 1;
+    a.tile = h->tile;
     a.Tcap = h->tcap;
     a.resampler = h->cfg.resampler; a.resamp_sched = h->cfg.resamp_sched;
     a.keyp = h->keybuf; a.first_filter = h->cfg.first_filter_id;

@@ -94,8 +94,6 @@ struct StepArgs {
     const double* gtot;        // [nT][R]    sum(gam) + E_{N+1}
     int32_t N, Npad, B, Bs, Bpow2, rshift, R;
     int32_t tile;              // particles per tile (2048, 1024 or 512): part of the arithmetic specification
-    int32_t exp_table;         // 1: the bootstrap filter's table exp in the level-2 rescale (k_level2_plan / k_shard_plan serve
-                               // the Liu-West filter too, whose weight arithmetic uses the Taylor exp: 0)
     int32_t t, yi, gi, Tcap;   // t: time index (RNG counter, schedule); yi / gi: rows of y / gamma tables
     int32_t resampler, resamp_sched;
     int32_t finalize_prev;     // account log p(y_{t-1}|.) of the previous step
@@ -1055,7 +1053,7 @@ __global__ __launch_bounds__(1024) void k_level2_plan(const StepArgs a, int plan
         double A = 0.0, Ap = 0.0;
         if (j < a.B) {
             A = ts[j];
-            const double ex = a.exp_table ? dexp_scaled_t(tm[j] - m, a.rshift - kTileShift, kExpTable) : dexp_scaled(tm[j] - m, a.rshift - kTileShift);
+            const double ex = dexp_scaled_t(tm[j] - m, a.rshift - kTileShift, kExpTable);
             Ap = __builtin_rint(A * ex);
         }
         const double inc = wave_incl_scan_f64(Ap);
@@ -1129,8 +1127,7 @@ __global__ __launch_bounds__(512) void k_shard_plan(const StepArgs a, int world,
     const int tid = threadIdx.x;
     double A2[NE], M2[NE], Ap[NE], Tinc[NE], S, m;
     level2_load<NT>(a.tsum_in, a.tmax_in, a.B, A2, M2);
-    if (a.exp_table) level2_scan<NT, true>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
-    else level2_scan<NT, false>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg);
+    level2_scan<NT, true>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int j = e * NT + tid;

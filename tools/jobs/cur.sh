@@ -1,9 +1,8 @@
 set -e
 mkdir -p gpurun_out
-for n in 1048576 2097152; do
-  for ss in 0 1 0 1; do
-    echo "LW n=$n stream=$ss" >> gpurun_out/r2_ss_lw2.log
-    SSME_LW_STREAM_STORES=$ss python tools/prof_run.py --lw --T 64 --passes 3 --n $n >> gpurun_out/r2_ss_lw2.log 2>&1
-  done
+python -m pytest tests -x -q -m gpu > gpurun_out/r2_t11.log 2>&1 || true
+tail -8 gpurun_out/r2_t11.log
+for n in 262144 1048576 2097152 16777216; do
+  python tools/prof_run.py --lw --T 64 --passes 3 --n $n >> gpurun_out/r2_lw11.log 2>&1
 done
-grep -v amdgpu.ids gpurun_out/r2_ss_lw2.log | cut -c1-90
+grep -v amdgpu.ids gpurun_out/r2_lw11.log | cut -c1-100
