@@ -339,18 +339,59 @@ private:
     std::vector<double> y_, ll_;
 };
 
-// ---- svol_lw_1_par (LWFilterWithCovs) ---------------------------------------------------------------------------
+// ---- svol_lw_1_par / svol_lw_2_par (Liu-West filters) ------------------------------------------------------------
 // test/test_liu_west.cpp:22-157: ctor (delta, phi_l, phi_u, mu_l, mu_u, sig_l, sig_u, rho_l, rho_u[, dte]);
-// filter(y, z), getLogCondLike() (liu_west_filter.h:971-1159).  Transforms as svol_lw_1_par passes them to its base:
-// logit, null, log, twice_fisher (test_liu_west.cpp:70).
+// filter(y, z[, fs]), getLogCondLike(), getExpectations() (liu_west_filter.h:971-1159).  Transforms as svol_lw_1_par passes
+// them to its base: logit, null, log, twice_fisher (test_liu_west.cpp:70).
 // FORM 0 = auxiliary-particle form (LWFilterWithCovs, svol_lw_1_par); 1 = SISR form (LWFilter2WithCovs::filter,
 // liu_west_filter.h:2191-2343, svol_lw_2_par of test/test_liu_west.cpp:214-358).  gpu_options::resamp_sched = m_rs.
-template <std::size_t nparts, typename float_t = double, int FORM = 0>
+// filter(y[, fs]) without a covariate is the call of the no-covariate LWFilter / LWFilter2 (:238, :1447): the same model
+// with the covariate term at zero.
+// Functionals: the reference's std::function<const Mat(const ssv&, const csv&, const psv&)> (no-covariate forms:
+// (const ssv&, const psv&)) with the UNTRANSFORMED parameters (:1054-1075, :2267-2290).  Each h is probed on the host; one
+// that is constant, x, x^2, exp(x/2) or one of the four parameters there runs on the device (ssme_lw_get_expectations),
+// anything else is summed on the host over one download of (x, theta, weights).  Mat = the caller's dynamic matrix
+// (Eigen::Matrix<float_t,-1,-1> in the reference); detail::small_matrix when none is given.
+namespace detail {
+template <typename T>
+class small_matrix {                                  // the least a dynamic matrix must offer here
+public:
+    small_matrix() = default;
+    small_matrix(long r, long c) : r_(r), c_(c), v_((std::size_t)(r * c), T(0)) {}
+    long rows() const { return r_; }
+    long cols() const { return c_; }
+    T& operator()(long i, long j) { return v_[(std::size_t)(i * c_ + j)]; }
+    const T& operator()(long i, long j) const { return v_[(std::size_t)(i * c_ + j)]; }
+private:
+    long r_ = 0, c_ = 0;
+    std::vector<T> v_;
+};
+// argument types of the two functional signatures
+template <typename F> struct lw_func_traits;
+template <typename M, typename S, typename C, typename P>
+struct lw_func_traits<std::function<const M(const S&, const C&, const P&)>> {
+    using Mat = M; using Ssv = S; using Psv = P;
+    static M call(const std::function<const M(const S&, const C&, const P&)>& f, const S& x, double z, const P& p) {
+        C zv;
+        zv(0) = z;
+        return f(x, zv, p);
+    }
+};
+template <typename M, typename S, typename P>
+struct lw_func_traits<std::function<const M(const S&, const P&)>> {
+    using Mat = M; using Ssv = S; using Psv = P;
+    static M call(const std::function<const M(const S&, const P&)>& f, const S& x, double, const P& p) { return f(x, p); }
+};
+}  // namespace detail
+
+template <std::size_t nparts, typename float_t = double, int FORM = 0, typename Mat = detail::small_matrix<float_t>>
 class svol_lw_1_par_gpu {
 public:
+    using float_type = float_t;
+    using dynamic_matrix = Mat;
     svol_lw_1_par_gpu(const float_t& delta, const float_t& phi_l, const float_t& phi_u, const float_t& mu_l, const float_t& mu_u,
                       const float_t& sig_l, const float_t& sig_u, const float_t& rho_l, const float_t& rho_u, unsigned /*dte*/ = 0,
-                      gpu_options o = gpu_options(), unsigned filter_id = auto_filter_id) {
+                      gpu_options o = gpu_options(), unsigned filter_id = auto_filter_id) : probe_(o.probe_functionals) {
         ssme_lw_config c{};
         c.n_particles = (int)nparts; c.n_filters = 1; c.seed = o.seed; c.device = o.device;
         c.first_filter_id = detail::resolve_filter_id(filter_id);
@@ -364,22 +405,33 @@ public:
         check(ssme_lw_create(&c, &raw));
         h_ = std::shared_ptr<ssme_lw_s>(raw, [](ssme_lw_handle p) { if (p) ssme_lw_destroy(p); });
     }
+    // LWFilterWithCovs::filter(obs, cov) / LWFilter2WithCovs::filter (:840, :2050)
     template <typename Osv, typename Cvsv>
-    void filter(const Osv& yt, const Cvsv& zt) {
-        const double y = (double)yt(0), z = (double)zt(0);
-        double out = 0.0;
-        const int rc = ssme_lw_step(h_.get(), &y, &z, &out);
-        if (rc != SSME_OK) throw std::runtime_error(std::string(ssme_pf_strerror(rc)) + " (" + ssme_lw_last_error(h_.get()) + ")");
-        last_ = (float_t)out;
+    void filter(const Osv& yt, const Cvsv& zt) { step((double)yt(0), (double)zt(0)); expectations_.clear(); }
+    // ... with functionals
+    template <typename Osv, typename Cvsv, typename F>
+    void filter(const Osv& yt, const Cvsv& zt, const std::vector<F>& fs) {
+        step((double)yt(0), (double)zt(0));
+        compute_expectations(fs, (double)zt(0));
+    }
+    // LWFilter::filter(data[, fs]) / LWFilter2::filter (:238, :1447): no covariate
+    template <typename Osv>
+    void filter(const Osv& yt) { step((double)yt(0), 0.0); expectations_.clear(); }
+    template <typename Osv, typename F>
+    void filter(const Osv& yt, const std::vector<F>& fs) {
+        step((double)yt(0), 0.0);
+        compute_expectations(fs, 0.0);
     }
     float_t getLogCondLike() const { return last_; }
+    // the reference's getExpectations(): one matrix per functional of the last filter() call (:1177-1180)
+    std::vector<Mat> getExpectations() const { return expectations_; }
     // weighted posterior means of (phi, mu, sigma, rho) under the last step's weights
     std::vector<double> getParamMeans() const {
         std::vector<double> m(4);
         check(ssme_lw_get_param_means(h_.get(), m.data()));
         return m;
     }
-    // getExpectations() for built-in functionals: ids 0-3 = SSME_H_* of the state, 4-7 = phi, mu, sigma, rho
+    // built-in functionals by id: 0-3 = SSME_H_* of the state, 4-7 = phi, mu, sigma, rho
     std::vector<double> getExpectations(const std::vector<int32_t>& ids) const {
         std::vector<double> e(ids.size());
         if (!ids.empty()) check(ssme_lw_get_expectations(h_.get(), ids.data(), (int32_t)ids.size(), e.data()));
@@ -388,12 +440,98 @@ public:
     ssme_lw_handle native() const { return h_.get(); }
 
 private:
+    void step(double y, double z) {
+        double out = 0.0;
+        const int rc = ssme_lw_step(h_.get(), &y, &z, &out);
+        if (rc != SSME_OK) throw std::runtime_error(std::string(ssme_pf_strerror(rc)) + " (" + ssme_lw_last_error(h_.get()) + ")");
+        last_ = (float_t)out;
+    }
+    // Which built-in id reproduces h?  Six probes with distinct states and parameters; -1 = evaluate on the host.
+    template <typename F>
+    static int classify(const F& h, double z, double* scale) {
+        using T = detail::lw_func_traits<F>;
+        static const double px[6] = {-1.7, -0.3125, 0.0, 0.5625, 1.9, 3.25};
+        static const double pp[6][4] = {{0.91, -0.07, 0.021, -0.31}, {0.83, 0.02, 0.034, -0.12}, {0.95, 0.09, 0.077, -0.45},
+                                        {0.88, -0.03, 0.055, -0.02}, {0.97, 0.05, 0.012, -0.27}, {0.81, -0.09, 0.093, -0.38}};
+        bool is_const = true, is_x = true, is_x2 = true, is_vol = true, is_p[4] = {true, true, true, true};
+        float_t c0 = 0;
+        for (int q = 0; q < 6; ++q) {
+            typename T::Ssv xv; typename T::Psv pv;
+            xv(0) = (float_t)px[q];
+            for (int d = 0; d < 4; ++d) pv(d) = (float_t)pp[q][d];
+            const Mat m = T::call(h, xv, z, pv);
+            if (m.rows() != 1 || m.cols() != 1) return -1;
+            const float_t v = m(0, 0), xx = xv(0);
+            if (q == 0) c0 = v;
+            is_const = is_const && (v == c0);
+            is_x = is_x && (v == xx);
+            is_x2 = is_x2 && (v == xx * xx);
+            const float_t e = (float_t)std::exp((float_t)0.5 * xx);
+            is_vol = is_vol && (std::fabs(v - e) <= 4 * std::numeric_limits<float_t>::epsilon() * e);
+            for (int d = 0; d < 4; ++d) is_p[d] = is_p[d] && (v == pv(d));
+        }
+        *scale = 1.0;
+        if (is_const) { *scale = (double)c0 / 42.0; return SSME_H_CONST42; }
+        if (is_x) return SSME_H_X;
+        if (is_x2) return SSME_H_X2;
+        if (is_vol) return SSME_H_VOL;
+        for (int d = 0; d < 4; ++d) if (is_p[d]) return 4 + d;
+        return -1;
+    }
+    template <typename F>
+    void compute_expectations(const std::vector<F>& fs, double z) {
+        using T = detail::lw_func_traits<F>;
+        expectations_.clear();
+        if (fs.empty()) return;
+        std::vector<int> kind(fs.size(), -1);
+        std::vector<double> scale(fs.size(), 1.0);
+        std::vector<int32_t> ids;
+        for (std::size_t i = 0; i < fs.size(); ++i) {
+            if (probe_) kind[i] = classify(fs[i], z, &scale[i]);
+            if (kind[i] >= 0) ids.push_back(kind[i]);
+        }
+        const std::vector<double> dev = getExpectations(ids);
+        std::vector<double> x, th, w;
+        std::size_t d = 0;
+        for (std::size_t i = 0; i < fs.size(); ++i) {
+            if (kind[i] >= 0) {
+                Mat m(1, 1);
+                m(0, 0) = (float_t)(dev[d++] * scale[i]);
+                expectations_.push_back(m);
+                continue;
+            }
+            if (w.empty()) {       // one download of (x, untransformed theta, weights) serves every host functional
+                x.resize(nparts); th.resize(4 * nparts); w.resize(nparts);
+                check(ssme_lw_download_weights(h_.get(), 0, x.data(), th.data(), w.data()));
+            }
+            std::vector<double> acc;
+            long rows = 0, cols = 0;
+            double wsum = 0.0;
+            for (std::size_t p = 0; p < nparts; ++p) {
+                typename T::Ssv xv; typename T::Psv pv;
+                xv(0) = (float_t)x[p];
+                for (int q = 0; q < 4; ++q) pv(q) = (float_t)th[(std::size_t)q * nparts + p];
+                const Mat hv = T::call(fs[i], xv, z, pv);
+                if (p == 0) { rows = (long)hv.rows(); cols = (long)hv.cols(); acc.assign((std::size_t)(rows * cols), 0.0); }
+                for (long r = 0; r < rows; ++r)
+                    for (long c = 0; c < cols; ++c) acc[(std::size_t)(r * cols + c)] += (double)hv(r, c) * w[p];
+                wsum += w[p];
+            }
+            Mat m(rows, cols);
+            for (long r = 0; r < rows; ++r)
+                for (long c = 0; c < cols; ++c) m(r, c) = (float_t)(acc[(std::size_t)(r * cols + c)] / wsum);
+            expectations_.push_back(m);
+        }
+    }
+
     std::shared_ptr<ssme_lw_s> h_;
     float_t last_ = 0;
+    bool probe_ = true;
+    std::vector<Mat> expectations_;
 };
 
-template <std::size_t nparts, typename float_t = double>
-using svol_lw_2_par_gpu = svol_lw_1_par_gpu<nparts, float_t, 1>;
+template <std::size_t nparts, typename float_t = double, typename Mat = detail::small_matrix<float_t>>
+using svol_lw_2_par_gpu = svol_lw_1_par_gpu<nparts, float_t, 1, Mat>;
 
 // ---- SwarmWithCovs over SVOL-leverage members (include/ssme/pswarm_filter.h:325-560; test/test_pswarm.cpp:146-208) ----
 // All nparamparts member filters live in ONE handle (n_filters = nparamparts, one theta row each): update(y, z) is one

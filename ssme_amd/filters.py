@@ -389,15 +389,42 @@ class svol_lw_1_par:
     def reset(self):
         self._chk(capi.lib().ssme_lw_reset(self._h))
 
-    def filter(self, y, z=0.0):
+    def filter(self, y, z=0.0, fs=()):
+        """filter(obs, cov, fs) of LWFilterWithCovs / LWFilter2WithCovs (liu_west_filter.h:840, :2050); without z it is
+        the no-covariate LWFilter / LWFilter2 call (:238, :1447; the same model with the covariate term at zero).
+        fs: functionals for getExpectations(): ids 0-7 (see expectations()) run on the device; callables
+        h(x, z, theta) -- the reference's std::function (state, covariate, UNTRANSFORMED parameters) -- on the host."""
         yv = np.array([float(np.ravel(y)[0])])
         zv = np.array([float(np.ravel(z)[0])])
         out = np.empty(self.r)
         self._chk(capi.lib().ssme_lw_step(self._h, capi.dptr(yv), capi.dptr(zv), capi.dptr(out)))
         self._last = out
+        self._fs, self._z = tuple(fs), zv[0]
 
     def getLogCondLike(self):
         return float(self._last[0]) if self.r == 1 else self._last.copy()
+
+    def getExpectations(self):
+        """E[h(x_t, z_t, theta) | y_{1:t}] for the fs given to the last filter() call (:1054-1075, :2267-2290), filter 0:
+        a list with one entry per functional, shaped as h returns (scalars for the built-in ids)."""
+        fs = getattr(self, "_fs", ())
+        ids = [int(f) for f in fs if not callable(f)]
+        dev = self.expectations(ids)[:, 0] if ids else []
+        out, d, host = [], 0, None
+        for f in fs:
+            if not callable(f):
+                out.append(float(dev[d]))
+                d += 1
+                continue
+            if host is None:
+                host = self.weights(0)
+            x, th, w = host
+            acc = None
+            for i in range(self.n):
+                hv = np.asarray(f(x[i], self._z, th[:, i]), dtype=np.float64) * w[i]
+                acc = hv if acc is None else acc + hv
+            out.append(acc / w.sum())
+        return out
 
     def run_series(self, y, z=None):
         yv = capi.as_f64(y)

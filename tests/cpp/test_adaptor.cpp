@@ -126,6 +126,32 @@ int main(int argc, char** argv) {
     }
     std::printf("liu_west2 %.17g\n", lw2ll);
     std::printf("liu_west2_42 %.17g\n", lw2.getExpectations({SSME_H_CONST42})[0]);
+    // (6c) functionals as test/test_liu_west.cpp:176-200 / :381-403 pass them: std::function (state, covariate, untransformed
+    //      parameters) -> matrix; 42 and phi are recognised and run on the device, the 2x2 one is summed on the host
+    {
+        using psv4 = shape::vec4<double>;
+        using lwfunc = std::function<const Mat(const vec1&, const vec1&, const psv4&)>;
+        ssme_gpu::svol_lw_1_par_gpu<800, double, 0, Mat> lwf(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, 10, o, 0);
+        std::vector<lwfunc> lfs;
+        lfs.push_back([](const vec1&, const vec1&, const psv4&) -> const Mat { vec1 ans; ans(0) = 42.0; return ans; });
+        lfs.push_back([](const vec1&, const vec1&, const psv4& pt) -> const Mat { vec1 ans; ans(0) = pt(0); return ans; });
+        lfs.push_back([](const vec1& xt, const vec1& zt, const psv4& pt) -> const Mat {
+            Mat m(2, 2); m(0, 0) = xt(0); m(0, 1) = xt(0) * pt(2); m(1, 0) = zt(0); m(1, 1) = pt(3); return m; });
+        for (size_t row = 0; row < 6; ++row) lwf.filter(data[row], vec1{row ? data[row - 1].v : 0.0}, lfs);
+        const std::vector<Mat> e = lwf.getExpectations();
+        const std::vector<double> dev = lwf.getExpectations(std::vector<int32_t>{SSME_H_X, 7});
+        std::printf("lwf_ll %.17g\nlwf_42 %.17g\nlwf_phi %.17g\n", (double)lwf.getLogCondLike(), e[0](0, 0), e[1](0, 0));
+        std::printf("lwf_host_x %.17g\nlwf_host_xsig %.17g\nlwf_host_z %.17g\nlwf_host_rho %.17g\n", e[2](0, 0), e[2](0, 1), e[2](1, 0), e[2](1, 1));
+        std::printf("lwf_dev_x %.17g\nlwf_dev_rho %.17g\n", dev[0], dev[1]);
+        // the no-covariate call (LWFilter::filter(data, fs), :238) with its two-argument functionals
+        using lwfunc2 = std::function<const Mat(const vec1&, const psv4&)>;
+        ssme_gpu::svol_lw_2_par_gpu<800, double, Mat> lwn(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, 10, o, 0);
+        std::vector<lwfunc2> nfs;
+        nfs.push_back([](const vec1& xt, const psv4&) -> const Mat { vec1 ans; ans(0) = xt(0) * xt(0); return ans; });
+        double nll = 0.0;
+        for (size_t row = 0; row < 4; ++row) { lwn.filter(data[row], nfs); nll += lwn.getLogCondLike(); }
+        std::printf("lwn_ll %.17g\nlwn_x2 %.17g\n", nll, lwn.getExpectations()[0](0, 0));
+    }
     // (7) utils::read_data stand-in
     const auto rows = ssme_gpu::read_data(argv[1], 1);
     std::printf("read_data %zu %.17g\n", rows.size(), rows.empty() ? 0.0 : rows[0](0));

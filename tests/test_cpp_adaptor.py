@@ -52,6 +52,24 @@ def test_adaptor_matches_oracle(oracle, spy):
     lw2 = oracle.LWFilter(800, 77, form=1)
     assert float(vals["liu_west2"]) == sum(lw2.step(y[t], z[t]) for t in range(6))
     assert abs(float(vals["liu_west2_42"]) - 42.0) < 1e-9
+    # (6c) std::function functionals of the Liu-West filters: device-recognised and host-summed ones, the no-covariate call
+    lwf = oracle.LWFilter(800, 77)
+    for t in range(6):
+        ll_t = lwf.step(y[t], z[t])
+    assert float(vals["lwf_ll"]) == ll_t
+    assert abs(float(vals["lwf_42"]) - 42.0) < 1e-9
+    assert abs(float(vals["lwf_phi"]) - lwf.expectation(4)) <= 1e-10 * abs(lwf.expectation(4))
+    assert abs(float(vals["lwf_host_x"]) - float(vals["lwf_dev_x"])) <= 1e-10 * abs(float(vals["lwf_dev_x"]))
+    assert abs(float(vals["lwf_host_rho"]) - float(vals["lwf_dev_rho"])) <= 1e-10 * abs(float(vals["lwf_dev_rho"]))
+    assert abs(float(vals["lwf_host_z"]) - z[5]) <= 1e-12 * abs(z[5])
+    st = lwf.state()
+    wts = np.exp(st["logw"] - st["logw"].max())
+    sig = np.exp(st["theta"][2])                          # sigma = exp(theta_2): transforms logit, null, log, twice_fisher
+    want = (st["x"] * sig * wts).sum() / wts.sum()
+    assert abs(float(vals["lwf_host_xsig"]) - want) <= 1e-9 * abs(want)
+    lwn = oracle.LWFilter(800, 77, form=1)
+    assert float(vals["lwn_ll"]) == sum(lwn.step(y[t], 0.0) for t in range(4))
+    assert abs(float(vals["lwn_x2"]) - lwn.expectation(1)) <= 1e-10 * abs(lwn.expectation(1))
     # swarm: 5 members, theta rows as test_swarm::samp_untrans_params, plain averages over members
     mem = []
     for k in range(5):

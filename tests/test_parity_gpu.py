@@ -601,6 +601,37 @@ def test_liu_west_series_equals_steps_and_replicates(sa, oracle):
     g.close()
 
 
+@pytest.mark.parametrize("cls,form", [("svol_lw_1_par", 0), ("svol_lw_2_par", 1)])
+def test_liu_west_filter_with_functionals_as_the_reference_tests_call_it(sa, oracle, cls, form):
+    """test/test_liu_west.cpp:176-200, :381-403: mod.filter(y, z, fs); mod.getExpectations()[0] == 42 -- with callables
+    h(x, z, theta) on untransformed parameters (host sum over the downloaded weights) next to the device ids; and the
+    no-covariate call filter(y, fs=...) (LWFilter::filter, liu_west_filter.h:238)."""
+    n, T = 2500, 5
+    y, z = _lw_series(T, seed=9)
+    g = getattr(sa, cls)(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, 10, nparts=n, seed=4)
+    o = oracle.LWFilter(n, 4, form=form)
+    fs = [lambda x, zt, th: 42.0, 0, 6, lambda x, zt, th: np.array([[x, th[2] * x], [zt, np.sin(x) + th[0]]])]
+    for t in range(T):
+        g.filter(y[t], z[t], fs)
+        assert g.getLogCondLike() == o.step(y[t], z[t])
+    e = g.getExpectations()
+    assert abs(e[0] - 42.0) < 1e-9
+    assert abs(e[1] - o.expectation(0)) <= 1e-10 * abs(o.expectation(0))
+    assert abs(e[2] - o.expectation(6)) <= 1e-10 * abs(o.expectation(6))
+    st = o.state()
+    w = np.exp(st["logw"] - st["logw"].max())
+    phi, sig = 1.0 / (1.0 + np.exp(-st["theta"][0])), np.exp(st["theta"][2])       # transforms: logit, null, log, twice_fisher
+    want = np.array([[(st["x"] * w).sum(), (sig * st["x"] * w).sum()], [z[T - 1] * w.sum(), ((np.sin(st["x"]) + phi) * w).sum()]]) / w.sum()
+    np.testing.assert_allclose(e[3], want, rtol=1e-9)
+    g.reset()
+    o2 = oracle.LWFilter(n, 4, form=form)
+    for t in range(3):
+        g.filter(y[t], fs=[1])                              # no covariate
+        assert g.getLogCondLike() == o2.step(y[t], 0.0)
+    assert abs(g.getExpectations()[0] - o2.expectation(1)) <= 1e-10 * abs(o2.expectation(1))
+    g.close()
+
+
 def test_liu_west_rejects_bad_config(sa):
     from ssme_amd import SsmeError
     with pytest.raises(SsmeError):
