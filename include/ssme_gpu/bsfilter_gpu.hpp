@@ -55,9 +55,10 @@ inline void check(int status, ssme_pf_handle h = nullptr) {
 class handle {
 public:
     handle() = default;
-    handle(int model, int nparts, int nfilters, std::uint64_t seed, int resampler, int rs, int device, unsigned first_id) {
+    handle(int model, int nparts, int nfilters, std::uint64_t seed, int resampler, int rs, int device, unsigned first_id,
+           int dtype = SSME_F64) {
         ssme_pf_config c{};
-        c.model = model; c.n_particles = nparts; c.n_filters = nfilters; c.dtype = SSME_F64; c.resampler = resampler;
+        c.model = model; c.n_particles = nparts; c.n_filters = nfilters; c.dtype = dtype; c.resampler = resampler;
         c.resamp_sched = rs; c.seed = seed; c.device = device; c.first_filter_id = first_id;
         ssme_pf_handle raw = nullptr;
         check(ssme_pf_create(&c, &raw));
@@ -82,6 +83,8 @@ struct gpu_options {
 constexpr unsigned auto_filter_id = 0xffffffffu;
 namespace detail {
 struct no_base {};
+// float_t = float (the shipped example, example/main.cpp:13) -> SSME_F32: float at the boundary (ssme_pf.h)
+template <typename float_t> constexpr int dtype_of() { return sizeof(float_t) == sizeof(float) ? SSME_F32 : SSME_F64; }
 inline unsigned resolve_filter_id(unsigned id) {
     static std::atomic<unsigned> next{0};
     return id == auto_filter_id ? next.fetch_add(1) : id;
@@ -95,7 +98,8 @@ public:
     using float_type = float_t;
     svol_bs_gpu(const float_t& phi, const float_t& beta, const float_t& sigma, gpu_options o = gpu_options(),
                 unsigned filter_id = auto_filter_id)
-        : h_(SSME_MODEL_SVOL, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device, detail::resolve_filter_id(filter_id)) {
+        : h_(SSME_MODEL_SVOL, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device, detail::resolve_filter_id(filter_id),
+             detail::dtype_of<float_t>()) {
         const double th[3] = {(double)beta, (double)phi, (double)sigma};
         check(ssme_pf_set_params(h_.get(), th, 3, 1), h_.get());
     }
@@ -225,7 +229,7 @@ public:
     svol_leverage_gpu(const float_t& phi, const float_t& mu, const float_t& sigma, const float_t& rho, unsigned /*dte*/ = 0,
                       gpu_options o = gpu_options(), unsigned filter_id = auto_filter_id)
         : h_(SSME_MODEL_SVOL_LEVERAGE, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device,
-             detail::resolve_filter_id(filter_id)), probe_(o.probe_functionals) {
+             detail::resolve_filter_id(filter_id), detail::dtype_of<float_t>()), probe_(o.probe_functionals) {
         const double th[4] = {(double)phi, (double)mu, (double)sigma, (double)rho};
         check(ssme_pf_set_params(h_.get(), th, 4, 1), h_.get());
     }
@@ -262,7 +266,8 @@ public:
     svol_bs_member_gpu() = default;
     svol_bs_member_gpu(const float_t& phi, const float_t& beta, const float_t& sigma, gpu_options o = gpu_options(),
                        unsigned filter_id = auto_filter_id)
-        : h_(SSME_MODEL_SVOL, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device, detail::resolve_filter_id(filter_id)),
+        : h_(SSME_MODEL_SVOL, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device, detail::resolve_filter_id(filter_id),
+             detail::dtype_of<float_t>()),
           probe_(o.probe_functionals) {
         const double th[3] = {(double)beta, (double)phi, (double)sigma};
         check(ssme_pf_set_params(h_.get(), th, 3, 1), h_.get());
@@ -576,7 +581,7 @@ private:
             for (int d = 0; d < 4; ++d) theta_[i * 4 + d] = (double)p[d];
         }
         h_ = handle(SSME_MODEL_SVOL_LEVERAGE, (int)n_state_parts, (int)n_param_parts, opt_.seed, opt_.resampler, opt_.resamp_sched,
-                    opt_.device, 0);
+                    opt_.device, 0, detail::dtype_of<float_t>());
         check(ssme_pf_set_params(h_.get(), theta_.data(), 4, (int)n_param_parts), h_.get());
     }
     std::vector<func> fs_;
@@ -626,7 +631,8 @@ private:
             if (p.size() != 3) throw std::invalid_argument("samp_untrans_params must return phi, beta, sigma");
             theta[i * 3 + 0] = (double)p[1]; theta[i * 3 + 1] = (double)p[0]; theta[i * 3 + 2] = (double)p[2];   // C ABI order: beta, phi, sigma
         }
-        h_ = handle(SSME_MODEL_SVOL, (int)n_state_parts, (int)n_param_parts, opt_.seed, opt_.resampler, opt_.resamp_sched, opt_.device, 0);
+        h_ = handle(SSME_MODEL_SVOL, (int)n_state_parts, (int)n_param_parts, opt_.seed, opt_.resampler, opt_.resamp_sched, opt_.device, 0,
+                    detail::dtype_of<float_t>());
         check(ssme_pf_set_params(h_.get(), theta.data(), 3, (int)n_param_parts), h_.get());
     }
     std::vector<func> fs_;

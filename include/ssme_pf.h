@@ -68,7 +68,14 @@ typedef struct ssme_pf_config {
     int32_t  n_filters;        /* R independent filters/replicates held by this handle:
                                   thread_pool's num_pfilters (thread_pool.h:189-215) or the
                                   swarm's nparamparts (pswarm_filter.h:280-304)              */
-    int32_t  dtype;            /* SSME_F64                                                   */
+    int32_t  dtype;            /* SSME_F64, or SSME_F32 = float at the boundary (the reference
+                                  built with float_t = float, example/main.cpp:13): y, z and theta
+                                  are rounded to float on entry and every returned log-likelihood,
+                                  expectation, particle and weight is rounded to float; the
+                                  arithmetic stays fp64 (plain fp32 VALU issues at the fp64 rate on
+                                  gfx950, so float arithmetic would buy no time).  Not for sharded
+                                  handles or the parity downloads (ssme_pf_download_state / _scalars
+                                  hand out the raw fp64 state)                                 */
     int32_t  resampler;        /* SSME_RESAMP_*                                              */
     int32_t  resamp_sched;     /* resample every k-th step; 1 = reference default            */
     uint64_t seed;             /* Philox4x32-10 key (reference RNGs are clock-seeded)        */

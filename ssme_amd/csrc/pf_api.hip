@@ -114,6 +114,15 @@ static hipError_t wait_results(hipStream_t s, const double* slots, int R) {
     return hipSuccess;
 }
 
+// SSME_F32 handles (the reference instantiated with float_t = float, example/main.cpp:13): float at the boundary --
+// observations, covariates and parameters are rounded to float on entry, every value handed back is rounded to float --
+// while the arithmetic stays fp64.  Plain fp32 VALU instructions issue at the fp64 rate on gfx950 (only packed fp32 is
+// faster), so float arithmetic would buy no time; it would only coarsen the callbacks below the fixed-point weights.
+static inline double f32r(double v) { return (double)(float)v; }
+static void round_out(const ssme_pf_handle h, double* p, size_t n) {
+    if (h->cfg.dtype == SSME_F32 && p) for (size_t i = 0; i < n; ++i) p[i] = f32r(p[i]);
+}
+
 static int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 static int ceil_log2(int n) { int k = 0; while ((1ll << k) < n) ++k; return k; }
 
@@ -453,7 +462,8 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     if (cfg->model < 0 || cfg->model > SSME_MODEL_LIN_GAUSS) return SSME_ERR_INVALID_ARG;
     if (cfg->resampler < 0 || cfg->resampler > SSME_RESAMP_MULTINOMIAL_IID) return SSME_ERR_INVALID_ARG;
     if (cfg->resamp_sched < 1) return SSME_ERR_INVALID_ARG;
-    if (cfg->dtype != SSME_F64) return SSME_ERR_UNSUPPORTED;
+    if (cfg->dtype != SSME_F64 && cfg->dtype != SSME_F32) return SSME_ERR_INVALID_ARG;
+    if (cfg->dtype == SSME_F32 && shard_world > 0) return SSME_ERR_UNSUPPORTED;     // the sharded entry points exchange raw fp64 arrays
     if (cfg->tile_particles != 0 && cfg->tile_particles != kTile && cfg->tile_particles != kTileSmall && cfg->tile_particles != kTileMid) return SSME_ERR_INVALID_ARG;
     const int tile = shard_world > 0 ? kTile : (cfg->tile_particles ? cfg->tile_particles : default_tile(cfg->n_particles, cfg->n_filters));
     const int B = (cfg->n_particles + tile - 1) / tile;
@@ -885,7 +895,14 @@ int ssme_pf_set_params(ssme_pf_handle h, const double* theta, int32_t n_theta, i
     if (n_rows != 1 && n_rows != h->R) return SSME_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
     h->h_mc.resize(h->R);
-    for (int r = 0; r < h->R; ++r) h->h_mc[r] = derive(h->cfg.model, theta + (size_t)(n_rows == 1 ? 0 : r) * n_theta);
+    for (int r = 0; r < h->R; ++r) {
+        double th[8];
+        for (int d = 0; d < n_theta; ++d) {
+            const double v = theta[(size_t)(n_rows == 1 ? 0 : r) * n_theta + d];
+            th[d] = h->cfg.dtype == SSME_F32 ? f32r(v) : v;
+        }
+        h->h_mc[r] = derive(h->cfg.model, th);
+    }
     HIPCHK(hipMemcpyAsync(h->mc, h->h_mc.data(), sizeof(ModelConst) * h->R, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->params_set = true;
@@ -964,6 +981,7 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
     // last workgroup of the step kernel itself: a filter() call is one launch and a poll (two launches with the split
     // level-2 of very large filters), no copy operation in either direction
     h->pin[0] = *y; h->pin[1] = z ? *z : 0.0;
+    if (h->cfg.dtype == SSME_F32) { h->pin[0] = f32r(h->pin[0]); h->pin[1] = f32r(h->pin[1]); }
     // Gamma tables are drawn kStepGammaChunk time steps at a time (data independent), so that the two table launches are paid
     // once per chunk and not once per filter() call
     int gi = 0;
@@ -981,6 +999,7 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
     h->t += 1;
     HIPCHK(wait_results(h->stream, h->pin + 2, h->R));
     if (out) for (int r = 0; r < h->R; ++r) out[r] = h->pin[2 + r];
+    round_out(h, out, h->R);
     return SSME_OK;
 }
 
@@ -998,8 +1017,16 @@ int ssme_pf_run_series(ssme_pf_handle h, const double* y, const double* z, int32
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc = ensure_series_capacity(h, T);
     if (rc != SSME_OK) return rc;
+    std::vector<double> y32, z32;
+    if (h->cfg.dtype == SSME_F32) {
+        y32.resize(T);
+        for (int t = 0; t < T; ++t) y32[t] = f32r(y[t]);
+        y = y32.data();
+        if (z) { z32.resize(T); for (int t = 0; t < T; ++t) z32[t] = f32r(z[t]); z = z32.data(); }
+    }
     HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
     if (z) HIPCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    if (h->cfg.dtype == SSME_F32) HIPCHK(hipStreamSynchronize(h->stream));      // the staging vectors go out of scope
     rc = do_reset(h);
     if (rc != SSME_OK) return rc;
     const bool has_z = z != nullptr;
@@ -1038,6 +1065,7 @@ int ssme_pf_run_series(ssme_pf_handle h, const double* y, const double* z, int32
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
     if (loglik_out) for (int r = 0; r < h->R; ++r) loglik_out[r] = sc[r].loglik;
+    round_out(h, loglik_out, h->R);
     return SSME_OK;
 }
 
@@ -1049,6 +1077,7 @@ int ssme_pf_get_per_step(ssme_pf_handle h, double* out, int32_t T) {
         HIPCHK(hipMemcpyAsync(out + (size_t)r * T, h->per_step + (size_t)r * h->tcap, sizeof(double) * T,
                               hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    round_out(h, out, (size_t)h->R * T);
     return SSME_OK;
 }
 
@@ -1059,6 +1088,7 @@ int ssme_pf_get_loglik(ssme_pf_handle h, double* out) {
     HIPCHK(hipMemcpyAsync(sc.data(), h->scal, sizeof(FilterScalars) * h->R, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     for (int r = 0; r < h->R; ++r) out[r] = sc[r].loglik;
+    round_out(h, out, h->R);
     return SSME_OK;
 }
 
@@ -1073,6 +1103,7 @@ int ssme_pf_log_mean_exp(ssme_pf_handle h, double* out) {
     double s = 0.0;
     for (double v : ll) s += std::exp(v - m);
     *out = m + std::log(s) - std::log((double)h->R);
+    round_out(h, out, 1);
     return SSME_OK;
 }
 
@@ -1102,6 +1133,7 @@ int ssme_pf_get_expectations_multi(ssme_pf_handle h, const int32_t* functionals,
     if (rc != SSME_OK) return rc;
     HIPCHK(hipMemcpyAsync(out, h->exp_out, sizeof(double) * (size_t)n * h->R, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    round_out(h, out, (size_t)n * h->R);
     return SSME_OK;
 }
 
@@ -1133,6 +1165,8 @@ int ssme_pf_swarm_aggregate(ssme_pf_handle h, const int32_t* functionals, int32_
     HIPCHK(wait_stream_low_latency(h->stream));
     *mean_logcondlike = pin[kMaxFunctionals];
     for (int i = 0; i < n; ++i) mean_expectations[i] = pin[i];
+    round_out(h, mean_logcondlike, 1);
+    round_out(h, mean_expectations, (size_t)n);
     return SSME_OK;
 }
 
@@ -1152,6 +1186,8 @@ int ssme_pf_download_weights(ssme_pf_handle h, int32_t f, double* x, double* w) 
     HIPCHK(hipMemcpyAsync(w, h->wscratch, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
     if (x) HIPCHK(hipMemcpyAsync(x, h->x[h->cur] + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    round_out(h, x, h->N);
+    round_out(h, w, h->N);
     return SSME_OK;
 }
 

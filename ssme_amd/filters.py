@@ -30,12 +30,13 @@ class ParticleFilterBank:
     """
 
     def __init__(self, model, n_particles, n_filters=1, seed=0, resampler=RESAMP_MULTINOMIAL, resamp_sched=1,
-                 device=0, first_filter_id=0, tile=0):
-        """tile: particles per tile, 0 = by N (2048 for N <= 2048 and N > 2^18, 512 in between), or 2048 / 512."""
+                 device=0, first_filter_id=0, tile=0, dtype=capi.F64):
+        """tile: particles per tile, 0 = chosen from (N, n_filters), or 2048 / 1024 / 512.
+        dtype: F64, or F32 = float at the boundary (inputs and outputs rounded to float, fp64 arithmetic; ssme_pf.h)."""
         self._h = C.c_void_p()
         self.model, self.n, self.r = int(model), int(n_particles), int(n_filters)
         self._last_T = 0
-        cfg = capi.Config(model=model, n_particles=n_particles, n_filters=n_filters, dtype=capi.F64,
+        cfg = capi.Config(model=model, n_particles=n_particles, n_filters=n_filters, dtype=dtype,
                           resampler=resampler, resamp_sched=resamp_sched, seed=seed, device=device,
                           first_filter_id=first_filter_id, tile_particles=tile, reserved=0)
         capi.check(capi.lib().ssme_pf_create(C.byref(cfg), C.byref(self._h)))

@@ -36,6 +36,42 @@ def test_svol_bs_device_vs_mode_a(dev, oracle, spy):
     sa.assert_same_mean(a, g, "svol_bs device vs mode A")
 
 
+@pytest.mark.parametrize("n", [100, 500])
+def test_svol_bs_float_configuration_device_vs_mode_a_in_float(dev, oracle, spy, n):
+    """BASELINE.json configs[0] as shipped: FLOATTYPE float (example/main.cpp:13), N = 100 / 500.  The device handle is
+    SSME_F32 (float at the boundary, fp64 arithmetic); mode A runs entirely in float, as the reference would."""
+    th = [1.0, 0.95, 0.25]
+    y = spy[:300]
+    seeds = 2 * sa.SEEDS            # 400 per side: the first 200 alone sit at 3.3 SE (two 2.3-SE excursions in opposite directions)
+    bank = dev.ParticleFilterBank(dev.MODEL_SVOL, n, seeds, seed=314, dtype=dev._capi.F32)
+    bank.set_params(th)
+    g = bank.run_series(y)
+    bank.close()
+    assert np.array_equal(g, g.astype(np.float32).astype(np.float64))            # what comes back is float
+    a = np.array(sa.pmap(lambda s: oracle.ref_run_series(oracle.MODEL_SVOL, th, n, y, None, seed=1 + s, use_float=True)[0],
+                         range(seeds)))
+    sa.assert_same_mean(a, g, f"svol_bs float configuration (N = {n}) device vs mode A in float")
+
+
+def test_float_configuration_is_the_double_one_on_rounded_inputs(dev, spy):
+    """SSME_F32 semantics: y, z, theta rounded to float on entry, results rounded to float on exit, nothing else."""
+    f32 = lambda v: np.asarray(v, dtype=np.float32).astype(np.float64)
+    th = [0.9, 0.0, 1.0, -0.1]
+    y = spy[:40]
+    z = np.concatenate([[0.0], y[:-1]])
+    b32 = dev.ParticleFilterBank(dev.MODEL_SVOL_LEVERAGE, 3000, 3, seed=5, dtype=dev._capi.F32)
+    b64 = dev.ParticleFilterBank(dev.MODEL_SVOL_LEVERAGE, 3000, 3, seed=5)
+    b32.set_params(th)
+    b64.set_params(f32(th))
+    np.testing.assert_array_equal(b32.run_series(y, z), f32(b64.run_series(f32(y), f32(z))))
+    np.testing.assert_array_equal(b32.per_step(), f32(b64.per_step()))
+    np.testing.assert_array_equal(b32.expectations_multi([0, 1, 3]), f32(b64.expectations_multi([0, 1, 3])))
+    b32.reset(); b64.reset()
+    for t in range(5):
+        np.testing.assert_array_equal(b32.step(y[t], z[t]), f32(b64.step(f32(y[t]), f32(z[t]))))
+    b32.close(); b64.close()
+
+
 @pytest.mark.parametrize("tile", [512, 2048])
 def test_svol_bs_tiled_kernel_device_vs_mode_a(dev, oracle, spy, tile):
     """The same through the tiled step kernel with several tiles per filter (N = 5000: level-2 rescale + tile search),
