@@ -771,7 +771,17 @@ __global__ __launch_bounds__(kThreads) void k_lw_param_partials(const LwArgs a) 
 __global__ __launch_bounds__(kWave) void k_lw_param_means(const LwArgs a, double* out /*[R][8]*/) {
     const int r = blockIdx.x, q = threadIdx.x;
     double t = 0.0;
-    if (q < kLwNExp) for (int b = 0; b < a.B; ++b) t = t + a.mom[((size_t)r * a.B + b) * 16 + q];
+    if (q < kLwNExp) {
+        // tile order, as a plain loop would add them; the loads of 16 tiles are issued together (one memory latency per
+        // batch instead of one per tile: 115 us at 512 tiles otherwise)
+        for (int b0 = 0; b0 < a.B; b0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = (b0 + u < a.B) ? a.mom[((size_t)r * a.B + b0 + u) * 16 + q] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (b0 + u < a.B) t = t + v[u];
+        }
+    }
     const double den = __shfl(t, kDP, kWave);
     if (q < kDP) out[(size_t)r * kLwNExp + q] = t / den;
     else if (q == kDP) out[(size_t)r * kLwNExp + 7] = 42.0 * (den / den);          // NaN weights stay NaN

@@ -43,7 +43,8 @@ for n in 1048576 2097152 16777216; do python3 tools/prof_run.py --lw --T 32 --pa
 cat $OUT/${TAG}_liu_west_vs_N.txt
 python3 bench.py --mode sharded --steps 2 --no-cpu-baseline > $OUT/${TAG}_bench_sharded_world1_native.json 2> $OUT/sh1.err
 python3 bench.py --mode sharded --driver python --steps 2 --no-cpu-baseline > $OUT/${TAG}_bench_sharded_world1_python.json 2> $OUT/sh2.err
+python3 bench.py --mode sharded --lw --particles 2097152 --steps 2 --no-cpu-baseline > $OUT/${TAG}_bench_sharded_world1_lw_native.json 2> $OUT/sh3.err
 cut -c1-300 $OUT/${TAG}_bench_sharded_world1_native.json; cut -c1-300 $OUT/${TAG}_bench_sharded_world1_python.json
-g++ -std=c++17 -O2 tools/step_latency.cpp -o tools/step_latency ssme_amd/libssme_pf.so -Wl,-rpath,$PWD/ssme_amd
+g++ -std=c++17 -O2 -Iinclude tools/step_latency.cpp -o tools/step_latency -Lssme_amd -l:libssme_pf.so -Wl,-rpath,$PWD/ssme_amd
 ./tools/step_latency tests/golden/spy_returns.csv > $OUT/${TAG}_step_api_latency.txt
 cat $OUT/${TAG}_step_api_latency.txt
