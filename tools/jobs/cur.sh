@@ -1,4 +1,6 @@
 set -e
 mkdir -p gpurun_out
-python -m pytest tests/test_stat_anchor_gpu.py -x -q -m gpu > gpurun_out/r2_t16.log 2>&1 || true
-tail -12 gpurun_out/r2_t16.log
+for sd in 1 2 3 4; do
+python tests/soak_parity.py 3000 800 $sd > gpurun_out/r2_soak_$sd.log 2>&1
+tail -2 gpurun_out/r2_soak_$sd.log
+done
