@@ -111,7 +111,9 @@ int ssme_pf_reset(ssme_pf_handle h);
 
 /* One filter() call on every filter of the handle: BSFilter::filter(y_t) /
  * BSFilterWC::filter(y_t, z_t).  y: 1 value; z: 1 value or NULL.  logcondlike_out (R
- * values, nullable) receives getLogCondLike() of each filter. */
+ * values, nullable) receives getLogCondLike() of each filter.  With logcondlike_out = NULL the
+ * step is only queued on the handle's stream (the swarm classes: ssme_pf_swarm_aggregate, which
+ * follows, hands the data back); every later call on the handle is ordered behind it. */
 int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* logcondlike_out);
 
 /* The whole log_like_eval loop (estimate_univ_svol.h:121-127) for all R filters in one

@@ -158,12 +158,6 @@ constexpr int kStepGammaChunk = 64;
 static int n_theta_of(int model) { return model == SSME_MODEL_SVOL_LEVERAGE ? 4 : 3; }
 static bool logw_needed(ssme_pf_handle h) { return h->keep_logw || h->cfg.resamp_sched > 1; }
 
-// the R log conditional likelihoods of the last step, contiguous (the step API returns them through one small copy)
-__global__ void k_collect_last_ll(const FilterScalars* scal, double* out, int R) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < R) out[r] = scal[r].last_ll;
-}
-
 // arguments of the step that reads buffers `cur` and writes `cur ^ 1`
 static StepArgs step_args(ssme_pf_handle h) {
     StepArgs a{};
@@ -336,12 +330,12 @@ static void launch_kf(ssme_pf_handle h, int t, bool record_per_step, double* ll_
 
 // enqueue one filter step at time index t reading y[yi] and gamma-table row gi
 static void enqueue_step(ssme_pf_handle h, int t, int yi, int gi, bool has_z, bool finalize_prev, bool record_per_step,
-                         bool from_step_staging = false) {
+                         bool from_step_staging = false, bool results_to_host = true) {
     StepArgs a = step_args(h);
     a.z = has_z ? h->zbuf : nullptr;
     if (from_step_staging) {
         a.by_value = 1; a.y_now = h->pin[0]; a.z_now = has_z ? h->pin[1] : 0.0;
-        if (!h->split_l2) { a.ticket = h->ticket; a.ll_host = h->pin_dev + 2; }     // accounting inside the step kernel (its last workgroup)
+        if (!h->split_l2) { a.ticket = h->ticket; a.ll_host = results_to_host ? h->pin_dev + 2 : nullptr; }     // accounting inside the step kernel (its last workgroup)
     }
     a.per_step = record_per_step ? h->per_step : nullptr;
     a.t = t; a.yi = yi; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
@@ -992,12 +986,15 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
         }
         gi = h->t - h->gamma_t0;
     }
-    mark_results_pending(h->pin + 2, h->R);
-    enqueue_step(h, h->t, 0, gi, z != nullptr, /*finalize_prev=*/false, /*per_step=*/false, /*from_step_staging=*/true);
-    if (h->split_l2) launch_kf(h, h->t, false, h->pin_dev + 2);
+    // out == NULL (the swarm classes: the aggregation that follows hands the data back): the step is only queued -- no result
+    // slots, no wait; anything that reads the handle afterwards is ordered behind it on the stream
+    const bool want = out != nullptr;
+    if (want) mark_results_pending(h->pin + 2, h->R);
+    enqueue_step(h, h->t, 0, gi, z != nullptr, /*finalize_prev=*/false, /*per_step=*/false, /*from_step_staging=*/true, want);
+    if (h->split_l2) launch_kf(h, h->t, false, want ? h->pin_dev + 2 : nullptr);
     HIPCHK(hipGetLastError());
     h->t += 1;
-    HIPCHK(wait_results(h->stream, h->pin + 2, h->R));
+    if (want) HIPCHK(wait_results(h->stream, h->pin + 2, h->R));
     if (out) for (int r = 0; r < h->R; ++r) out[r] = h->pin[2 + r];
     round_out(h, out, h->R);
     return SSME_OK;
@@ -1154,15 +1151,15 @@ int ssme_pf_swarm_aggregate(ssme_pf_handle h, const int32_t* functionals, int32_
         int rc = enqueue_expectations(h, functionals, n);
         if (rc != SSME_OK) return rc;
     }
-    double* ll_row = h->exp_out + (size_t)kMaxFunctionals * h->R;            // row 4: the members' log conditional likelihoods
-    double* means = h->exp_out + (size_t)(kMaxFunctionals + 1) * h->R;       // [5]
-    hipLaunchKernelGGL(k_collect_last_ll, dim3((h->R + 255) / 256), dim3(256), 0, h->stream, (const FilterScalars*)h->scal, ll_row, h->R);
-    if (n > 0) hipLaunchKernelGGL(k_rows_mean, dim3(n), dim3(kThreads), 0, h->stream, (const double*)h->exp_out, h->R, means);
-    hipLaunchKernelGGL(k_rows_mean, dim3(1), dim3(kThreads), 0, h->stream, (const double*)ll_row, h->R, means + kMaxFunctionals);
-    HIPCHK(hipGetLastError());
+    // one launch writes the n + 1 means straight into mapped host memory, where the host waits for them (see wait_results)
     double* pin = h->pin + 2 + h->R + 64;
-    HIPCHK(hipMemcpyAsync(pin, means, sizeof(double) * (kMaxFunctionals + 1), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(wait_stream_low_latency(h->stream));
+    mark_results_pending(pin, n);
+    mark_results_pending(pin + kMaxFunctionals, 1);
+    hipLaunchKernelGGL(k_swarm_means, dim3(n + 1), dim3(kThreads), 0, h->stream, (const double*)h->exp_out, (const FilterScalars*)h->scal,
+                       h->R, n, kMaxFunctionals, h->pin_dev + 2 + h->R + 64);
+    HIPCHK(hipGetLastError());
+    HIPCHK(wait_results(h->stream, pin + kMaxFunctionals, 1));
+    if (n > 0) HIPCHK(wait_results(h->stream, pin, n));
     *mean_logcondlike = pin[kMaxFunctionals];
     for (int i = 0; i < n; ++i) mean_expectations[i] = pin[i];
     round_out(h, mean_logcondlike, 1);

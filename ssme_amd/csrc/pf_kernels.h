@@ -1313,16 +1313,20 @@ __global__ __launch_bounds__(kThreads) void k_expect_final(const double* part, c
     }
 }
 
-// mean over the R rows of each of n_rows series: in [n_rows][R] -> out [n_rows]   (swarm aggregation on the device)
-__global__ __launch_bounds__(kThreads) void k_rows_mean(const double* in, int R, double* out) {
+// Swarm aggregation in one launch: block f < n: mean over the R members of expectation row f ([n][R] in exp_rows);
+// block n: mean of the members' last log conditional likelihoods.  out: n + 1 doubles at
+// out[0..n) and out[slot_ll] (device-mapped host memory: the host polls it).  grid (n + 1), block 256.
+__global__ __launch_bounds__(kThreads) void k_swarm_means(const double* exp_rows, const FilterScalars* scal, int R, int n, int slot_ll,
+                                                          double* out) {
     __shared__ double lds[4];
     const int tid = threadIdx.x, f = blockIdx.x;
     double s = 0.0;
-    for (int r = tid; r < R; r += kThreads) s = s + in[(size_t)f * R + r];
+    if (f < n) { for (int r = tid; r < R; r += kThreads) s = s + exp_rows[(size_t)f * R + r]; }
+    else { for (int r = tid; r < R; r += kThreads) s = s + scal[r].last_ll; }
     s = wave_sum_xor(s);
     if ((tid & 63) == 0) lds[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) out[f] = (((lds[0] + lds[1]) + lds[2]) + lds[3]) / (double)R;
+    if (tid == 0) out[f < n ? f : slot_ll] = (((lds[0] + lds[1]) + lds[2]) + lds[3]) / (double)R;
 }
 
 // Normalisable weights of one filter for host-side functionals (arbitrary std::function h: pswarm_filter.h:44,87-89):

@@ -1,6 +1,7 @@
 set -e
 mkdir -p gpurun_out
-for sd in 1 2 3 4; do
-python tests/soak_parity.py 3000 800 $sd > gpurun_out/r2_soak_$sd.log 2>&1
-tail -2 gpurun_out/r2_soak_$sd.log
-done
+python -m pytest tests -x -q -m gpu > gpurun_out/r2_t18.log 2>&1 || true
+tail -5 gpurun_out/r2_t18.log
+g++ -O2 -std=c++17 -Iinclude tools/step_latency.cpp -Lssme_amd -l:libssme_pf.so -Wl,-rpath,$PWD/ssme_amd -o tools/step_latency
+./tools/step_latency tests/golden/spy_returns.csv > gpurun_out/r2_lat18.txt 2>&1
+cat gpurun_out/r2_lat18.txt

@@ -39,6 +39,30 @@ static void run_lw(const std::vector<vec1>& data, const char* label) {
     std::printf("Liu-West filter() N=%s: %.1f us per call (loglik %.6f)\n", label, us, ll);
 }
 
+// SwarmWithCovs::update (pswarm_filter.h:380-460) with all members in one handle: one step launch + the aggregation
+template <std::size_t NS, std::size_t NP>
+struct lat_swarm : ssme_gpu::swarm_with_covs_gpu<NS, NP, double> {
+    using ssme_gpu::swarm_with_covs_gpu<NS, NP, double>::swarm_with_covs_gpu;
+    int k = 0;
+    std::vector<double> samp_untrans_params() override {
+        const double u = (0.5 + (k++ % 97)) / 97.0;
+        return {0.8 + 0.19 * u, -0.1 + 0.2 * u, 0.01 + 0.09 * u, -0.5 + 0.49 * u};
+    }
+};
+template <std::size_t NS, std::size_t NP>
+static void run_swarm(const std::vector<vec1>& data, const char* label) {
+    ssme_gpu::gpu_options o;
+    o.seed = 1;
+    lat_swarm<NS, NP> sw({SSME_H_CONST42, SSME_H_X}, o);
+    double ll = 0.0;
+    for (int t = 0; t < 64; ++t) { sw.update(data[t], vec1{t ? data[t - 1].v : 0.0}); ll += sw.getLogCondLike(); }
+    const int K = 500;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < K; ++t) { sw.update(data[64 + t], data[63 + t]); ll += sw.getLogCondLike(); }
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / K;
+    std::printf("swarm update() %s: %.1f us per call (loglik %.6f, E[x] %.6f)\n", label, us, ll, sw.getExpectations()[1]);
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::vector<vec1> data;
@@ -49,6 +73,8 @@ int main(int argc, char** argv) {
     run<4096>(data, "4096");
     run<65536>(data, "2^16");
     run<1048576>(data, "2^20");
+    run_swarm<500, 100>(data, "100 members x 500 particles, 2 functionals");
+    run_swarm<16384, 64>(data, "64 members x 2^14 particles, 2 functionals");
     run_lw<500>(data, "500");
     run_lw<65536>(data, "2^16");
     return 0;
