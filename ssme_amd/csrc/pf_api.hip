@@ -35,6 +35,7 @@ struct ssme_pf_s {
     double *l2_T, *l2_R;     // [R][Bs] split level-2 outputs
     int32_t *l2_lo, *l2_hi;
     size_t lds_bytes_big, lds_bytes_plan;
+    double* small_ms;        // [R][tcap][2] scratch of the one-tile whole-series kernel
     double* yz_step;         // device [2]: y and z of the step API, uploaded by ONE copy
     int32_t* ticket;         // device [R]: arrival counters of the step API's in-kernel accounting (zero between launches)
     double* pin;             // pinned, device-mapped host staging: [2 .. 2+R) log conditional likelihoods of the step API (written by the accounting kernel)
@@ -348,8 +349,12 @@ static void enqueue_step(ssme_pf_handle h, int t, int yi, int gi, bool has_z, bo
 template <int MODEL>
 static void launch_small_m(ssme_pf_handle h, const StepArgs& a, int T) {
     const dim3 grid(h->R);
-    if (h->N <= 256) hipLaunchKernelGGL((k_filter_series_small<MODEL, 128, 1>), grid, dim3(128), 0, h->stream, a, T);
-    else if (h->N <= 512) hipLaunchKernelGGL((k_filter_series_small<MODEL, 256, 1>), grid, dim3(256), 0, h->stream, a, T);
+    // one particle per lane up to 512 particles (twice the waves, about half the chain per wave: N = 100 3.0 -> 2.2 us per step,
+    // N = 500 3.3 -> 3.1); pairs above (N = 1000: 4.6 against 4.9 us; profiles/r02_small_series.txt)
+    if (h->N <= 64) hipLaunchKernelGGL((k_filter_series_lane<MODEL, 64>), grid, dim3(64), 0, h->stream, a, T);
+    else if (h->N <= 128) hipLaunchKernelGGL((k_filter_series_lane<MODEL, 128>), grid, dim3(128), 0, h->stream, a, T);
+    else if (h->N <= 256) hipLaunchKernelGGL((k_filter_series_lane<MODEL, 256>), grid, dim3(256), 0, h->stream, a, T);
+    else if (h->N <= 512) hipLaunchKernelGGL((k_filter_series_lane<MODEL, 512>), grid, dim3(512), 0, h->stream, a, T);
     else if (h->N <= 1024) hipLaunchKernelGGL((k_filter_series_small<MODEL, 512, 1>), grid, dim3(512), 0, h->stream, a, T);
     else hipLaunchKernelGGL((k_filter_series_small<MODEL, 512, 2>), grid, dim3(512), 0, h->stream, a, T);
 }
@@ -359,6 +364,7 @@ static void enqueue_series_small(ssme_pf_handle h, int T, bool has_z) {
     StepArgs a = step_args(h);
     a.z = has_z ? h->zbuf : nullptr;
     a.per_step = h->per_step;
+    a.small_ms = h->small_ms;
     switch (h->cfg.model) {
         case SSME_MODEL_SVOL: launch_small_m<MODEL_SVOL>(h, a, T); break;
         case SSME_MODEL_SVOL_LEVERAGE: launch_small_m<MODEL_SVOL_LEVERAGE>(h, a, T); break;
@@ -397,8 +403,10 @@ static int ensure_series_capacity(ssme_pf_handle h, int T) {
     if (rcg != SSME_OK) return rcg;
     if (T > h->tcap) {
         if (h->per_step) hipFree(h->per_step);
-        h->per_step = nullptr;
+        if (h->small_ms) hipFree(h->small_ms);
+        h->per_step = h->small_ms = nullptr;
         HIPCHK(hipMalloc(&h->per_step, sizeof(double) * (size_t)T * h->R));
+        if (h->B == 1) HIPCHK(hipMalloc(&h->small_ms, sizeof(double) * (size_t)T * h->R * 2));
         h->tcap = T;
         if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     }
@@ -541,7 +549,7 @@ int ssme_pf_destroy(ssme_pf_handle h) {
     h->stream = h->own_stream;
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     void* bufs[] = {h->x[0], h->x[1], h->cdf[0], h->cdf[1], h->tsum[0], h->tsum[1], h->tmax[0], h->tmax[1], h->logw,
-                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_lo, h->l2_hi, h->yz_step, h->ticket, h->exp_part, h->exp_out, h->wscratch,
+                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_lo, h->l2_hi, h->yz_step, h->ticket, h->small_ms, h->exp_part, h->exp_out, h->wscratch,
                     h->sh_x[0], h->sh_x[1], h->sh_c[0], h->sh_c[1], h->sh_loc, h->sh_raw, h->sh_tsum, h->sh_tmax, h->sh_winx, h->sh_winc, h->sh_flag};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->pin) hipHostFree(h->pin);

@@ -89,6 +89,7 @@ struct StepArgs {
     int32_t by_value;          // 1: use y_now / z_now instead of y[yi] / z[yi] (no upload, no memory read)
     double* ll_host;           // step API: host-mapped buffer that receives the R log conditional likelihoods from the accounting kernel, or null
     double* per_step;          // [R][Tcap] or null
+    double* small_ms;          // [R][Tcap][2] scratch of k_filter_series_lane: (m_t, S_t), then lse_t
     const double* gam;         // [nT][R][B] Gamma(n_b) draws          (multinomial)
     const double* pgam;        // [nT][R][B] exclusive prefixes of gam
     const double* gtot;        // [nT][R]    sum(gam) + E_{N+1}

@@ -262,4 +262,218 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One particle per lane (N <= 512; measured slower than the pair kernel at 1024).  The pair kernel above runs one wave per SIMD, each carrying the ~1000-instruction
+// chain of a particle PAIR, and is bound by dependent-instruction latency.  Here a lane owns ONE particle: the two lanes
+// of a pair both evaluate the pair's Philox call and Box-Muller (lanes are free, instructions are not) and each keeps
+// its own half, so a wave's chain per step is ~55 % of the pair kernel's and twice as many waves share a SIMD.
+// The log conditional likelihoods leave the time loop altogether: a step only records (m_t, S_t) (thread 0, 16 bytes);
+// after the loop the T logarithms are evaluated in parallel and one wave replays the sequential accounting
+// (ll_t = lse_t - prev_t, loglik += ll_t) in the order of the loop, 64 steps per load.  Same arithmetic, same bits.
+// grid = (R), block = NT = P particle slots (64 .. 512); a.small_ms: [R][Tcap][2] scratch.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void block_scan1_f64(double v, double& incl, double& total, double* lds_seg) {
+    constexpr int NSEG = NT / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double inc = wave_incl_scan_f64(v);
+    if constexpr (NSEG == 1) { incl = inc; total = readlane_f64(inc, 63); return; }
+    if (lane == 63) lds_seg[wave] = inc;
+    __syncthreads();
+    double sv = (lane & 15) < NSEG ? lds_seg[lane & 15] : 0.0;
+    sv = sv + dpp_f64_zero<0x111, 0xF>(sv);
+    sv = sv + dpp_f64_zero<0x112, 0xF>(sv);
+    sv = sv + dpp_f64_zero<0x114, 0xF>(sv);
+    sv = sv + dpp_f64_zero<0x118, 0xF>(sv);
+    total = readlane_f64(sv, 15);
+    const double pre = wave ? readlane_f64(sv, wave - 1) : 0.0;
+    incl = pre + inc;
+}
+
+// min(#{ j < P : tile[j] < target }, P-1) by a radix-8 descent (see count_less_radix8_x2)
+template <int P>
+__device__ __forceinline__ int count_less_radix8(const double* tile, double t0) {
+    int p0 = 0;
+#pragma unroll
+    for (int w = P; w > 1;) {
+        const int radix = (w >= 8) ? 8 : w;
+        const int s = w / radix;
+        int c0 = 0;
+#pragma unroll
+        for (int k = 1; k < radix; ++k) c0 += (tile[p0 + k * s - 1] < t0) ? 1 : 0;
+        p0 += c0 * s;
+        w = s;
+    }
+    return p0;
+}
+
+template <int MODEL, int NT>
+__global__ __launch_bounds__(NT) void k_filter_series_lane(const StepArgs a, const int T) {
+    constexpr int P = NT;
+    __shared__ double lds_x[P];
+    __shared__ double lds_cdf[P];
+    __shared__ double lds_seg_a[16];
+    __shared__ double lds_seg_c[16];
+    __shared__ double lds_d2[16];
+    __shared__ __attribute__((aligned(16))) LogTabEntry lds_ltab[SSME_LOG_TABLE_SIZE];
+    __shared__ __attribute__((aligned(16))) ExpTabEntry lds_etab[SSME_EXP_TABLE_SIZE];
+
+    const int tid = threadIdx.x;
+    load_log_table<NT>(lds_ltab);
+    load_exp_table<NT>(lds_etab);
+    __syncthreads();
+    const int r = blockIdx.x;
+    const uint32_t rep = a.first_filter + (uint32_t)r;
+    const uint32_t key0 = a.keyp[0], key1 = a.keyp[1];
+    const size_t rowoff = (size_t)r * a.Npad;
+    const ModelConst mc = a.mc[r];
+    const bool multinomial_kind = a.resampler == RESAMP_MULTINOMIAL;
+    const bool valid = tid < a.N;
+    const int c = tid & 1;                            // which half of the pair (tid >> 1) this lane keeps
+    double* ms = a.small_ms + (size_t)r * a.Tcap * 2;
+
+    double xcur = 0.0, lwcur = 0.0;
+    double A_prev = 0.0, mb_prev = 0.0;
+    double y_n = a.y[0], z_n = a.z ? a.z[0] : 0.0;
+    double gam_n = 0.0, pgam_n = 0.0, G_n = 1.0;
+
+    for (int t = 0; t < T; ++t) {
+        const double y = y_n, zcov = z_n;
+        const double gam = gam_n, pgam = pgam_n, G = G_n;
+        if (t + 1 < T) {
+            y_n = a.y[t + 1];
+            if (a.z) z_n = a.z[t + 1];
+            if (multinomial_kind && ((t + 1) % a.resamp_sched == 0)) {
+                const size_t gidx = ((size_t)(t + 1) * a.R + r) * a.B;
+                gam_n = a.gam[gidx]; pgam_n = a.pgam[gidx]; G_n = a.gtot[(size_t)(t + 1) * a.R + r];
+            }
+        }
+        const bool resampled = (t > 0) && (t % a.resamp_sched == 0);
+        const bool multinomial = resampled && multinomial_kind;
+
+        // --- level-2 with one tile; (m, S) of step t-1 go to the scratch, their logarithm is taken after the loop ---
+        double S = 0.0, R0 = 0.0;
+        if (t > 0) {
+            const double m = (mb_prev != mb_prev) ? dnan() : mb_prev;
+            const double dm = mb_prev - m;
+            const int sh = a.rshift - kTileShift;
+            const double Ap = (dm == 0.0 && sh == 0) ? __builtin_rint(A_prev) : __builtin_rint(A_prev * dexp_scaled_t(dm, sh, lds_etab));
+            S = Ap;
+            R0 = A_prev / Ap;
+            if (tid == 0) { ms[2 * (t - 1)] = m; ms[2 * (t - 1) + 1] = S; }
+        }
+
+        // --- the pair's Philox call: words 0-1 -> Box-Muller (this lane keeps cos or sin), words 2 / 3 -> this lane's spacing ---
+        double zn, le = 0.0, se = 1.0;
+        {
+            const u32x4 o = pair_words((uint32_t)(tid >> 1), (uint32_t)t, rep, key0, key1);
+            double z0, z1;
+            pair_normals(o.v0, o.v1, lds_ltab, &z0, &z1);
+            zn = c ? z1 : z0;
+            if (multinomial) {
+                const double e = -dlog_u(u01_mid32(c ? o.v3 : o.v2), lds_ltab);
+                const double qe = valid ? __builtin_rint(e * 34359738368.0 /* 2^35 */) : 0.0;
+                block_scan1_f64<NT>(qe, le, se, lds_seg_a);
+            }
+        }
+
+        double xin = 0.0, lw_old = 0.0;
+        if (t == 0) {
+        } else if (!resampled) {
+            xin = xcur; lw_old = lwcur;
+        } else {
+            double tau;
+            if (a.resampler == RESAMP_MULTINOMIAL) {
+                const double t_scale = S / G;
+                const double ratio = gam / se;
+                const double t1 = ratio * le;
+                const double t2 = pgam + t1;
+                tau = __builtin_ceil(t2 * t_scale);
+            } else if (a.resampler == RESAMP_SYSTEMATIC) {
+                const double t_scale = S / (double)a.N;
+                const u32x4 ox = philox4x32_10(0u, (uint32_t)t, rep, STREAM_RESAMP_EXTRA, key0, key1);
+                const double u0 = u01_co(ox.v0, ox.v1);
+                tau = __builtin_ceil(((double)tid + u0) * t_scale);
+            } else {
+                const double t_scale = S / (double)a.N;
+                const u32x4 o = philox4x32_10((uint32_t)(tid >> 1), (uint32_t)t, rep, STREAM_RESAMP, key0, key1);
+                const double v = c ? u01_co(o.v2, o.v3) : u01_co(o.v0, o.v1);
+                tau = (a.resampler == RESAMP_STRATIFIED) ? __builtin_ceil(((double)tid + v) * t_scale) : __builtin_ceil(v * S);
+            }
+            const double tl = __builtin_ceil((tau - 0.0) * R0);
+            const int jj = count_less_radix8<P>(lds_cdf, tl);
+            const int anc = jj < a.N - 1 ? jj : a.N - 1;
+            if (a.anc && valid) a.anc[rowoff + tid] = (uint32_t)anc;
+            xin = lds_x[anc];
+        }
+
+        // --- fSamp / q1Samp, logGEv, tile max ---
+        const double xn = (t == 0) ? zn * mc.a2 : model_prop<MODEL>(mc, xin, zn, zcov, lds_etab);
+        const double l = lw_old + model_logg<MODEL>(mc, y, xn, lds_etab);
+        xcur = valid ? xn : 0.0;
+        const double lg = valid ? l : -dinf();
+        lwcur = lg;
+        const bool nan = valid && (l != l);
+        const double mx = (valid && l > -dinf()) ? l : -dinf();
+        const double mb = block_max_nanprop<NT>(mx, nan, lds_d2);    // barrier: every search / gather of this step is done
+
+        // --- tile-local fixed-point weights, exact scan -> the next step's cdf (LDS) ---
+        const double q = valid ? __builtin_rint(dexp_scaled_t(lg - mb, kTileShift, lds_etab)) : 0.0;
+        double inc, total;
+        block_scan1_f64<NT>(q, inc, total, lds_seg_c);
+        lds_cdf[tid] = inc;
+        lds_x[tid] = xcur;
+        A_prev = total;
+        mb_prev = mb;
+        __syncthreads();                                              // cdf / x of step t visible to step t+1
+    }
+
+    // --- the last step's (m, S); then every log conditional likelihood: logarithms in parallel, accounting in loop order ---
+    const double m_last = (mb_prev != mb_prev) ? dnan() : mb_prev;
+    const double S_last = __builtin_rint(A_prev * dexp_scaled_t(mb_prev - m_last, a.rshift - kTileShift, lds_etab));
+    if (tid == 0) { ms[2 * (T - 1)] = m_last; ms[2 * (T - 1) + 1] = S_last; }
+    __syncthreads();
+    for (int t = tid; t < T; t += NT) {
+        const double m = ms[2 * t], S = ms[2 * t + 1];
+        const double Sd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
+        ms[2 * t] = m + dlog(Sd);                     // lse_t (this thread wrote... read its own slot only)
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double prev = a.scal[r].prev, loglik = a.scal[r].loglik, last = 0.0;
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + tid;
+            const double lse = (t < T) ? ms[2 * t] : 0.0;
+            double mine = 0.0;
+            const int nb = (T - t0 < 64) ? T - t0 : 64;
+            for (int j = 0; j < nb; ++j) {
+                const double lj = readlane_f64(lse, j);
+                const double ll = lj - prev;
+                loglik = loglik + ll;
+                prev = (((t0 + j + 1) % a.resamp_sched) == 0) ? a.logN : lj;
+                last = ll;
+                if (tid == j) mine = ll;
+            }
+            if (t < T && a.per_step) a.per_step[(size_t)r * a.Tcap + t] = mine;
+        }
+        if (tid == 0) {
+            FilterScalars* o = a.scal + r;
+            o->m = m_last; o->S = S_last; o->prev = prev; o->loglik = loglik; o->last_ll = last;
+            a.tsum_out[(size_t)r * a.Bs] = A_prev;
+            a.tmax_out[(size_t)r * a.Bs] = mb_prev;
+        }
+    }
+    // --- state hand-over: what k_filter_step leaves (slots beyond N: x = 0, flat cdf, log-weight -inf) ---
+    a.x_out[rowoff + tid] = xcur;
+    a.cdf_out[rowoff + tid] = lds_cdf[tid];
+    if (a.logw) a.logw[rowoff + tid] = lwcur;
+    for (int i = P + tid; i < kTile; i += NT) {
+        a.x_out[rowoff + i] = 0.0;
+        a.cdf_out[rowoff + i] = A_prev;
+        if (a.logw) a.logw[rowoff + i] = -dinf();
+    }
+}
+
 }  // namespace ssme

@@ -1,7 +1,9 @@
 set -e
 mkdir -p gpurun_out
-python -m pytest tests -x -q -m gpu > gpurun_out/r2_t18.log 2>&1 || true
-tail -5 gpurun_out/r2_t18.log
-g++ -O2 -std=c++17 -Iinclude tools/step_latency.cpp -Lssme_amd -l:libssme_pf.so -Wl,-rpath,$PWD/ssme_amd -o tools/step_latency
-./tools/step_latency tests/golden/spy_returns.csv > gpurun_out/r2_lat18.txt 2>&1
-cat gpurun_out/r2_lat18.txt
+for cfg in "--n 50" "--n 100" "--n 250" "--n 500" "--n 1000" "--n 500 --filters 100" "--n 100 --filters 100" "--n 500 --filters 100 --model 1" "--n 500 --resampler 1"; do
+  for sp in 1 0; do
+  echo "$cfg pair=$sp" >> gpurun_out/r2_small20.log
+  SSME_SMALL_PAIR=$sp python tools/prof_run.py --T 3084 --passes 3 $cfg >> gpurun_out/r2_small20.log 2>&1
+  done
+done
+grep -v amdgpu.ids gpurun_out/r2_small20.log | cut -c1-120
