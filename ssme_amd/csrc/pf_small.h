@@ -36,6 +36,46 @@ __device__ __forceinline__ void count_less_radix8_x2(const double* tile, double 
     j0 = p0; j1 = p1;
 }
 
+// Log conditional likelihoods of a whole series outside the time loop (both one-tile kernels): the loop only records
+// (m_t, S_t) (thread 0, ms[2t], ms[2t+1]); here the T logarithms are evaluated in parallel and one wave replays the
+// sequential accounting (ll_t = lse_t - prev_t, loglik += ll_t) in loop order, 64 steps per load.  Same arithmetic and
+// order as kf_finalize step by step, so the same bits.  Called by every thread after a barrier that follows the last record.
+template <int NT>
+__device__ __forceinline__ void series_accounting(const StepArgs& a, int r, int T, double* ms, double m_last, double S_last,
+                                                  double A_prev, double mb_prev) {
+    const int tid = threadIdx.x;
+    for (int t = tid; t < T; t += NT) {
+        const double m = ms[2 * t], S = ms[2 * t + 1];
+        const double Sd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
+        ms[2 * t] = m + dlog(Sd);                     // lse_t
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double prev = a.scal[r].prev, loglik = a.scal[r].loglik, last = 0.0;
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + tid;
+            const double lse = (t < T) ? ms[2 * t] : 0.0;
+            double mine = 0.0;
+            const int nb = (T - t0 < 64) ? T - t0 : 64;
+            for (int j = 0; j < nb; ++j) {
+                const double lj = readlane_f64(lse, j);
+                const double ll = lj - prev;
+                loglik = loglik + ll;
+                prev = (((t0 + j + 1) % a.resamp_sched) == 0) ? a.logN : lj;
+                last = ll;
+                if (tid == j) mine = ll;
+            }
+            if (t < T && a.per_step) a.per_step[(size_t)r * a.Tcap + t] = mine;
+        }
+        if (tid == 0) {
+            FilterScalars* o = a.scal + r;
+            o->m = m_last; o->S = S_last; o->prev = prev; o->loglik = loglik; o->last_ll = last;
+            a.tsum_out[(size_t)r * a.Bs] = A_prev;
+            a.tmax_out[(size_t)r * a.Bs] = mb_prev;
+        }
+    }
+}
+
 // grid = (R filters), block = NT, covers P = 2*NT*NK >= N particle slots (P a power of two, 256 .. 2048).
 // a.x_out / cdf_out / tsum_out / tmax_out / logw receive the state after the last step (as k_filter_step
 // leaves it), a.scal the accumulated log-likelihood; a.t / yi / gi are ignored (t = yi = gi = 0 .. T-1).
@@ -61,9 +101,7 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
     const ModelConst mc = a.mc[r];
     const bool multinomial_kind = a.resampler == RESAMP_MULTINOMIAL;
 
-    FilterScalars sc;                                // every thread carries the (uniform) scalars
-    sc.m = 0.0; sc.S = 0.0; sc.last_ll = 0.0;
-    sc.prev = a.scal[r].prev; sc.loglik = a.scal[r].loglik;
+    double* ms = a.small_ms + (size_t)r * a.Tcap * 2;
     double xcur[NK][2], lwcur[NK][2];
 #pragma unroll
     for (int k = 0; k < NK; ++k) { xcur[k][0] = 0.0; xcur[k][1] = 0.0; lwcur[k][0] = 0.0; lwcur[k][1] = 0.0; }
@@ -97,13 +135,7 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
             const double Ap = (dm == 0.0 && sh == 0) ? __builtin_rint(A_prev) : __builtin_rint(A_prev * dexp_scaled_t(dm, sh, lds_etab));
             S = Ap;
             R0 = A_prev / Ap;
-            const double Sdd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
-            const double lse = m + dlog(Sdd);
-            const double ll = lse - sc.prev;
-            sc.m = m; sc.S = S; sc.last_ll = ll;
-            sc.loglik = sc.loglik + ll;
-            sc.prev = resampled ? a.logN : lse;
-            if (tid == 0 && a.per_step) a.per_step[(size_t)r * a.Tcap + (t - 1)] = ll;
+            if (tid == 0) { ms[2 * (t - 1)] = m; ms[2 * (t - 1) + 1] = S; }       // its logarithm is taken after the loop
         }
 
         // --- standard normals of this step: independent of the resampling chain, issued next to the spacings so that the
@@ -226,24 +258,13 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
         __syncthreads();                                              // cdf / x of step t visible to step t+1
     }
 
-    // --- log conditional likelihood of the last step (kf_finalize) and the state hand-over ---
+    // --- the last step's (m, S), then the accounting of the whole series (series_accounting) and the state hand-over ---
     {
-        const double m = (mb_prev != mb_prev) ? dnan() : mb_prev;
-        const double S = __builtin_rint(A_prev * dexp_scaled_t(mb_prev - m, a.rshift - kTileShift, lds_etab));
-        const bool resample_now = (T % a.resamp_sched == 0);
-        const double Sd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
-        const double lse = m + dlog(Sd);
-        const double ll = lse - sc.prev;
-        sc.m = m; sc.S = S; sc.last_ll = ll;
-        sc.loglik = sc.loglik + ll;
-        sc.prev = resample_now ? a.logN : lse;
-        if (tid == 0) {
-            if (a.per_step) a.per_step[(size_t)r * a.Tcap + (T - 1)] = ll;
-            FilterScalars* o = a.scal + r;
-            o->m = sc.m; o->S = sc.S; o->prev = sc.prev; o->loglik = sc.loglik; o->last_ll = sc.last_ll;
-            a.tsum_out[(size_t)r * a.Bs] = A_prev;
-            a.tmax_out[(size_t)r * a.Bs] = mb_prev;
-        }
+        const double m_last = (mb_prev != mb_prev) ? dnan() : mb_prev;
+        const double S_last = __builtin_rint(A_prev * dexp_scaled_t(mb_prev - m_last, a.rshift - kTileShift, lds_etab));
+        if (tid == 0) { ms[2 * (T - 1)] = m_last; ms[2 * (T - 1) + 1] = S_last; }
+        __syncthreads();
+        series_accounting<NT>(a, r, T, ms, m_last, S_last, A_prev, mb_prev);
     }
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -435,36 +456,7 @@ __global__ __launch_bounds__(NT) void k_filter_series_lane(const StepArgs a, con
     const double S_last = __builtin_rint(A_prev * dexp_scaled_t(mb_prev - m_last, a.rshift - kTileShift, lds_etab));
     if (tid == 0) { ms[2 * (T - 1)] = m_last; ms[2 * (T - 1) + 1] = S_last; }
     __syncthreads();
-    for (int t = tid; t < T; t += NT) {
-        const double m = ms[2 * t], S = ms[2 * t + 1];
-        const double Sd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
-        ms[2 * t] = m + dlog(Sd);                     // lse_t (this thread wrote... read its own slot only)
-    }
-    __syncthreads();
-    if (tid < 64) {
-        double prev = a.scal[r].prev, loglik = a.scal[r].loglik, last = 0.0;
-        for (int t0 = 0; t0 < T; t0 += 64) {
-            const int t = t0 + tid;
-            const double lse = (t < T) ? ms[2 * t] : 0.0;
-            double mine = 0.0;
-            const int nb = (T - t0 < 64) ? T - t0 : 64;
-            for (int j = 0; j < nb; ++j) {
-                const double lj = readlane_f64(lse, j);
-                const double ll = lj - prev;
-                loglik = loglik + ll;
-                prev = (((t0 + j + 1) % a.resamp_sched) == 0) ? a.logN : lj;
-                last = ll;
-                if (tid == j) mine = ll;
-            }
-            if (t < T && a.per_step) a.per_step[(size_t)r * a.Tcap + t] = mine;
-        }
-        if (tid == 0) {
-            FilterScalars* o = a.scal + r;
-            o->m = m_last; o->S = S_last; o->prev = prev; o->loglik = loglik; o->last_ll = last;
-            a.tsum_out[(size_t)r * a.Bs] = A_prev;
-            a.tmax_out[(size_t)r * a.Bs] = mb_prev;
-        }
-    }
+    series_accounting<NT>(a, r, T, ms, m_last, S_last, A_prev, mb_prev);
     // --- state hand-over: what k_filter_step leaves (slots beyond N: x = 0, flat cdf, log-weight -inf) ---
     a.x_out[rowoff + tid] = xcur;
     a.cdf_out[rowoff + tid] = lds_cdf[tid];
