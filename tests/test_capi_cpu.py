@@ -41,7 +41,7 @@ def test_strerror_and_null_handling():
 
 @pytest.mark.parametrize("field,value,status", [
     ("n_particles", 0, 1), ("n_filters", 0, 1), ("model", 9, 1), ("resampler", 7, 1), ("resamp_sched", 0, 1),
-    ("dtype", 1, 3), ("n_particles", (1 << 25) + 1, 3),
+    ("dtype", 2, 1), ("n_particles", (1 << 25) + 1, 3),
 ])
 def test_create_validates_config(field, value, status):
     from ssme_amd import _capi
@@ -91,6 +91,8 @@ def test_shard_and_liu_west_entry_points_validate_arguments():
     assert L.ssme_pf_shard_create(C.byref(cfg), 0, 2, C.byref(h)) == _capi.ERR_UNSUPPORTED        # one filter only
     cfg.n_filters, cfg.resamp_sched = 1, 2
     assert L.ssme_pf_shard_create(C.byref(cfg), 0, 2, C.byref(h)) == _capi.ERR_UNSUPPORTED
+    cfg.resamp_sched, cfg.dtype = 1, _capi.F32
+    assert L.ssme_pf_shard_create(C.byref(cfg), 0, 2, C.byref(h)) == _capi.ERR_UNSUPPORTED        # float-at-the-boundary handles do not shard
     assert not h.value
     for fn in (L.ssme_pf_set_stream, ):
         assert fn(None, None) == _capi.ERR_INVALID_ARG
