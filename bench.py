@@ -268,8 +268,14 @@ def main():
     sync()
     t0 = time.perf_counter()
     ll = None
-    for _ in range(args.steps):
+    pass_lls = []
+    for k in range(args.steps):
+        if args.mode == "replicas":
+            # seed 20260101 "and 4 more seeds for spread": pass k runs seed + k, the last pass the base
+            # seed again (set_seed keeps the captured graph: the key lives in device memory), same workload every pass
+            bank.set_seed(SEED + (k + 1) % args.steps)
         ll = run()
+        pass_lls.append(float(ll))
         if args.mode == "replicas":
             dev_ms += bank.last_elapsed_ms()
     sync()
@@ -310,6 +316,7 @@ def main():
                                        f"particles sharded x{world} (per step: all_gather of tile sums/maxima + halo tile exchange)"),
                        "backend": "gloo rehearsal on one GPU (NOT a performance number)" if rehearse else ("rccl" if world > 1 or args.mode == "sharded" else "none")},
             "loglik_log_mean_exp": lme,
+            "loglik_by_pass": pass_lls if args.mode == "replicas" else None,          # rank 0's filter, seeds SEED+1 .. , SEED (last)
         }
         if args.mode == "replicas":
             out["device_ms_per_step"] = dev_ms / args.steps

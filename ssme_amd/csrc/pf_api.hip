@@ -1621,8 +1621,9 @@ static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record
         hipLaunchKernelGGL(k_lw_mid<true>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
         hipLaunchKernelGGL(k_lw_stage2<true>, grid, dim3(kLwNT), h->lds_bytes_big, h->stream, a);
     } else {
+        // two launches: every workgroup of stage 2 takes theta-bar and the Cholesky factor from stage 1's tile partials itself
+        a.fuse_mid = 1;
         hipLaunchKernelGGL(k_lw_stage1<false>, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
-        hipLaunchKernelGGL(k_lw_mid<false>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
         hipLaunchKernelGGL(k_lw_stage2<false>, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
     }
 }

@@ -161,6 +161,12 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
     return bits2d(((u64)hi << 32) | lo);
 }
+__device__ __forceinline__ double readfirstlane_f64(double v) {       // a value every lane holds -> scalar registers
+    const u64 b = d2bits(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+    return bits2d(((u64)hi << 32) | lo);
+}
 
 // row_shr:n = 0x110+n ; row_bcast:15 = 0x142 ; row_bcast:31 = 0x143 ; wave_shr:1 = 0x138
 __device__ __forceinline__ u64 readlane_u64(u64 v, int lane) {
