@@ -643,30 +643,41 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
 #pragma unroll
         for (int q = 0; q < 14; ++q) prop[q] = a.prop[(size_t)r * 16 + q];
     } else {
+        // the tile partials ([B][16] doubles, 14 used) come in through LDS: one coalesced pass into the not yet used window
+        // area (B <= 512 tiles x 14 doubles = at most the 56 KB of lds_T + lds_R + three staged tiles), then every lane
+        // walks its chunk there.  (Read straight from global memory each lane touches its own cache line per tile:
+        // 8192 line accesses per workgroup, +8 us per launch.)
+        double* lds_momall = L.lds_T;
+        const double* gm = a.mom + (size_t)r * a.B * 16;
+        {
+            // all loads of a thread are issued before its first LDS store (a rolled loop waits for every load in turn);
+            // B * 14 doubles fit the window area (host check), i.e. B * 7 <= 8 * NT pairs
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = tid + u * NT, j = it / 7, p2 = it - j * 7;
+                v[u] = make_double2(0.0, 0.0);
+                if (it < a.B * 7) v[u] = *reinterpret_cast<const double2*>(gm + (size_t)j * 16 + 2 * p2);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = tid + u * NT, j = it / 7, p2 = it - j * 7;
+                if (it < a.B * 7) *reinterpret_cast<double2*>(lds_momall + j * kNMom + 2 * p2) = v[u];
+            }
+        }
+        __syncthreads();
         const int lane = tid & 63, wave = tid >> 6;
         const int cch = (a.B + 63) / 64;
         const int j0 = lane * cch, j1 = ((lane + 1) * cch < a.B) ? (lane + 1) * cch : a.B;
-        double acc[2] = {0.0, 0.0};
-        for (int j = j0; j < j1; j += 8) {
-            double v[2][8];
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-                const int q = wave + 8 * qi;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[qi][u] = (q < kNMom && j + u < j1) ? a.mom[((size_t)r * a.B + j + u) * 16 + q] : 0.0;
-            }
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) if (j + u < j1) acc[qi] = acc[qi] + v[qi][u];
-            }
-        }
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
             const int q = wave + 8 * qi;
-            const double sw = wave_incl_scan_f64(acc[qi]);
+            double acc = 0.0;
+            if (q < kNMom) for (int j = j0; j < j1; ++j) acc = acc + lds_momall[j * kNMom + q];
+            const double sw = wave_incl_scan_f64(acc);
             if (lane == 63 && q < kNMom) lds_sums[q] = sw;
         }
+        __syncthreads();                                   // the window area is free again (lw_select fills it next)
     }
 
     // form 0: k ~ Categorical(first-stage weights): k_gen.sample, :1006 (every step, whatever the resampling schedule);
@@ -696,7 +707,6 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
         }
     }
     if (fuse) {
-        __syncthreads();                                   // lds_sums complete (the SISR form has no barrier before this point)
         if (tid == 0) {
             lw_proposal_components(lds_sums, a.N, a.a_shrink, lds_prop);
             if (b == a.tile0) {                            // the filter's first workgroup keeps k_lw_mid's records

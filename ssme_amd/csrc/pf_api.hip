@@ -1621,9 +1621,11 @@ static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record
         hipLaunchKernelGGL(k_lw_mid<true>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
         hipLaunchKernelGGL(k_lw_stage2<true>, grid, dim3(kLwNT), h->lds_bytes_big, h->stream, a);
     } else {
-        // two launches: every workgroup of stage 2 takes theta-bar and the Cholesky factor from stage 1's tile partials itself
-        a.fuse_mid = 1;
+        // two launches when the tile partials ([B][14] doubles) fit the window area of stage 2's LDS: every workgroup of stage 2
+        // then takes theta-bar and the Cholesky factor from them itself
+        a.fuse_mid = ((size_t)h->B * kNMom * sizeof(double) <= h->lds_bytes) ? 1 : 0;
         hipLaunchKernelGGL(k_lw_stage1<false>, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
+        if (!a.fuse_mid) hipLaunchKernelGGL(k_lw_mid<false>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
         hipLaunchKernelGGL(k_lw_stage2<false>, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
     }
 }
