@@ -69,6 +69,7 @@ struct LwArgs {
     int32_t win_tiles;                          // C++ shard driver, fixed-halo path: tiles held in the source windows (0: unchecked)
     int32_t* win_flag;                          // ... and where to record that an output tile's sources left them, or null
     int32_t fuse_mid;                           // 1: k_lw_stage2 takes theta-bar and the Cholesky factor itself (no k_lw_mid launch)
+    double* momtot;                             // [R][16] moment totals from k_lw_mom_totals (filters of many tiles), or null: k_lw_mid adds them itself
     // split level-2 (k_level2_plan; filters of more than 2048 tiles or by policy): per draw T', A/A', source ranges, (m, S)
     const double *l2B_T, *l2B_R, *l2A_T, *l2A_R;      // [R][Bs]
     const int32_t *l2B_lo, *l2B_hi, *l2A_lo, *l2A_hi;
@@ -558,6 +559,27 @@ __device__ __forceinline__ void lw_proposal_components(const double* sums, int N
 }
 
 // ---------------------------------------------------------------------------------------
+// Moment totals for filters of many tiles: one WAVE per (moment, filter) instead of one workgroup per filter for all 14
+// (k_lw_mid is a single workgroup bound by memory round trips: 81 us at 8192 tiles).  Same order of additions as k_lw_mid:
+// lane l adds its contiguous chunk of tiles in order, then the wave tree.  grid = (14, R), block = 64.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_lw_mom_totals(const LwArgs a) {
+    const int lane = threadIdx.x, q = blockIdx.x, r = blockIdx.y;
+    const int c = (a.B + 63) / 64;
+    const int j0 = lane * c, j1 = ((lane + 1) * c < a.B) ? (lane + 1) * c : a.B;
+    double acc = 0.0;
+    for (int j = j0; j < j1; j += 32) {
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = (j + u < j1) ? a.mom[((size_t)r * a.B + j + u) * 16 + q] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) if (j + u < j1) acc = acc + v[u];
+    }
+    const double sw = wave_incl_scan_f64(acc);
+    if (lane == 63) a.momtot[(size_t)r * 16 + q] = sw;
+}
+
+// ---------------------------------------------------------------------------------------
 // Mid: proposal components (:1184-1198) + log-sum-exp of the first-stage weights.  grid = (R), block = 256
 // ---------------------------------------------------------------------------------------
 template <bool BIG>
@@ -575,7 +597,9 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid(const LwArgs a) {
     // wave w sums moments w, w+4, w+8, w+12; for each, lane l adds its chunk of tiles in order and the wave tree adds the
     // 64 chunk sums.  The loads of all of a wave's moments are issued together (8 tiles x 4 moments per batch) so that
     // one memory latency is paid per batch, not per moment; the order of the additions is that of a plain loop.
-    {
+    if (a.momtot) {
+        if (tid < kNMom) sums[tid] = a.momtot[(size_t)r * 16 + tid];
+    } else {
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
         const int j0 = lane * c, j1 = ((lane + 1) * c < a.B) ? (lane + 1) * c : a.B;
         for (int j = j0; j < j1; j += 8) {

@@ -33,6 +33,7 @@ struct ssme_pf_s {
     int32_t* plan_dev;       // [world][2] source-tile ranges (k_shard_plan)
     int split_l2;            // 1: level-2 by k_level2_plan (filters of more than 2048 tiles, or forced by set_debug bit 2)
     double *l2_T, *l2_R;     // [R][Bs] split level-2 outputs
+    double* l2_work;         // [R][Bs] + [R][32]: scratch of the multi-workgroup level-2
     int32_t *l2_lo, *l2_hi;
     size_t lds_bytes_big, lds_bytes_plan;
     double* small_ms;        // [R][tcap][2] scratch of the one-tile whole-series kernel
@@ -177,7 +178,7 @@ static StepArgs step_args(ssme_pf_handle h) {
     a.resampler = h->cfg.resampler; a.resamp_sched = h->cfg.resamp_sched;
     a.keyp = h->keybuf; a.first_filter = h->cfg.first_filter_id;
     a.logN = dlog((double)h->N);
-    a.l2_T = h->l2_T; a.l2_R = h->l2_R; a.l2_lo = h->l2_lo; a.l2_hi = h->l2_hi;
+    a.l2_T = h->l2_T; a.l2_R = h->l2_R; a.l2_lo = h->l2_lo; a.l2_hi = h->l2_hi; a.l2_work = h->l2_work;
     {
         // two 512-thread workgroups fit a CU (LDS): is the whole grid resident at once?
         const long blocks = (long)(h->shard_world > 0 ? h->B / h->shard_world : h->B) * h->R;
@@ -310,6 +311,15 @@ static void launch_gamma(ssme_pf_handle h, int t0, int nT) {
                            h->gam, h->pgam, h->gtot, h->B, h->R, nT, t0, (const uint32_t*)h->keybuf, h->cfg.first_filter_id,
                            (uint32_t)STREAM_RESAMP_EXTRA);
 }
+// the split level-2 of one draw: one workgroup per filter up to 1024 tiles, several above (k_l2_scan_blocks + k_l2_ranges)
+static void launch_level2(hipStream_t st, const StepArgs& a, int n_filters, size_t lds, int ranges) {
+    if (a.l2_work && a.B > 1024) {
+        const dim3 grid((a.B + 1023) / 1024, n_filters);
+        hipLaunchKernelGGL(k_l2_scan_blocks, grid, dim3(1024), 0, st, a);
+        hipLaunchKernelGGL(k_l2_ranges, grid, dim3(1024), lds, st, a, ranges);
+    } else
+        hipLaunchKernelGGL(k_level2_plan, dim3(n_filters), dim3(1024), lds, st, a, ranges);
+}
 // accounts the log conditional likelihood of step t from the buffers the step wrote (now `cur`)
 // split level-2 of the buffers `cur` holds: for the step t about to run (plan_ranges) or only the accounting of step t-1
 static void launch_plan(ssme_pf_handle h, int t, int gi, bool plan_ranges, bool finalize_prev, bool record_per_step,
@@ -318,7 +328,7 @@ static void launch_plan(ssme_pf_handle h, int t, int gi, bool plan_ranges, bool 
     a.t = t; a.gi = gi; a.finalize_prev = finalize_prev ? 1 : 0;
     a.ll_host = ll_host;
     a.per_step = record_per_step ? h->per_step : nullptr;
-    hipLaunchKernelGGL(k_level2_plan, dim3(h->R), dim3(1024), h->lds_bytes_plan, h->stream, a, plan_ranges ? 1 : 0);
+    launch_level2(h->stream, a, h->R, h->lds_bytes_plan, plan_ranges ? 1 : 0);
 }
 static void launch_kf(ssme_pf_handle h, int t, bool record_per_step, double* ll_host = nullptr) {
     if (h->split_l2) { launch_plan(h, t + 1, 0, false, true, record_per_step, ll_host); return; }
@@ -513,6 +523,9 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
         HIPCHK(hipGetLastError());
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level2_plan), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lds_bytes_plan));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_l2_ranges), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lds_bytes_plan));
+        HIPCHK(hipMalloc(&h->l2_work, sizeof(double) * ((size_t)h->R * h->Bs + (size_t)h->R * 32)));
         HIPCHK(hipMalloc(&h->l2_T, sizeof(double) * (size_t)h->R * h->Bs));
         HIPCHK(hipMalloc(&h->l2_R, sizeof(double) * (size_t)h->R * h->Bs));
         HIPCHK(hipMalloc(&h->l2_lo, sizeof(int32_t) * (size_t)h->R * h->Bs));
@@ -549,7 +562,7 @@ int ssme_pf_destroy(ssme_pf_handle h) {
     h->stream = h->own_stream;
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     void* bufs[] = {h->x[0], h->x[1], h->cdf[0], h->cdf[1], h->tsum[0], h->tsum[1], h->tmax[0], h->tmax[1], h->logw,
-                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_lo, h->l2_hi, h->yz_step, h->ticket, h->small_ms, h->exp_part, h->exp_out, h->wscratch,
+                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_work, h->l2_lo, h->l2_hi, h->yz_step, h->ticket, h->small_ms, h->exp_part, h->exp_out, h->wscratch,
                     h->sh_x[0], h->sh_x[1], h->sh_c[0], h->sh_c[1], h->sh_loc, h->sh_raw, h->sh_tsum, h->sh_tmax, h->sh_winx, h->sh_winc, h->sh_flag};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->pin) hipHostFree(h->pin);
@@ -616,7 +629,7 @@ static void shard_plan_device(ssme_pf_handle h, int t, const double* tsum_all, c
     StepArgs a = shard_args(h, t, tsum_all, tmax_all);
     if (h->split_l2) {
         a.finalize_prev = 1;
-        hipLaunchKernelGGL(k_level2_plan, dim3(1), dim3(1024), h->lds_bytes_plan, h->stream, a, 1);
+        launch_level2(h->stream, a, 1, h->lds_bytes_plan, 1);
         if (flag) hipLaunchKernelGGL(k_shard_window_check, dim3(1), dim3(64), 0, h->stream, (const int32_t*)nullptr, (const int32_t*)h->l2_lo,
                                      (const int32_t*)h->l2_hi, h->shard_world, h->B / h->shard_world, margin, flag, flag + 1);
     } else {
@@ -681,7 +694,7 @@ int ssme_pf_shard_finalize(ssme_pf_handle h, int32_t t, const double* tsum_all, 
     StepArgs a = shard_args(h, t, tsum_all, tmax_all);
     if (h->split_l2) {
         a.t = t + 1; a.finalize_prev = 1;
-        hipLaunchKernelGGL(k_level2_plan, dim3(1), dim3(1024), h->lds_bytes_plan, h->stream, a, 0);
+        launch_level2(h->stream, a, 1, h->lds_bytes_plan, 0);
     } else
         hipLaunchKernelGGL(kf_finalize, dim3(1), dim3(kThreads), 0, h->stream, a);
     HIPCHK(hipGetLastError());
@@ -1485,6 +1498,7 @@ struct ssme_lw_s {
     hipEvent_t ev0, ev1;
     float last_ms;
     double *xB, *thB, *xr, *thr, *lw1, *cdfA, *tsumA, *tmaxA, *cdfB, *tsumB, *tmaxB, *mom, *prop;
+    double* momtot;                  // [R][16] moment totals of k_lw_mom_totals (filters of more than 512 tiles)
     double* lwB;                     // carried second-stage log-weights (resamp_sched > 1 only)
     double* wscratch;                // [5][Npad] weights + untransformed parameters of one filter (host-side functionals)
     int form, rs;                    // 0 auxiliary form / 1 SISR form; resampling schedule m_rs
@@ -1507,6 +1521,7 @@ struct ssme_lw_s {
     int gamma_t0, gamma_rows;        // step API: the Gamma tables hold time indices gamma_t0 .. gamma_t0 + gamma_rows - 1
     int split_l2;                    // level-2 of both draws by k_level2_plan (more than 512 tiles)
     double *l2T[2], *l2R[2];         // [draw: 0 resampling (B), 1 k draw (A)][R][Bs]
+    double* l2_work;                 // scratch of the multi-workgroup level-2 (the two draws run one after the other)
     int32_t *l2lo[2], *l2hi[2];
     FilterScalars* l2s[2];
     size_t lds_bytes_big, lds_bytes_plan;
@@ -1602,7 +1617,8 @@ static void lw_launch_plan(ssme_lw_handle h, int draw, int t, int gi, const doub
     a.t = t; a.gi = gi; a.finalize_prev = 0;
     a.pgam = draw ? h->pgamA : h->pgamB; a.gtot = draw ? h->gtotA : h->gtotB;
     a.keyp = h->keybuf; a.first_filter = h->cfg.first_filter_id;
-    hipLaunchKernelGGL(k_level2_plan, dim3(h->shard_world > 0 ? 1 : h->R), dim3(1024), h->lds_bytes_plan, h->stream, a, ranges ? 1 : 0);
+    a.l2_work = h->l2_work;
+    launch_level2(h->stream, a, h->shard_world > 0 ? 1 : h->R, h->lds_bytes_plan, ranges ? 1 : 0);
 }
 
 static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record, bool finalize_prev, const double* yz_now = nullptr) {
@@ -1618,6 +1634,8 @@ static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record
         lw_launch_plan(h, 0, t, gi, h->tsumB, h->tmaxB, resampled);
         hipLaunchKernelGGL(k_lw_stage1<true>, grid, dim3(kLwNT), h->lds_bytes_big, h->stream, a);
         if (h->form == 0) lw_launch_plan(h, 1, t, gi, h->tsumA, h->tmaxA, true);
+        a.momtot = h->momtot;
+        hipLaunchKernelGGL(k_lw_mom_totals, dim3(kNMom, h->R), dim3(64), 0, h->stream, a);
         hipLaunchKernelGGL(k_lw_mid<true>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
         hipLaunchKernelGGL(k_lw_stage2<true>, grid, dim3(kLwNT), h->lds_bytes_big, h->stream, a);
     } else {
@@ -1658,9 +1676,9 @@ int ssme_lw_destroy(ssme_lw_handle h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     h->stream = h->own_stream;
-    void* bufs[] = {h->xB, h->thB, h->xr, h->thr, h->lw1, h->cdfA, h->tsumA, h->tmaxA, h->cdfB, h->tsumB, h->tmaxB, h->mom, h->prop,
+    void* bufs[] = {h->xB, h->thB, h->xr, h->thr, h->lw1, h->cdfA, h->tsumA, h->tmaxA, h->cdfB, h->tsumB, h->tmaxB, h->mom, h->prop, h->momtot,
                     h->ybuf, h->zbuf, h->per_step, h->scratch, h->gamA, h->pgamA, h->gtotA, h->gamB, h->pgamB, h->gtotB, h->anc,
-                    h->kidx, h->scal, h->keybuf, h->plan_dev, h->l2T[0], h->l2T[1], h->l2R[0], h->l2R[1], h->l2lo[0], h->l2lo[1],
+                    h->kidx, h->scal, h->keybuf, h->plan_dev, h->l2_work, h->l2T[0], h->l2T[1], h->l2R[0], h->l2R[1], h->l2lo[0], h->l2lo[1],
                     h->l2hi[0], h->l2hi[1], h->l2s[0], h->l2s[1], h->lwB, h->wscratch,
                     h->sh_xB, h->sh_thB, h->sh_cdfB, h->sh_xr, h->sh_thr, h->sh_g1, h->sh_cdfA, h->sh_locB, h->sh_locA, h->sh_allB_s, h->sh_allB_m,
                     h->sh_allA_s, h->sh_allA_m, h->sh_mom_all, h->sh_flag};
@@ -1703,6 +1721,7 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
     int rc = [&]() -> int {
         LWCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->own_stream = h->stream;
+        LWCHK(hipMalloc(&h->l2_work, sizeof(double) * ((size_t)h->R * h->Bs + (size_t)h->R * 32)));
         for (int d = 0; d < 2; ++d) {
             LWCHK(hipMalloc(&h->l2T[d], sizeof(double) * (size_t)h->R * h->Bs));
             LWCHK(hipMalloc(&h->l2R[d], sizeof(double) * (size_t)h->R * h->Bs));
@@ -1714,6 +1733,8 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
             LWCHK(hipMemset(h->l2s[d], 0, sizeof(FilterScalars) * (size_t)h->R));
         }
         LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level2_plan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)h->lds_bytes_plan));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_l2_ranges), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)h->lds_bytes_plan));
         LWCHK(hipEventCreate(&h->ev0));
         LWCHK(hipEventCreate(&h->ev1));
@@ -1733,6 +1754,7 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
         }
         LWCHK(hipMalloc(&h->mom, sizeof(double) * (size_t)h->R * h->B * 16));
         LWCHK(hipMalloc(&h->prop, sizeof(double) * (size_t)h->R * 16));
+        LWCHK(hipMalloc(&h->momtot, sizeof(double) * (size_t)h->R * 16));
         LWCHK(hipMemset(h->prop, 0, sizeof(double) * (size_t)h->R * 16));
         LWCHK(hipMalloc(&h->scal, sizeof(LwScalars) * h->R));
         LWCHK(hipMalloc(&h->scratch, sizeof(double) * h->R * kLwNExp));
@@ -1887,7 +1909,11 @@ int ssme_lw_shard_mid(ssme_lw_handle h, int32_t t, const double* tsumA_all, cons
     LwArgs a = lw_shard_args(h, t);
     a.tsumA = const_cast<double*>(tsumA_all); a.tmaxA = const_cast<double*>(tmaxA_all); a.mom = const_cast<double*>(mom_all);
     // split level-2: the plan of the k draw (ssme_lw_shard_plan(which = 1)) must precede this call -- it provides m and S
-    if (h->split_l2) hipLaunchKernelGGL(k_lw_mid<true>, dim3(1), dim3(kThreads), 0, h->stream, a);
+    if (h->split_l2) {
+        a.momtot = h->momtot;
+        hipLaunchKernelGGL(k_lw_mom_totals, dim3(kNMom, 1), dim3(64), 0, h->stream, a);
+        hipLaunchKernelGGL(k_lw_mid<true>, dim3(1), dim3(kThreads), 0, h->stream, a);
+    }
     else hipLaunchKernelGGL(k_lw_mid<false>, dim3(1), dim3(kThreads), 0, h->stream, a);
     LWCHK(hipGetLastError());
     return SSME_OK;

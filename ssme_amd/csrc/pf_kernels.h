@@ -109,6 +109,8 @@ struct StepArgs {
     double* l2_R;              // [R][Bs] A_b / A'_b
     int32_t* l2_lo;            // [R][Bs] first / last source tile of every output tile's targets
     int32_t* l2_hi;
+    double* l2_work;           // [R][Bs] block-local scans + [R][32] block totals and m: scratch of the multi-workgroup level-2
+                               // (k_l2_scan_blocks / k_l2_ranges, filters of more than 1024 tiles), or null
     int32_t prio_mode;         // wave-priority schedule of k_filter_step (prio_at): 0 none, 1 single residency wave, 2 several
     int32_t stream_stores;     // 1: particles and cdf are stored non-temporally (grids that are resident all at once)
     const uint32_t* keyp;      // [2] Philox key (the seed), device resident so that a captured graph survives ssme_pf_set_seed
@@ -1048,35 +1050,52 @@ __global__ __launch_bounds__(1024) void k_level2_plan(const StepArgs a, int plan
     double* Rp = a.l2_R + (size_t)r * a.Bs;
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const bool resampled = (a.t % a.resamp_sched == 0);
+    // This kernel is ONE workgroup per filter and bound by memory round trips, not by arithmetic: every tile sum and maximum
+    // is therefore requested up front (tile j = k * 1024 + tid, k < 16: coalesced, all loads in flight at once) and the
+    // max, the rescale and the scan run from registers.
+    constexpr int KMAX = kMaxTilesSplit / NT;                    // 16
+    double Areg[KMAX], Mreg[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int j = k * NT + tid;
+        Areg[k] = 0.0; Mreg[k] = -dinf();
+        if (j < a.B) { Areg[k] = ts[j]; Mreg[k] = tm[j]; }
+    }
     // global max of the tile maxima, NaN propagating
     double mx = -dinf();
     bool nan = false;
-    for (int j = tid; j < a.B; j += NT) { const double v = tm[j]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k * NT + tid < a.B) { const double v = Mreg[k]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
+    }
     const double m = block_max_nanprop<NT>(mx, nan, lds_d);
     // rescaled tile sums and their exact inclusive scan, 1024 tiles per round
     double carry = 0.0;
-    for (int j0 = 0; j0 < a.Bpow2; j0 += NT) {
-        const int j = j0 + tid;
-        double A = 0.0, Ap = 0.0;
-        if (j < a.B) {
-            A = ts[j];
-            const double ex = dexp_scaled_t(tm[j] - m, a.rshift - kTileShift, kExpTable);
-            Ap = __builtin_rint(A * ex);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k * NT < a.Bpow2) {
+            const int j = k * NT + tid;
+            double A = 0.0, Ap = 0.0;
+            if (j < a.B) {
+                A = Areg[k];
+                const double ex = dexp_scaled_t(Mreg[k] - m, a.rshift - kTileShift, kExpTable);
+                Ap = __builtin_rint(A * ex);
+            }
+            const double inc = wave_incl_scan_f64(Ap);
+            __syncthreads();                                     // lds_seg of the previous round has been read
+            if (lane == 63) lds_seg[wave] = inc;
+            __syncthreads();
+            double sv = (lane & 15) < NW ? lds_seg[lane & 15] : 0.0;
+            sv = sv + dpp_f64_zero<0x111, 0xF>(sv);
+            sv = sv + dpp_f64_zero<0x112, 0xF>(sv);
+            sv = sv + dpp_f64_zero<0x114, 0xF>(sv);
+            sv = sv + dpp_f64_zero<0x118, 0xF>(sv);
+            const double pre = wave ? readlane_f64(sv, wave - 1) : 0.0;
+            const double T = (carry + pre) + inc;
+            carry = carry + readlane_f64(sv, 15);
+            if (j < a.Bpow2) lds_T[j] = (j < a.B) ? T : dinf();
+            if (j < a.B) { Tp[j] = T; Rp[j] = A / Ap; }
         }
-        const double inc = wave_incl_scan_f64(Ap);
-        __syncthreads();                                         // lds_seg of the previous round has been read
-        if (lane == 63) lds_seg[wave] = inc;
-        __syncthreads();
-        double sv = (lane & 15) < NW ? lds_seg[lane & 15] : 0.0;
-        sv = sv + dpp_f64_zero<0x111, 0xF>(sv);
-        sv = sv + dpp_f64_zero<0x112, 0xF>(sv);
-        sv = sv + dpp_f64_zero<0x114, 0xF>(sv);
-        sv = sv + dpp_f64_zero<0x118, 0xF>(sv);
-        const double pre = wave ? readlane_f64(sv, wave - 1) : 0.0;
-        const double T = (carry + pre) + inc;
-        carry = carry + readlane_f64(sv, 15);
-        if (j < a.Bpow2) lds_T[j] = (j < a.B) ? T : dinf();
-        if (j < a.B) { Tp[j] = T; Rp[j] = A / Ap; }
     }
     const double S = carry;
     __syncthreads();
@@ -1089,20 +1108,179 @@ __global__ __launch_bounds__(1024) void k_level2_plan(const StepArgs a, int plan
             const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, key0, key1);
             u0 = u01_co(ox.v0, ox.v1);
         }
-        for (int b = tid; b < a.B; b += NT) {
-            double pg = 0.0, pgn = 0.0;
-            if (a.resampler == RESAMP_MULTINOMIAL) { pg = a.pgam[g0 + b]; pgn = (b + 1 < a.B) ? a.pgam[g0 + b + 1] : G; }
-            const int i_first = b * a.tile;
-            const int nvalid = (a.N - i_first) < a.tile ? (a.N - i_first) : a.tile;
-            double ts_, t_lo, t_hi;
-            tile_target_bounds(a.resampler, S, a.N, i_first, nvalid, pg, pgn, G, u0, ts_, t_lo, t_hi);
-            int lo = count_less_pow2(a.Bpow2, t_lo, [&](int j) { return lds_T[j]; });
-            int hi = count_less_pow2(a.Bpow2, t_hi, [&](int j) { return lds_T[j]; });
-            a.l2_lo[(size_t)r * a.Bs + b] = lo < a.B - 1 ? lo : a.B - 1;
-            a.l2_hi[(size_t)r * a.Bs + b] = hi < a.B - 1 ? hi : a.B - 1;
+        // The source-tile range [lo, hi] of every output tile.  The bounds grow with the tile index (t_lo(b) <= t_hi(b),
+        // t_lo(b) <= t_lo(b + 1)), so a thread takes CONSECUTIVE tiles and every count after its first starts where the
+        // last one ended: a short gallop instead of a log2(B)-level descent (this phase is bound by the LDS traffic of one
+        // CU: 2 x 14 probes per tile at B = 16384 before, 3-4 now).  The Gamma prefixes of a thread's tiles are all
+        // requested before the first use (Areg / Mreg are dead by now).
+        const int per = (a.B + NT - 1) / NT;                     // <= KMAX
+        const int bb0 = tid * per;
+        double pgreg[KMAX + 1];
+#pragma unroll
+        for (int k = 0; k <= KMAX; ++k) {
+            const int b = bb0 + k;
+            pgreg[k] = 0.0;
+            if (a.resampler == RESAMP_MULTINOMIAL && k <= per && b <= a.B) pgreg[k] = (b < a.B) ? a.pgam[g0 + b] : G;
+        }
+        // #{ j : T'_j < t } given that every entry below `from` is < t (entries past B are +inf)
+        auto count_from = [&](int from, double t) {
+            int p = from, sz = 1;
+            while (p + sz - 1 < a.Bpow2 && lds_T[p + sz - 1] < t) { p += sz; sz <<= 1; }
+            for (sz >>= 1; sz >= 1; sz >>= 1)
+                if (p + sz - 1 < a.Bpow2 && lds_T[p + sz - 1] < t) p += sz;
+            return p;
+        };
+        int prev = 0;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int b = bb0 + k;
+            if (k < per && b < a.B) {
+                const int i_first = b * a.tile;
+                const int nvalid = (a.N - i_first) < a.tile ? (a.N - i_first) : a.tile;
+                double ts_, t_lo, t_hi;
+                tile_target_bounds(a.resampler, S, a.N, i_first, nvalid, pgreg[k], pgreg[k + 1], G, u0, ts_, t_lo, t_hi);
+                const int lo = (k == 0) ? count_less_pow2(a.Bpow2, t_lo, [&](int j) { return lds_T[j]; }) : count_from(prev, t_lo);
+                const int hi = count_from(lo, t_hi);
+                prev = lo;
+                a.l2_lo[(size_t)r * a.Bs + b] = lo < a.B - 1 ? lo : a.B - 1;
+                a.l2_hi[(size_t)r * a.Bs + b] = hi < a.B - 1 ? hi : a.B - 1;
+            }
         }
     }
     if (tid == 0) {
+        FilterScalars* sc = a.scal + r;
+        sc->m = m;
+        sc->S = S;
+        if (a.finalize_prev) {
+            const double Sdd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
+            const double lse = m + dlog(Sdd);
+            const double ll = lse - sc->prev;
+            sc->last_ll = ll;
+            sc->loglik = sc->loglik + ll;
+            sc->prev = resampled ? a.logN : lse;
+            if (a.per_step) a.per_step[(size_t)r * a.Tcap + (a.t - 1)] = ll;
+            if (a.ll_host) a.ll_host[r] = ll;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The same split level-2 over SEVERAL workgroups, for filters of more than 1024 tiles.  k_level2_plan is one workgroup per
+// filter and its time grows with the number of tiles (B = 4096: 15 us, 16384: 51 us per launch -- a sixth of the step at
+// N >= 2^23, and every rank of a sharded filter plans ALL tiles); here workgroup g takes tiles [1024 g, 1024 g + 1024):
+//   k_l2_scan_blocks  global max (every workgroup reads all maxima itself), rescaled sums A', A / A', the inclusive scan
+//                     of its own 1024 tiles and their total
+//   k_l2_ranges       offsets from the (at most 16) totals, T' = local scan + offset for all tiles into LDS and for its
+//                     own tiles into l2_T, source ranges of its own tiles, and (workgroup 0) the accounting.
+// Integer sums are exact, so T', S', the ranges and the log-likelihood are k_level2_plan's to the bit.
+// grid = (ceil(B / 1024), R), block = 1024; k_l2_ranges: dynamic LDS = Bpow2 doubles.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_l2_scan_blocks(const StepArgs a) {
+    constexpr int NT = 1024, NW = NT / 64, KMAX = kMaxTilesSplit / NT;
+    __shared__ double lds_d[16];
+    __shared__ double lds_seg[16];
+    const int tid = threadIdx.x, blk = blockIdx.x, r = blockIdx.y;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double* ts = a.tsum_in + (size_t)r * a.Bs;
+    const double* tm = a.tmax_in + (size_t)r * a.Bs;
+    double Mreg[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int j = k * NT + tid;
+        Mreg[k] = (j < a.B) ? tm[j] : -dinf();
+    }
+    const int jo = blk * NT + tid;
+    const double A = (jo < a.B) ? ts[jo] : 0.0;
+    const double Mo = (jo < a.B) ? tm[jo] : 0.0;
+    double mx = -dinf();
+    bool nan = false;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k * NT + tid < a.B) { const double v = Mreg[k]; nan = nan || (v != v); mx = (v > mx) ? v : mx; }
+    }
+    const double m = block_max_nanprop<NT>(mx, nan, lds_d);
+    double Ap = 0.0;
+    if (jo < a.B) Ap = __builtin_rint(A * dexp_scaled_t(Mo - m, a.rshift - kTileShift, kExpTable));
+    const double inc = wave_incl_scan_f64(Ap);
+    if (lane == 63) lds_seg[wave] = inc;
+    __syncthreads();
+    double sv = (lane & 15) < NW ? lds_seg[lane & 15] : 0.0;
+    sv = sv + dpp_f64_zero<0x111, 0xF>(sv);
+    sv = sv + dpp_f64_zero<0x112, 0xF>(sv);
+    sv = sv + dpp_f64_zero<0x114, 0xF>(sv);
+    sv = sv + dpp_f64_zero<0x118, 0xF>(sv);
+    const double pre = wave ? readlane_f64(sv, wave - 1) : 0.0;
+    double* Tloc = a.l2_work + (size_t)r * a.Bs;
+    double* blkv = a.l2_work + (size_t)a.R * a.Bs + (size_t)r * 32;
+    if (jo < a.B) {
+        Tloc[jo] = pre + inc;
+        a.l2_R[(size_t)r * a.Bs + jo] = A / Ap;
+    }
+    if (tid == 0) {
+        blkv[blk] = readlane_f64(sv, 15);
+        if (blk == 0) blkv[KMAX] = m;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_l2_ranges(const StepArgs a, int plan_ranges) {
+    constexpr int NT = 1024, KMAX = kMaxTilesSplit / NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_l2r[];
+    double* lds_T = reinterpret_cast<double*>(smem_l2r);         // [Bpow2]
+    const int tid = threadIdx.x, blk = blockIdx.x, r = blockIdx.y;
+    const double* Tloc = a.l2_work + (size_t)r * a.Bs;
+    const double* blkv = a.l2_work + (size_t)a.R * a.Bs + (size_t)r * 32;
+    double* Tp = a.l2_T + (size_t)r * a.Bs;
+    const uint32_t rep = a.first_filter + (uint32_t)r;
+    const bool resampled = (a.t % a.resamp_sched == 0);
+    const int nblk = (a.B + NT - 1) / NT;
+    // local scans of all tiles, requested before anything else
+    double Treg[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int j = k * NT + tid;
+        Treg[k] = (j < a.B) ? Tloc[j] : 0.0;
+    }
+    double off[KMAX + 1];
+    off[0] = 0.0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) off[k + 1] = off[k] + ((k < nblk) ? blkv[k] : 0.0);
+    const double S = off[KMAX];
+    const double m = blkv[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int j = k * NT + tid;
+        if (j < a.Bpow2) {
+            const double T = off[k] + Treg[k];
+            lds_T[j] = (j < a.B) ? T : dinf();
+            if (k == blk && j < a.B) Tp[j] = T;
+        }
+    }
+    __syncthreads();
+    const int b = blk * NT + tid;
+    if (plan_ranges && resampled && a.resampler != RESAMP_MULTINOMIAL_IID && b < a.B) {
+        const uint32_t key0 = a.keyp[0], key1 = a.keyp[1];
+        double G = 1.0, u0 = 0.0, pg = 0.0, pgn = 0.0;
+        const size_t g0 = ((size_t)a.gi * a.R + r) * a.B;
+        if (a.resampler == RESAMP_MULTINOMIAL) {
+            G = a.gtot[(size_t)a.gi * a.R + r];
+            pg = a.pgam[g0 + b]; pgn = (b + 1 < a.B) ? a.pgam[g0 + b + 1] : G;
+        } else if (a.resampler == RESAMP_SYSTEMATIC) {
+            const u32x4 ox = philox4x32_10(0u, (uint32_t)a.t, rep, STREAM_RESAMP_EXTRA, key0, key1);
+            u0 = u01_co(ox.v0, ox.v1);
+        }
+        const int i_first = b * a.tile;
+        const int nvalid = (a.N - i_first) < a.tile ? (a.N - i_first) : a.tile;
+        double ts_, t_lo, t_hi;
+        tile_target_bounds(a.resampler, S, a.N, i_first, nvalid, pg, pgn, G, u0, ts_, t_lo, t_hi);
+        int lo = 0, hi = 0;
+        for (int step = a.Bpow2 >> 1; step >= 1; step >>= 1) {       // the two counts descend together
+            if (lds_T[lo + step - 1] < t_lo) lo += step;
+            if (lds_T[hi + step - 1] < t_hi) hi += step;
+        }
+        a.l2_lo[(size_t)r * a.Bs + b] = lo < a.B - 1 ? lo : a.B - 1;
+        a.l2_hi[(size_t)r * a.Bs + b] = hi < a.B - 1 ? hi : a.B - 1;
+    }
+    if (blk == 0 && tid == 0) {
         FilterScalars* sc = a.scal + r;
         sc->m = m;
         sc->S = S;
