@@ -161,7 +161,7 @@ int ssme_pf_download_scalars(ssme_pf_handle h, int32_t filter, double* max_logw,
                              uint64_t* tile_sums, double* tile_max, int32_t* rshift);
 /* flags: bit 0 = record ancestor indices, bit 1 = keep log-weights in memory (parity tests), bit 2 = compute level-2 (global
  * max, rescaled tile sums, their scan, every tile's source range) once per filter in its own launch instead of in every
- * workgroup; bit 3 = the opposite (in-kernel level-2, possible up to 2048 tiles).  Default: split above 512 tiles
+ * workgroup; bit 3 = the opposite (in-kernel level-2, possible up to 2048 tiles).  Default: split above 1024 tiles
  * (N > 2^20), where it is faster; always split above 2048 tiles (N > 2^22; limit N <= 2^25).  Same results to the bit. */
 int ssme_pf_set_debug(ssme_pf_handle h, int32_t flags);
 
@@ -306,7 +306,7 @@ const char* ssme_lw_last_error(ssme_lw_handle h);
  * exchanges windows of (cdfB, x, theta) for the resampling draw (stage 1), gathers the first-stage tile sums / maxima and
  * the 14 moment partials per tile, runs ssme_lw_shard_mid on every rank (theta-bar, Cholesky factor: the moment sums are
  * added in tile order, so every rank gets the unsharded filter's bits), plans and exchanges windows of (cdfA, lw1, x, theta)
- * for the k draw (stage 2) -- call ssme_lw_shard_plan(which = 1) BEFORE ssme_lw_shard_mid: above 512 tiles the plan also
+ * for the k draw (stage 2) -- call ssme_lw_shard_plan(which = 1) BEFORE ssme_lw_shard_mid: above 1024 tiles the plan also
  * provides the first-stage (m, S) that mid turns into the log-sum-exp.  theta buffers are 4 planes: [4][tiles * 2048].  Bit-identical to ssme_lw_run_series. */
 int ssme_lw_shard_create(const ssme_lw_config* cfg, int32_t rank, int32_t world, ssme_lw_handle* out);
 int ssme_lw_set_stream(ssme_lw_handle h, void* hip_stream);

@@ -622,7 +622,7 @@ static StepArgs shard_args(ssme_pf_handle h, int t, const double* tsum_all, cons
     return a;
 }
 
-// the plan of step t on the device: every rank's window into h->plan_dev (up to 512 tiles) or every tile's range into
+// the plan of step t on the device: every rank's window into h->plan_dev (up to 1024 tiles) or every tile's range into
 // l2_lo / l2_hi (split level-2, which also accounts log p(y_{t-1} | .))
 static void shard_plan_device(ssme_pf_handle h, int t, const double* tsum_all, const double* tmax_all, int margin = 0,
                               int32_t* flag = nullptr) {
@@ -646,7 +646,7 @@ int ssme_pf_shard_plan(ssme_pf_handle h, const double* tsum_all, const double* t
     HIPCHK(hipGetLastError());
     int32_t* stage = reinterpret_cast<int32_t*>(h->pin + 2 + h->R);            // pinned
     if (h->split_l2) {
-        // more than 512 tiles in total: the split level-2 plans every tile; a rank's window is [lo of its first tile, hi of its last]
+        // more than 1024 tiles in total: the split level-2 plans every tile; a rank's window is [lo of its first tile, hi of its last]
         const int Bl = h->B / h->shard_world;
         const bool sorted = h->cfg.resampler != SSME_RESAMP_MULTINOMIAL_IID;
         for (int d = 0; d < h->shard_world; ++d) {
@@ -790,7 +790,7 @@ static int shard_series(ssme_pf_handle h, ncclComm_t comm, const double* y, cons
             rc = shard_gather(h, comm);
             if (rc != SSME_OK) return rc;
             if (fast) {
-                // up to 512 tiles the step kernel runs level-2 itself and checks its own source tiles against the fixed
+                // up to 1024 tiles the step kernel runs level-2 itself and checks its own source tiles against the fixed
                 // halo (StepArgs::win_flag): no plan launch at all; above, k_level2_plan is needed anyway and a small check follows it
                 if (h->split_l2) {
                     shard_plan_device(h, t, h->sh_tsum, h->sh_tmax, m, h->sh_flag);
@@ -1498,7 +1498,7 @@ struct ssme_lw_s {
     hipEvent_t ev0, ev1;
     float last_ms;
     double *xB, *thB, *xr, *thr, *lw1, *cdfA, *tsumA, *tmaxA, *cdfB, *tsumB, *tmaxB, *mom, *prop;
-    double* momtot;                  // [R][16] moment totals of k_lw_mom_totals (filters of more than 512 tiles)
+    double* momtot;                  // [R][16] moment totals of k_lw_mom_totals (filters of more than 1024 tiles)
     double* lwB;                     // carried second-stage log-weights (resamp_sched > 1 only)
     double* wscratch;                // [5][Npad] weights + untransformed parameters of one filter (host-side functionals)
     int form, rs;                    // 0 auxiliary form / 1 SISR form; resampling schedule m_rs
@@ -1519,7 +1519,7 @@ struct ssme_lw_s {
     int sh_margin, sh_rows, sh_check;
     long sh_exchanged;
     int gamma_t0, gamma_rows;        // step API: the Gamma tables hold time indices gamma_t0 .. gamma_t0 + gamma_rows - 1
-    int split_l2;                    // level-2 of both draws by k_level2_plan (more than 512 tiles)
+    int split_l2;                    // level-2 of both draws by the split level-2 kernels (more than 1024 tiles)
     double *l2T[2], *l2R[2];         // [draw: 0 resampling (B), 1 k draw (A)][R][Bs]
     double* l2_work;                 // scratch of the multi-workgroup level-2 (the two draws run one after the other)
     int32_t *l2lo[2], *l2hi[2];
@@ -1958,7 +1958,7 @@ int ssme_lw_shard_finalize(ssme_lw_handle h, int32_t t, const double* tsumB_all,
 
 // ---- C++ driver of the sharded Liu-West filter over RCCL (BASELINE.json configs[4]; fixed-halo path) ------------------------
 // Per step, on one HIP stream, no host synchronisation inside the time loop:
-//   grouped all-gather (tsumB, tmaxB)  [-> plan(0) above 512 tiles]  -> halo exchange of (xB, theta B, cdfB)  -> stage 1
+//   grouped all-gather (tsumB, tmaxB)  [-> plan(0) above 1024 tiles]  -> halo exchange of (xB, theta B, cdfB)  -> stage 1
 //   grouped all-gather (tsumA, tmaxA, 16 moment slots per tile)  [-> plan(1)]  -> mid  -> halo exchange of (xr, theta r, g1, cdfA)  -> stage 2
 // The stage kernels check their own source tiles against the exchanged window and raise a flag (read once, after the
 // series): SSME_ERR_STATE then tells the caller to run the exact, host-planned loop (ssme_amd/sharded.py: ShardedLiuWest).
@@ -2053,7 +2053,7 @@ int ssme_lw_shard_run_series(ssme_lw_handle h, void* nccl_comm, const double* y,
         LWNCCL(rccl().AllGather(tmA, h->sh_allA_m, (size_t)Bl, ncclDouble, comm, h->stream));
         LWNCCL(rccl().AllGather(momL, h->sh_mom_all, (size_t)Bl * 16, ncclDouble, comm, h->stream));
         LWNCCL(rccl().GroupEnd());
-        // the plan of the k draw first: above 512 tiles it provides the (m, S) that mid turns into the first-stage log-sum-exp
+        // the plan of the k draw first: above 1024 tiles it provides the (m, S) that mid turns into the first-stage log-sum-exp
         if (h->split_l2) { lw_launch_plan(h, 1, t, t, h->sh_allA_s, h->sh_allA_m, true); LWCHK(hipGetLastError()); }
         rc = ssme_lw_shard_mid(h, t, h->sh_allA_s, h->sh_allA_m, h->sh_mom_all);
         if (rc != SSME_OK) return rc;

@@ -33,7 +33,7 @@ constexpr int kTile = 2048;                // large tile: N <= 2048 (one-tile se
 constexpr int kTileSmall = 512;
 constexpr int kTileMid = 1024;            // small tile: 2048 < N <= 2^18, so that a mid-size filter spreads over the chip (N = 2^16: 128 workgroups)
 constexpr int kMaxTilesPerFilter = 2048;   // in-kernel level-2 (one entry per thread at NT = 512 .. four at 512 threads)
-constexpr int kSplitLevel2Above = 512;     // measured: with more than one tile sum per thread the split level-2 wins (N = 3 2^20: 81 -> 49 us)
+constexpr int kSplitLevel2Above = 1024;    // measured (profiles/r02_level2_split.txt): in-kernel 24.7 vs split 25.4 us at 768 tiles, equal at 1024, 67.9 vs 43.3 at 1536
 constexpr int kMaxTilesSplit = 16384;      // split level-2 (k_level2_plan + k_filter_step<.., true>): N <= 2^25
 constexpr int kStageTiles = 3;             // cdf tiles staged in LDS per output tile
 constexpr int kEShift = 35;                // exponential spacings: qE = rne(E * 2^35)

@@ -5,7 +5,7 @@
 // particle redistribution".  One process per GPU; rank g owns B/world consecutive 2048-particle tiles.  Per time step,
 // everything on ONE HIP stream and -- on the fast path -- without any host synchronisation:
 //     two grouped ncclAllGather (tile sums, tile maxima: 16 bytes per tile), each straight into its final array
-//     k_shard_plan (or k_level2_plan + k_shard_window_check above 512 tiles): every rank's source-tile window [lo, hi] and
+//     k_shard_plan (or k_level2_plan + k_shard_window_check above 1024 tiles): every rank's source-tile window [lo, hi] and
 //         a device flag if a window leaves the fixed halo
 //     grouped ncclSend / ncclRecv of the halo tiles (integer cdf + particles) with the two neighbouring ranks
 //     k_filter_step on the rank's tiles, reading its window in place from the halo buffer

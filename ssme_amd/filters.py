@@ -74,7 +74,7 @@ class ParticleFilterBank:
     def set_debug(self, record_ancestors=True, keep_logw=True, split_level2=None):
         """Parity/debug: record ancestor indices and/or keep the log-weights in device memory; split_level2 forces the
         one-launch-per-filter level-2 (True) or the in-kernel one (False, up to 2048 tiles); None chooses by size."""
-        pol = 0 if split_level2 is None else (4 if split_level2 else 8)      # None: by size (split above 512 tiles)
+        pol = 0 if split_level2 is None else (4 if split_level2 else 8)      # None: by size (split above 1024 tiles)
         self._chk(capi.lib().ssme_pf_set_debug(self._h, (1 if record_ancestors else 0) | (2 if keep_logw else 0) | pol))
 
     def set_graph_mode(self, on=True):
@@ -383,7 +383,7 @@ class svol_lw_1_par:
             raise SsmeError(status, msg)
 
     def set_debug(self, on=True, split_level2=None):
-        """Record k / ancestor indices; split_level2: True / False force the level-2 policy (None: split above 512 tiles)."""
+        """Record k / ancestor indices; split_level2: True / False force the level-2 policy (None: split above 1024 tiles)."""
         pol = 0 if split_level2 is None else (4 if split_level2 else 8)
         self._chk(capi.lib().ssme_lw_set_debug(self._h, (1 if on else 0) | pol))
 

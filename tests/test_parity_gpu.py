@@ -859,7 +859,7 @@ def test_filter_of_more_than_2048_tiles(sa, oracle, spy):
 
 
 def test_level2_policy_by_size_is_result_invariant(sa, spy):
-    """1200 tiles: split level-2 (the default above 512 tiles) == in-kernel level-2 (four tile sums per thread)."""
+    """1200 tiles: split level-2 (the default above 1024 tiles) == in-kernel level-2 (four tile sums per thread)."""
     n, y = 1200 * 2048 - 5, spy[:5]
     res = []
     for pol in (None, False, True):

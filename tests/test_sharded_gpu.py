@@ -37,7 +37,7 @@ def _run_sharded(tmp_path, world, model, n, T, rs, seed):
 
 @pytest.mark.parametrize("world,model,n,rs,T", [(2, 0, 16384, 0, 24), (4, 0, 32768, 0, 24), (2, 0, 16384, 1, 24), (2, 1, 8192, 0, 24),
                                                 (2, 0, 16384, 2, 24), (2, 2, 8192, 3, 24), (4, 0, 8192, 0, 24),
-                                                # more than 512 tiles in total: the split level-2 plans the exchange
+                                                # more than 1024 tiles in total: the split level-2 plans the exchange
                                                 (2, 0, 2 * 640 * 2048, 0, 6), (4, 0, 4 * 300 * 2048, 1, 6),
                                                 # more than 2048 tiles (N > 2^22)
                                                 (2, 0, 2 * 1100 * 2048, 0, 4)])
@@ -97,7 +97,7 @@ def _run_sharded_lw(tmp_path, world, n, T, seed, delta):
 
 
 @pytest.mark.parametrize("world,n,delta", [(2, 16384, 0.99), (4, 32768, 0.95), (2, 8192, 1.0),
-                                           (2, 2 * 300 * 2048, 0.99),           # 600 tiles: split level-2
+                                           (2, 2 * 600 * 2048, 0.99),           # 1200 tiles: split level-2
                                            # BASELINE.json configs[4]'s per-GPU slice: 2^21 particles = 1024 tiles per rank
                                            (2, 2 * 1024 * 2048, 0.99)])
 def test_sharded_liu_west_is_bit_identical_to_unsharded(tmp_path, spy, world, n, delta):
@@ -123,7 +123,7 @@ def test_sharded_liu_west_is_bit_identical_to_unsharded(tmp_path, spy, world, n,
     assert sum(int(r["exchanged"]) for r in res) > 0
 
 
-@pytest.mark.parametrize("model,n,rs,T,mode", [(0, 65536, 0, 16, 0), (1, 32768, 1, 12, 2), (0, 600 * 2048, 0, 5, 0), (0, 600 * 2048, 0, 4, 2),
+@pytest.mark.parametrize("model,n,rs,T,mode", [(0, 65536, 0, 16, 0), (1, 32768, 1, 12, 2), (0, 600 * 2048, 0, 5, 0), (0, 1100 * 2048, 0, 4, 2),
                                                (2, 16384, 2, 10, 1)])
 def test_native_rccl_driver_matches_unsharded(tmp_path, spy, model, n, rs, T, mode):
     """ssme_pf_shard_run_series (C++ over RCCL, resolved from the process at run time) with one rank per GPU == the
@@ -153,7 +153,7 @@ def test_native_rccl_driver_matches_unsharded(tmp_path, spy, model, n, rs, T, mo
     assert int(r["path"]) == (2 if mode == 2 else 1)
 
 
-@pytest.mark.parametrize("n,delta,T", [(16384, 0.99, 10), (600 * 2048, 0.95, 4)])
+@pytest.mark.parametrize("n,delta,T", [(16384, 0.99, 10), (600 * 2048, 0.95, 4), (1100 * 2048, 0.95, 3)])
 def test_native_rccl_driver_liu_west_matches_unsharded(tmp_path, spy, n, delta, T):
     """ssme_lw_shard_run_series (C++ over RCCL, one rank per GPU) == the unsharded Liu-West filter: log-likelihoods,
     particles, transformed parameters; the Python-driven loop on the same handle gives the same log-likelihood."""
@@ -195,8 +195,9 @@ def _build_thread_harness():
 @pytest.mark.parametrize("world,n,T,model,rs,mode", [
     (2, 16384, 16, 0, 0, 1), (4, 65536, 12, 0, 0, 0), (4, 65536, 10, 1, 1, 1), (3, 3 * 4 * 2048, 10, 2, 2, 0), (6, 6 * 8 * 2048, 8, 0, 0, 2),
     (4, 16384, 8, 1, 1, 0),                       # two tiles per rank, heavy-tailed leverage weights: windows may leave the halo -> exact rerun
-    (2, 2 * 300 * 2048, 4, 0, 0, 1), (4, 4 * 160 * 2048, 4, 0, 1, 0),      # more than 512 tiles: split level-2 plans + window check kernel
-    (2, 16384, 10, -1, 990, 0), (4, 65536, 8, -1, 950, 0), (2, 2 * 300 * 2048, 3, -1, 990, 0)])      # Liu-West
+    (2, 2 * 300 * 2048, 4, 0, 0, 1),                                       # 600 tiles: in-kernel level-2, window check in the step kernel
+    (2, 2 * 600 * 2048, 4, 0, 0, 1), (4, 4 * 300 * 2048, 4, 0, 1, 0),      # more than 1024 tiles: split level-2 plans + window check kernel
+    (2, 16384, 10, -1, 990, 0), (4, 65536, 8, -1, 950, 0), (2, 2 * 600 * 2048, 3, -1, 990, 0)])      # Liu-West
 def test_native_drivers_with_several_ranks_on_one_gpu(world, n, T, model, rs, mode):
     """The C++ shard drivers with 2-6 ranks: the ranks are host threads sharing the GPU and RCCL is replaced by
     tests/cpp/mock_rccl.cpp (same stream ordering and send/recv matching; RCCL itself refuses two ranks per device).
