@@ -1643,7 +1643,11 @@ static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record
         // then takes theta-bar and the Cholesky factor from them itself
         a.fuse_mid = ((size_t)h->B * kNMom * sizeof(double) <= h->lds_bytes) ? 1 : 0;
         hipLaunchKernelGGL(k_lw_stage1<false>, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
-        if (!a.fuse_mid) hipLaunchKernelGGL(k_lw_mid<false>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
+        if (!a.fuse_mid) {
+            a.momtot = h->momtot;                // 586 .. 1024 tiles: the totals by one wave per moment, then the one-workgroup rest
+            hipLaunchKernelGGL(k_lw_mom_totals, dim3(kNMom, h->R), dim3(64), 0, h->stream, a);
+            hipLaunchKernelGGL(k_lw_mid<false>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
+        }
         hipLaunchKernelGGL(k_lw_stage2<false>, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
     }
 }
@@ -1914,7 +1918,11 @@ int ssme_lw_shard_mid(ssme_lw_handle h, int32_t t, const double* tsumA_all, cons
         hipLaunchKernelGGL(k_lw_mom_totals, dim3(kNMom, 1), dim3(64), 0, h->stream, a);
         hipLaunchKernelGGL(k_lw_mid<true>, dim3(1), dim3(kThreads), 0, h->stream, a);
     }
-    else hipLaunchKernelGGL(k_lw_mid<false>, dim3(1), dim3(kThreads), 0, h->stream, a);
+    else if (h->B > 256) {
+        a.momtot = h->momtot;
+        hipLaunchKernelGGL(k_lw_mom_totals, dim3(kNMom, 1), dim3(64), 0, h->stream, a);
+        hipLaunchKernelGGL(k_lw_mid<false>, dim3(1), dim3(kThreads), 0, h->stream, a);
+    } else hipLaunchKernelGGL(k_lw_mid<false>, dim3(1), dim3(kThreads), 0, h->stream, a);
     LWCHK(hipGetLastError());
     return SSME_OK;
 }
