@@ -873,6 +873,32 @@ def test_level2_policy_by_size_is_result_invariant(sa, spy):
         assert_bits_equal(per, res[0][1], "level-2 policy: per-step")
 
 
+@pytest.mark.parametrize("rs,model", [(0, 1), (1, 0), (2, 0)])
+def test_multi_workgroup_level2_matches_in_kernel_level2_and_oracle(sa, oracle, spy, rs, model):
+    """More than 1024 tiles, two filters: the split level-2 runs as k_l2_scan_blocks + k_l2_ranges (two workgroups per filter
+    here); all resamplers with a planned range, the leverage model, the step API; against the in-kernel level-2 and the oracle."""
+    n, T = 1100 * 2048 + 3, 4
+    th = {0: [1.0, 0.95, 0.25], 1: [0.9, 0.0, 1.0, -0.1]}[model]
+    y = spy[:T].copy()
+    y[2] *= 30.0                                           # an outlier: unbalanced weights, wide source ranges
+    z = np.concatenate([[0.0], y[:-1]]) if model == 1 else None
+    outs = []
+    for split in (True, False):
+        b = sa.ParticleFilterBank(model, n, 2, 17, rs)
+        b.set_debug(False, False, split_level2=split)
+        b.set_params(th)
+        ll = b.run_series(y, z)
+        per = b.per_step()
+        nxt = b.step(spy[T], None if z is None else y[T - 1])
+        outs.append((ll, per, nxt))
+        b.close()
+    assert_bits_equal(outs[0][0], outs[1][0], "multi-workgroup level-2: log-lik")
+    assert_bits_equal(outs[0][1], outs[1][1], "multi-workgroup level-2: per-step")
+    assert_bits_equal(outs[0][2], outs[1][2], "multi-workgroup level-2: step API")
+    o = oracle.Filter(model, n, th, 17, rep=1, resampler=rs)
+    assert_bits_equal(outs[0][1][1], o.run_series(y, z)[1], "multi-workgroup level-2 vs oracle")
+
+
 @pytest.mark.parametrize("n", [30000, 700 * 2048 - 9])
 def test_liu_west_split_level2_matches_in_kernel_level2(sa, oracle, n):
     """Liu-West with the level-2 of both draws in k_level2_plan == in-kernel level-2 (and the oracle at the small size)."""
