@@ -158,7 +158,7 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
         level2_load<NT>(tsum, tmax, B, A2, M2);
         if (tid == 0) { L.cnt[0] = 0; L.cnt[1] = 0; }
         double Ap[NE], Tinc[NE], m, S;
-        level2_scan<NT, true>(A2, M2, B, rshift, m, Ap, Tinc, S, L.d1, L.seg_l2, L.etab);
+        level2_scan<NT>(A2, M2, B, rshift, m, Ap, Tinc, S, L.d1, L.seg_l2, L.etab);
         m_out = m; S_out = S;
         t_scale = S / G;
         const double t_lo = __builtin_ceil(pgam * t_scale);
@@ -312,7 +312,7 @@ __device__ __forceinline__ void lw_level2_only(const double* tsum, const double*
         constexpr int NT = kLwNT, NE = 4;
         double A2[NE], M2[NE], Ap[NE], Tinc[NE];
         level2_load<NT>(tsum, tmax, B, A2, M2);
-        level2_scan<NT, true>(A2, M2, B, rshift, m_out, Ap, Tinc, S_out, L.d1, L.seg_l2, L.etab);
+        level2_scan<NT>(A2, M2, B, rshift, m_out, Ap, Tinc, S_out, L.d1, L.seg_l2, L.etab);
     }
 }
 
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid(const LwArgs a) {
     m = 0.0; S = 0.0;
     if (aux) {
         if (BIG) { m = a.l2A_s[r].m; S = a.l2A_s[r].S; }
-        else level2_scan<kThreads, true>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
+        else level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
     }
     __syncthreads();
     if (tid == 0) {
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(kThreads) void k_lw_finalize(const LwArgs a) {
     if (BIG) { m = a.l2B_s[r].m; S = a.l2B_s[r].S; }
     else {
         level2_load<kThreads>(a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, a.B, A2, M2);
-        level2_scan<kThreads, true>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
+        level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
     }
     if (tid == 0) {
         LwScalars* sc = a.scal + r;

@@ -329,13 +329,6 @@ template <int NT>
 __device__ __forceinline__ void load_exp_table(ExpTabEntry* lds_tab) {
     for (int i = threadIdx.x; i < SSME_EXP_TABLE_SIZE; i += NT) lds_tab[i] = kExpTable[i];
 }
-// exp(x) 2^sc of the weight arithmetic: the bootstrap filter's table form (TAB) or the Taylor form (Liu-West kernels)
-template <bool TAB>
-__device__ __forceinline__ double xexp_scaled(double x, int sc, const ExpTabEntry* tab) {
-    if constexpr (TAB) return dexp_scaled_t(x, sc, tab);
-    else return dexp_scaled(x, sc);
-}
-
 // Gamma(shape) draw, Marsaglia & Tsang (2000), attempts driven by the Philox counter
 __device__ __forceinline__ double gamma_draw(uint32_t b, uint32_t t, uint32_t rep, uint32_t k0, uint32_t k1, double shape,
                                              uint32_t stream_base = STREAM_GAMMA) {
@@ -385,10 +378,10 @@ __device__ __forceinline__ void level2_load(const double* ts, const double* tm, 
     }
 }
 
-template <int NT, bool TAB = false>
+template <int NT>
 __device__ __forceinline__ void level2_scan(const double (&A)[2048 / NT], const double (&mb)[2048 / NT], int B, int rshift,
                                             double& m, double (&Ap)[2048 / NT], double (&Tinc)[2048 / NT], double& S,
-                                            double* lds_d, double* lds_seg, const ExpTabEntry* etab = nullptr) {
+                                            double* lds_d, double* lds_seg, const ExpTabEntry* etab) {
     constexpr int NE = 2048 / NT, NW = NT / 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -409,7 +402,7 @@ __device__ __forceinline__ void level2_scan(const double (&A)[2048 / NT], const 
         if (e * NT < B) {
             const int j = e * NT + threadIdx.x;
             // NaN (m or m_b NaN) is squashed to 0 by dexp_scaled's clamp: A' = rint(A * 0) = 0
-            if (j < B) Ap[e] = __builtin_rint(A[e] * xexp_scaled<TAB>(mb[e] - m, rshift - kTileShift, etab));
+            if (j < B) Ap[e] = __builtin_rint(A[e] * dexp_scaled_t(mb[e] - m, rshift - kTileShift, etab));
             inc[e] = wave_incl_scan_f64(Ap[e]);
             if (lane == 63) lds_seg[e * 16 + wave] = inc[e];
         }
@@ -598,7 +591,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         if (a.stamps) { asm volatile("" :: "v"(A2[0]), "v"(M2[0])); }   // force the loads to have landed
         STAMP(a, 13);
 #endif
-        level2_scan<NT, true>(A2, M2, a.B, a.rshift, m, ApL2, Tinc, S, lds_d1, lds_seg_l2, lds_etab);
+        level2_scan<NT>(A2, M2, a.B, a.rshift, m, ApL2, Tinc, S, lds_d1, lds_seg_l2, lds_etab);
         STAMP(a, 14);
         // bounds [t_lo, t_hi] of this tile's targets, known to every thread without the spacings
         double t_lo = 0.0, t_hi = dinf();
@@ -973,7 +966,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                         M2[e] = __hip_atomic_load(a.tmax_out + (size_t)r * a.Bs + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                level2_scan<NT, true>(A2, M2, a.B, a.rshift, m2, Ap2, Tinc2, S2, lds_d1, lds_seg_l2, lds_etab);
+                level2_scan<NT>(A2, M2, a.B, a.rshift, m2, Ap2, Tinc2, S2, lds_d1, lds_seg_l2, lds_etab);
                 if (tid == 0) {
                     FilterScalars* sc = a.scal + r;
                     const bool resample_now = ((a.t + 1) % a.resamp_sched == 0);
@@ -1010,7 +1003,7 @@ __global__ __launch_bounds__(kThreads) void kf_finalize(const StepArgs a) {
     const int r = blockIdx.x;
     double A2[8], Ap[8], Tinc[8], M2[8], S, m;
     level2_load<kThreads>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
-    level2_scan<kThreads, true>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
+    level2_scan<kThreads>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
     if (tid == 0) {
         FilterScalars* sc = a.scal + r;
         const bool resample_now = ((a.t + 1) % a.resamp_sched == 0);
@@ -1312,7 +1305,7 @@ __global__ __launch_bounds__(512) void k_shard_plan(const StepArgs a, int world,
     const int tid = threadIdx.x;
     double A2[NE], M2[NE], Ap[NE], Tinc[NE], S, m;
     level2_load<NT>(a.tsum_in, a.tmax_in, a.B, A2, M2);
-    level2_scan<NT, true>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
+    level2_scan<NT>(A2, M2, a.B, a.rshift, m, Ap, Tinc, S, lds_d, lds_seg, kExpTable);
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int j = e * NT + tid;
