@@ -452,7 +452,7 @@ static int do_reset(ssme_pf_handle h) {
 
 extern "C" {
 
-int ssme_pf_version(void) { return 300; }
+int ssme_pf_version(void) { return 310; }
 
 const char* ssme_pf_strerror(int s) {
     switch (s) {
