@@ -197,7 +197,8 @@ def _build_thread_harness():
     (4, 16384, 8, 1, 1, 0),                       # two tiles per rank, heavy-tailed leverage weights: windows may leave the halo -> exact rerun
     (2, 2 * 300 * 2048, 4, 0, 0, 1),                                       # 600 tiles: in-kernel level-2, window check in the step kernel
     (2, 2 * 600 * 2048, 4, 0, 0, 1), (4, 4 * 300 * 2048, 4, 0, 1, 0),      # more than 1024 tiles: split level-2 plans + window check kernel
-    (2, 16384, 10, -1, 990, 0), (4, 65536, 8, -1, 950, 0), (2, 2 * 600 * 2048, 3, -1, 990, 0)])      # Liu-West
+    (8, 8 * 4 * 2048, 8, 0, 0, 0), (8, 8 * 2 * 2048, 6, 1, 0, 1),          # eight ranks, as a full node would run
+    (2, 16384, 10, -1, 990, 0), (4, 65536, 8, -1, 950, 0), (2, 2 * 600 * 2048, 3, -1, 990, 0), (8, 8 * 2 * 2048, 6, -1, 990, 0)])      # Liu-West
 def test_native_drivers_with_several_ranks_on_one_gpu(world, n, T, model, rs, mode):
     """The C++ shard drivers with 2-6 ranks: the ranks are host threads sharing the GPU and RCCL is replaced by
     tests/cpp/mock_rccl.cpp (same stream ordering and send/recv matching; RCCL itself refuses two ranks per device).
