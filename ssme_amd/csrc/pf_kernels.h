@@ -557,7 +557,20 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     // --- issue the level-2 loads first: previous step's tile sums and maxima ---
     constexpr int NE = 2048 / NT;
     double A2[NE], M2[NE], ApL2[NE];
-    if (need_l2 && !BIG) level2_load<NT>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
+    // Filters of at most 128 tiles (512 filters x 2^14: eight tiles each; one filter of 2^16: 128): every WAVE holds all tile
+    // sums, two per lane (entries lane and lane + 64), and takes the level-2 by itself -- wave max, wave scans, no LDS
+    // hand-over and one barrier less.  Afterwards a thread keeps the entry the general layout gives it (j = tid: the low
+    // half in wave 0, the high half in wave 1), so everything after the level-2 reads the same registers; the other waves'
+    // copies fail every `j < B` test below.  Integer sums and a max: the same bits as the block-wide form.
+    const bool wave_l2 = !BIG && need_l2 && a.B <= 128;
+    double Ahi = 0.0, Mhi = 0.0;
+    if (wave_l2) {
+        const int ln = tid & 63;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) { A2[e] = 0.0; M2[e] = 0.0; }
+        if (ln < a.B) { A2[0] = a.tsum_in[(size_t)r * a.Bs + ln]; M2[0] = a.tmax_in[(size_t)r * a.Bs + ln]; }
+        if (a.B > 64 && ln + 64 < a.B) { Ahi = a.tsum_in[(size_t)r * a.Bs + ln + 64]; Mhi = a.tmax_in[(size_t)r * a.Bs + ln + 64]; }
+    } else if (need_l2 && !BIG) level2_load<NT>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
     const double* l2T = a.l2_T + (size_t)r * a.Bs;
     const double* l2R = a.l2_R + (size_t)r * a.Bs;
     if (tid == 0) { lds_cnt[0] = 0; lds_cnt[1] = 0; }
@@ -591,6 +604,34 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         if (a.stamps) { asm volatile("" :: "v"(A2[0]), "v"(M2[0])); }   // force the loads to have landed
         STAMP(a, 13);
 #endif
+        if (wave_l2) {
+            __syncthreads();                               // the LDS tables and lds_cnt = 0 (level2_scan's first barrier otherwise)
+            const int ln = tid & 63;
+            const bool two = a.B > 64;                     // uniform: a second entry per lane
+            const bool v0 = ln < a.B, v1 = two && (ln + 64 < a.B);
+            const double mv = M2[0];
+            bool nanv = v0 && (mv != mv);
+            double mx = (v0 && !nanv) ? mv : -dinf();
+            if (two) {
+                const bool n1 = v1 && (Mhi != Mhi);
+                if (v1 && !n1) mx = (Mhi > mx) ? Mhi : mx;
+                nanv = nanv || n1;
+            }
+            const double mw = wave_max_f64(mx);
+            m = __ballot(nanv) ? dnan() : mw;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { ApL2[e] = 0.0; Tinc[e] = 0.0; }
+            if (v0) ApL2[0] = __builtin_rint(A2[0] * dexp_scaled_t(mv - m, a.rshift - kTileShift, lds_etab));
+            Tinc[0] = wave_incl_scan_f64(ApL2[0]);
+            S = readlane_f64(Tinc[0], 63);
+            if (two) {
+                double Ap1 = 0.0;
+                if (v1) Ap1 = __builtin_rint(Ahi * dexp_scaled_t(Mhi - m, a.rshift - kTileShift, lds_etab));
+                const double T1 = S + wave_incl_scan_f64(Ap1);
+                S = readlane_f64(T1, 63);
+                if ((tid >> 6) == 1) { A2[0] = Ahi; ApL2[0] = Ap1; Tinc[0] = T1; }       // the general layout: thread j = tid holds entry j
+            }
+        } else
         level2_scan<NT>(A2, M2, a.B, a.rshift, m, ApL2, Tinc, S, lds_d1, lds_seg_l2, lds_etab);
         STAMP(a, 14);
         // bounds [t_lo, t_hi] of this tile's targets, known to every thread without the spacings
