@@ -230,10 +230,10 @@ static int default_tile(int n_particles, int n_filters) {
 // One launcher per instantiation of the step kernel.  The dynamic-LDS ceiling of a kernel is process-wide state: it is
 // only ever raised (a handle with few tiles must not lower what a handle with many tiles was granted).
 static thread_local int g_grant_only = 0;      // != 0: launch_k only raises the LDS ceiling (handle creation); 1 general kernel, 2 / 3 the RS = 0 / 1 variants
-template <int MODEL, int NT, bool BIG, int TILE, int RS>
+template <int MODEL, int NT, bool BIG, int TILE, int RS, bool WL2 = false>
 static void launch_k(ssme_pf_handle h, const StepArgs& a, dim3 grid, size_t lds) {
     static std::atomic<size_t> granted{0};
-    auto kern = &k_filter_step<MODEL, NT, BIG, TILE, RS>;
+    auto kern = &k_filter_step<MODEL, NT, BIG, TILE, RS, WL2>;
     if (lds > granted.load(std::memory_order_relaxed)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         granted.store(lds, std::memory_order_relaxed);
@@ -250,11 +250,18 @@ static int hot_config(ssme_pf_handle h, const StepArgs& a) {
     return h->cfg.resampler == SSME_RESAMP_MULTINOMIAL ? 0 : (h->cfg.resampler == SSME_RESAMP_SYSTEMATIC ? 1 : -1);
 }
 
+template <int MODEL, int NT, bool BIG, int TILE, bool WL2>
+static void launch_rs_w(ssme_pf_handle h, const StepArgs& a, dim3 grid, size_t lds, int rs) {
+    if (rs == 0) launch_k<MODEL, NT, BIG, TILE, 0, WL2>(h, a, grid, lds);
+    else if (rs == 1) launch_k<MODEL, NT, BIG, TILE, 1, WL2>(h, a, grid, lds);
+    else launch_k<MODEL, NT, BIG, TILE, -1, WL2>(h, a, grid, lds);
+}
+// WL2: filters of at most 128 tiles take the level-2 wave by wave (k_filter_step); its own instantiations
 template <int MODEL, int NT, bool BIG, int TILE>
 static void launch_rs(ssme_pf_handle h, const StepArgs& a, dim3 grid, size_t lds, int rs) {
-    if (rs == 0) launch_k<MODEL, NT, BIG, TILE, 0>(h, a, grid, lds);
-    else if (rs == 1) launch_k<MODEL, NT, BIG, TILE, 1>(h, a, grid, lds);
-    else launch_k<MODEL, NT, BIG, TILE, -1>(h, a, grid, lds);
+    if (BIG) { launch_rs_w<MODEL, NT, BIG, TILE, false>(h, a, grid, lds, rs); return; }
+    if (g_grant_only || a.B <= 128) launch_rs_w<MODEL, NT, false, TILE, true>(h, a, grid, lds, rs);
+    if (g_grant_only || a.B > 128) launch_rs_w<MODEL, NT, false, TILE, false>(h, a, grid, lds, rs);
 }
 
 template <int MODEL>

@@ -508,7 +508,7 @@ __device__ __forceinline__ void store_pair(double* p, double v0, double v1, int 
         __builtin_nontemporal_store(v, reinterpret_cast<f64x2_t*>(p));
     } else *reinterpret_cast<double2*>(p) = make_double2(v0, v1);
 }
-template <int MODEL, int NT, bool BIG = false, int TILE = kTile, int RS = -1>
+template <int MODEL, int NT, bool BIG = false, int TILE = kTile, int RS = -1, bool WL2 = false>
 __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     constexpr int NK = TILE / 2 / NT;
     constexpr bool HOT = RS >= 0;
@@ -562,7 +562,8 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     // hand-over and one barrier less.  Afterwards a thread keeps the entry the general layout gives it (j = tid: the low
     // half in wave 0, the high half in wave 1), so everything after the level-2 reads the same registers; the other waves'
     // copies fail every `j < B` test below.  Integer sums and a max: the same bits as the block-wide form.
-    const bool wave_l2 = !BIG && need_l2 && a.B <= 128;
+    // (a template parameter, WL2 = the host's "B <= 128": as a run-time branch its mere presence cost the N = 2^20 kernel 2 %)
+    const bool wave_l2 = WL2 && !BIG && need_l2;
     double Ahi = 0.0, Mhi = 0.0;
     if (wave_l2) {
         const int ln = tid & 63;
