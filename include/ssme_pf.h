@@ -238,8 +238,9 @@ int ssme_pf_shard_finalize(ssme_pf_handle h, int32_t t, const double* tsum_all, 
  * one: rank 0 calls ssme_shard_comm_get_unique_id, ships the 128 bytes to the other ranks by any means, every rank calls
  * ssme_shard_comm_init).
  * ssme_pf_shard_run_series runs the whole series on the handle's stream.  mode 0: fixed-halo exchange with the two
- * neighbouring ranks and no host synchronisation inside the time loop; a device flag records whether any rank's
- * resampling window ever left the halo, and if so the series is run again on the exact path; mode 1: fixed halo only
+ * neighbouring ranks and no host synchronisation inside the time loop; a device flag per rank records whether one of its
+ * resampling windows ever left the halo, the flags are reduced over the ranks after the loop (ncclAllReduce, max), and if any is
+ * set EVERY rank runs the series again on the exact path; mode 1: fixed halo only
  * (SSME_ERR_STATE if a window left it); mode 2: exact path (the plan is downloaded every step, exactly the planned tiles
  * travel between any two ranks).  Results are bit-identical to the unsharded filter on every path.  loglik_out: 1 value,
  * identical on every rank.  Buffers are owned by the handle. */
@@ -251,6 +252,11 @@ int ssme_pf_shard_run_series(ssme_pf_handle h, void* nccl_comm, const double* y,
 /* after ssme_pf_shard_run_series: this rank's N / world particles and integer cdf (nullable), the path the last series
  * took (1 fixed halo, 2 exact) and the number of tiles this rank received from other ranks */
 int ssme_pf_shard_download(ssme_pf_handle h, double* x_local, uint64_t* cdf_local, int32_t* path, int64_t* exchanged_tiles);
+/* after ssme_pf_shard_run_series, of its last FIXED-HALO pass: out4[0] = 1 if a resampling window left the halo on ANY rank (the
+ * per-rank flags reduced by one ncclAllReduce(max) after the time loop -- every rank reads the same value, so every rank takes
+ * the same fallback decision), out4[1] = this rank's own flag, out4[2] / out4[3] = widest reach left / right of the own tiles
+ * where the split level-2 planned the exchange (0 otherwise) */
+int ssme_pf_shard_stats(ssme_pf_handle h, int32_t* out4);
 
 /* ============================================================================================
  * Liu-West filter: LWFilterWithCovs<nparts,1,1,1,4,float_t>::filter (include/ssme/liu_west_filter.h:971-1159)
@@ -331,11 +337,13 @@ int ssme_lw_shard_stage2(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t
 int ssme_lw_shard_finalize(ssme_lw_handle h, int32_t t, const double* tsumB_all, const double* tmaxB_all);
 /* The same loop in C++ over RCCL (see ssme_pf_shard_run_series; comm from ssme_shard_comm_init or the caller's own
  * ncclComm_t): fixed-halo exchange with the two neighbouring ranks, no host synchronisation inside the time loop.  The
- * stage kernels verify their own source tiles against the exchanged window; if one ever left it the call returns
- * SSME_ERR_STATE and the caller runs the exact host-planned loop over the step-wise entry points above.  loglik_out: 1. */
+ * stage kernels verify their own source tiles against the exchanged window; if one ever left it ON ANY RANK (flags reduced by
+ * ncclAllReduce after the loop) the call returns SSME_ERR_STATE ON EVERY RANK and the caller runs the exact host-planned loop over the step-wise entry points above.  loglik_out: 1. */
 int ssme_lw_shard_run_series(ssme_lw_handle h, void* nccl_comm, const double* y, const double* z, int32_t T, double* loglik_out);
 /* after ssme_lw_shard_run_series: this rank's N / world particles, transformed parameters theta[d * n + i], tiles received */
 int ssme_lw_shard_download(ssme_lw_handle h, double* x_local, double* theta_local, int64_t* exchanged_tiles);
+/* as ssme_pf_shard_stats: out4[0] the reduced flag (SSME_ERR_STATE was returned on EVERY rank if it is set), out4[1] this rank's own */
+int ssme_lw_shard_stats(ssme_lw_handle h, int32_t* out4);
 int ssme_lw_get_loglik(ssme_lw_handle h, double* out);
 
 

@@ -48,7 +48,9 @@ struct ssme_pf_s {
     // C++ shard driver (ssme_pf_shard_run_series): halo buffers [margin | own tiles | margin] x 2048 doubles, ping-pong;
     // this rank's tile sums / maxima, their gathered and repacked forms; exact-path window buffers; flag + statistics
     double *sh_x[2], *sh_c[2], *sh_loc, *sh_raw, *sh_tsum, *sh_tmax, *sh_winx, *sh_winc;
-    int32_t* sh_flag;        // [0] a window left the halo, [1] / [2] widest reach left / right of the own tiles (in tiles)
+    int32_t* sh_flag;        // [0] a window left the halo ON THIS RANK, [1] / [2] widest reach left / right of the own tiles (in tiles),
+                             // [3] max of [0] over all ranks (ncclAllReduce after the time loop): what the fallback decision reads
+    int32_t sh_stats[4];     // host copy of sh_flag after the last native series
     int sh_margin, sh_rows, sh_path;   // sh_path: path of the last native series (1 fixed halo, 2 exact)
     int sh_check;            // 1 while the driver's fixed-halo path launches a step: the kernel verifies its source tiles
     long sh_exchanged;       // tiles received from other ranks during the last native series
@@ -859,9 +861,15 @@ static int shard_series(ssme_pf_handle h, ncclComm_t comm, const double* y, cons
     rc = ssme_pf_shard_finalize(h, T - 1, h->sh_tsum, h->sh_tmax);                    // synchronises
     if (rc != SSME_OK) return rc;
     h->cur = cur;                                                                     // sh_x[cur] holds the final particles
-    int32_t flag[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpy(flag, h->sh_flag, sizeof(flag), hipMemcpyDeviceToHost));
-    *overflow = fast && flag[0] != 0;
+    // The fallback decision must be the SAME on every rank: a rank's own flag only says what its own workgroups saw (up to
+    // 1024 tiles no plan kernel runs), so the flags are reduced over the ranks before anyone reads them.  One int, once per series.
+    *overflow = false;
+    if (fast) {           // (the exact path has no halo to leave; sh_stats keeps the record of the fixed-halo pass it may be the rerun of)
+        NCCLCHK(rccl().AllReduce(h->sh_flag, h->sh_flag + 3, 1, ncclInt32, ncclMax, comm, h->stream));
+        HIPCHK(hipMemcpyAsync(h->sh_stats, h->sh_flag, sizeof(h->sh_stats), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        *overflow = h->sh_stats[3] != 0;
+    }
     return SSME_OK;
 }
 
@@ -877,11 +885,12 @@ int ssme_pf_shard_run_series(ssme_pf_handle h, void* nccl_comm, const double* y,
     int rc = shard_alloc(h, !want_fast);
     if (rc != SSME_OK) return rc;
     bool overflow = false;
+    std::memset(h->sh_stats, 0, sizeof(h->sh_stats));
     h->sh_path = want_fast ? 1 : 2;
     rc = shard_series(h, comm, y, z, T, want_fast, &overflow);
     if (rc != SSME_OK) return rc;
     if (overflow) {
-        // a window left the fixed halo on SOME rank (the flag is computed from the shared plan, so every rank sees it):
+        // a window left the fixed halo on SOME rank (the reduced flag: every rank reads the same value and takes the same branch):
         // mode 1 reports it, mode 0 runs the series again on the exact path
         if (mode == 1) { h->err = "a resampling window left the fixed halo"; return SSME_ERR_STATE; }
         rc = shard_alloc(h, true);
@@ -908,6 +917,13 @@ int ssme_pf_shard_download(ssme_pf_handle h, double* x_local, uint64_t* cdf_loca
     }
     if (path) *path = h->sh_path;
     if (exchanged_tiles) *exchanged_tiles = h->sh_exchanged;
+    return SSME_OK;
+}
+
+int ssme_pf_shard_stats(ssme_pf_handle h, int32_t* out4) {
+    if (!h || !out4) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1 || !h->sh_x[0]) return SSME_ERR_STATE;
+    out4[0] = h->sh_stats[3]; out4[1] = h->sh_stats[0]; out4[2] = h->sh_stats[1]; out4[3] = h->sh_stats[2];
     return SSME_OK;
 }
 
@@ -1522,7 +1538,8 @@ struct ssme_lw_s {
     // this rank's stage outputs for the gathers, the gathered arrays, flag
     double *sh_xB, *sh_thB, *sh_cdfB, *sh_xr, *sh_thr, *sh_g1, *sh_cdfA;
     double *sh_locB, *sh_locA, *sh_allB_s, *sh_allB_m, *sh_allA_s, *sh_allA_m, *sh_mom_all;
-    int32_t* sh_flag;
+    int32_t* sh_flag;        // [0] a window left the halo on this rank, [3] max of [0] over all ranks
+    int32_t sh_stats[4];
     int sh_margin, sh_rows, sh_check;
     long sh_exchanged;
     int gamma_t0, gamma_rows;        // step API: the Gamma tables hold time indices gamma_t0 .. gamma_t0 + gamma_rows - 1
@@ -2084,9 +2101,11 @@ int ssme_lw_shard_run_series(ssme_lw_handle h, void* nccl_comm, const double* y,
     if (rc != SSME_OK) return rc;
     rc = ssme_lw_shard_finalize(h, T - 1, h->sh_allB_s, h->sh_allB_m);           // synchronises
     if (rc != SSME_OK) return rc;
-    int32_t flag[4] = {0, 0, 0, 0};
-    LWCHK(hipMemcpy(flag, h->sh_flag, sizeof(flag), hipMemcpyDeviceToHost));
-    if (flag[0]) { h->err = "a resampling window left the fixed halo: run the exact host-planned loop"; return SSME_ERR_STATE; }
+    // every rank must take the same branch (see shard_series): reduce the per-rank flags before reading them
+    LWNCCL(rccl().AllReduce(h->sh_flag, h->sh_flag + 3, 1, ncclInt32, ncclMax, comm, h->stream));
+    LWCHK(hipMemcpyAsync(h->sh_stats, h->sh_flag, sizeof(h->sh_stats), hipMemcpyDeviceToHost, h->stream));
+    LWCHK(hipStreamSynchronize(h->stream));
+    if (h->sh_stats[3]) { h->err = "a resampling window left the fixed halo on some rank: run the exact host-planned loop"; return SSME_ERR_STATE; }
     if (loglik_out) return ssme_lw_get_loglik(h, loglik_out);
     return SSME_OK;
 }
@@ -2104,6 +2123,13 @@ int ssme_lw_shard_download(ssme_lw_handle h, double* x_local, double* theta_loca
         for (size_t i = 0; i < n; ++i) for (int d = 0; d < kDP; ++d) theta_local[(size_t)d * n + i] = rec[i * kDP + d];
     }
     if (exchanged_tiles) *exchanged_tiles = h->sh_exchanged;
+    return SSME_OK;
+}
+
+int ssme_lw_shard_stats(ssme_lw_handle h, int32_t* out4) {
+    if (!h || !out4) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1 || !h->sh_xB) return SSME_ERR_STATE;
+    out4[0] = h->sh_stats[3]; out4[1] = h->sh_stats[0]; out4[2] = h->sh_stats[1]; out4[3] = h->sh_stats[2];
     return SSME_OK;
 }
 

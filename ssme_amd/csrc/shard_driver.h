@@ -9,8 +9,11 @@
 //         a device flag if a window leaves the fixed halo
 //     grouped ncclSend / ncclRecv of the halo tiles (integer cdf + particles) with the two neighbouring ranks
 //     k_filter_step on the rank's tiles, reading its window in place from the halo buffer
-// The flag is read once, after the series: if a window ever left the halo (very unbalanced weights), the series is run
-// again on the exact path (the plan is downloaded every step and exactly the planned tiles travel, any rank to any rank).
+// A rank's flag says what ITS OWN workgroups saw (up to 1024 tiles no plan kernel runs, so nothing else knows), and the
+// decision to run again must be the same on every rank -- otherwise one rank re-enters the collectives alone.  After the
+// time loop the flags are therefore reduced over the ranks (one ncclAllReduce(max) of one int, still on the stream), and
+// the reduced flag is what the host reads: if a window ever left the halo on ANY rank (very unbalanced weights), EVERY rank runs
+// the series again on the exact path (the plan is downloaded every step and exactly the planned tiles travel, any rank to any rank).
 // Results are bit-identical to the unsharded filter on both paths (RNG counters are global particle indices, the level-2
 // is the same exact integer arithmetic on the gathered tile sums).
 //
@@ -27,6 +30,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -50,12 +54,13 @@ static const RcclApi& rccl() {
         a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(rccl_sym(lib, "ncclCommInitRank"));
         a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(rccl_sym(lib, "ncclCommDestroy"));
         a.AllGather = reinterpret_cast<decltype(a.AllGather)>(rccl_sym(lib, "ncclAllGather"));
+        a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(rccl_sym(lib, "ncclAllReduce"));
         a.Send = reinterpret_cast<decltype(a.Send)>(rccl_sym(lib, "ncclSend"));
         a.Recv = reinterpret_cast<decltype(a.Recv)>(rccl_sym(lib, "ncclRecv"));
         a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(rccl_sym(lib, "ncclGroupStart"));
         a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(rccl_sym(lib, "ncclGroupEnd"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(rccl_sym(lib, "ncclGetErrorString"));
-        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.Send && a.Recv && a.GroupStart && a.GroupEnd;
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.AllReduce && a.Send && a.Recv && a.GroupStart && a.GroupEnd;
         return a;
     }();
     return api;

@@ -499,7 +499,9 @@ class ShardedLiuWest:
     # ---- the same loop in C++ over RCCL (ssme_lw_shard_run_series) ----
     def run_series_native(self, y, z=None):
         """log p(y_{1:T}) through the C++ driver (fixed-halo exchange, no host synchronisation per step).  If a resampling
-        window ever leaves the halo the driver says so and the exact Python-driven loop runs instead.  One GPU per rank."""
+        window ever leaves the halo ON ANY RANK the driver says so ON EVERY RANK (the per-rank flags are reduced by one
+        ncclAllReduce after the time loop) and the exact Python-driven loop runs instead -- on all ranks together, so the
+        collectives stay matched.  One GPU per rank."""
         import torch
         yv = capi.as_f64(y)
         zv = None if z is None else capi.as_f64(z)

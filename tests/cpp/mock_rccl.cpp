@@ -15,12 +15,13 @@
 
 extern "C" {
 typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclInvalidArgument = 4 } ncclResult_t;
-typedef enum { ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclInt32 = 2, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 }
 
 namespace {
-struct Op { int kind; const void* send; void* recv; size_t count; int peer; };   // kind 0 all-gather, 1 send, 2 recv
+struct Op { int kind; const void* send; void* recv; size_t count; int peer; };   // kind 0 all-gather, 1 send, 2 recv, 3 all-reduce(max) of int32
 struct World {
     int size = 0, arrived = 0, generation = 0, attached = 0;
     std::mutex mu;
@@ -56,6 +57,16 @@ ncclResult_t flush() {
                 if (hipMemcpyAsync(static_cast<char*>(op.recv) + (size_t)p * op.count * 8, peer.send, op.count * 8, hipMemcpyDeviceToDevice, g_stream) != hipSuccess)
                     return ncclUnhandledCudaError;
             }
+        } else if (op.kind == 3) {
+            // max of int32 over the ranks: every rank reads every peer's values and writes the maximum to its own output
+            std::vector<int32_t> acc(op.count), tmp(op.count);
+            for (int p = 0; p < w->size; ++p) {
+                const Op& peer = w->posted[p][i];
+                if (peer.kind != 3 || peer.count != op.count) return ncclInvalidArgument;
+                if (hipMemcpy(tmp.data(), peer.send, op.count * 4, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+                for (size_t k = 0; k < op.count; ++k) acc[k] = (p == 0 || tmp[k] > acc[k]) ? tmp[k] : acc[k];
+            }
+            if (hipMemcpy(op.recv, acc.data(), op.count * 4, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
         } else if (op.kind == 2) {
             // my k-th receive from `peer` pairs with its k-th send to me
             int k = 0;
@@ -93,6 +104,10 @@ ncclResult_t ncclGroupStart() { ++g_depth; return ncclSuccess; }
 ncclResult_t ncclGroupEnd() { return --g_depth == 0 ? flush() : ncclSuccess; }
 ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t, void* comm, hipStream_t s) {
     return add(static_cast<Comm*>(comm), s, Op{0, send, recv, count, -1});
+}
+ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, void* comm, hipStream_t s) {
+    if (dt != ncclInt32 || op != ncclMax) return ncclInvalidArgument;            // the one form the drivers use
+    return add(static_cast<Comm*>(comm), s, Op{3, send, recv, count, -1});
 }
 ncclResult_t ncclSend(const void* send, size_t count, ncclDataType_t, int peer, void* comm, hipStream_t s) {
     return add(static_cast<Comm*>(comm), s, Op{1, send, nullptr, count, peer});

@@ -1,7 +1,10 @@
 // test_shard_threads.cpp -- the C++ shard drivers with SEVERAL ranks on one GPU: every rank is a host thread with its own
 // handle, the "RCCL" underneath is tests/cpp/mock_rccl.cpp (linked before anything else, so dlsym finds it).  Prints, per
 // configuration, what every rank got and what the unsharded filter gives; tests/test_sharded_gpu.py compares.
-//   usage: test_shard_threads CSV WORLD N T MODEL RESAMPLER MODE SEED      (MODEL -1: Liu-West, RESAMPLER = delta x 1000)
+//   usage: test_shard_threads CSV WORLD N T MODEL RESAMPLER MODE SEED [TAU [YSCALE]]     (MODEL -1: Liu-West, RESAMPLER = delta x 1000)
+//   TAU (linear-Gaussian model only): observation noise; a tiny value puts all the weight of a step on the one particle next to
+//   y_t, so every rank's next resampling window is that particle's tile -- far ranks leave their halo, near ranks do not.
+//   YSCALE: the observations are multiplied by it (outliers: the stochastic-volatility weights then degenerate the same way).
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -19,13 +22,14 @@ int main(int argc, char** argv) {
     const unsigned long long seed = std::strtoull(argv[8], nullptr, 10);
     std::vector<double> y, z;
     { std::ifstream f(argv[1]); double v; while (f >> v && (int)y.size() < T) y.push_back(v); }
+    if (argc > 10) for (double& v : y) v *= std::atof(argv[10]);
     z.assign(y.size(), 0.0);
     for (size_t t = 1; t < y.size(); ++t) z[t] = y[t - 1];
-    const double th_svol[3] = {1.0, 0.95, 0.25}, th_lev[4] = {0.9, 0.0, 1.0, -0.1}, th_lg[3] = {0.9, 0.5, 0.7};
+    const double th_svol[3] = {1.0, 0.95, 0.25}, th_lev[4] = {0.9, 0.0, 1.0, -0.1}, th_lg[3] = {0.9, 0.5, argc > 9 ? std::atof(argv[9]) : 0.7};
     char id[128];
     ssme_shard_comm_get_unique_id(id);
     std::vector<double> ll(world, 0.0);
-    std::vector<int> path(world, 0);
+    std::vector<int> path(world, 0), own_flag(world, 0), any_flag(world, 0);
     std::vector<long long> exch(world, 0);
     std::vector<std::vector<double>> xs(world);
     std::vector<std::thread> ranks;
@@ -48,6 +52,9 @@ int main(int argc, char** argv) {
             int32_t p = 0; int64_t e = 0;
             ssme_pf_shard_download(h, xs[r].data(), nullptr, &p, &e);
             path[r] = p; exch[r] = e;
+            int32_t st[4] = {0, 0, 0, 0};
+            ssme_pf_shard_stats(h, st);
+            any_flag[r] = st[0]; own_flag[r] = st[1];
             ssme_pf_destroy(h);
         } else {
             ssme_lw_config c{};
@@ -64,6 +71,9 @@ int main(int argc, char** argv) {
             int64_t e = 0;
             if (!rc) ssme_lw_shard_download(h, xs[r].data(), nullptr, &e);
             exch[r] = e;
+            int32_t st[4] = {0, 0, 0, 0};
+            ssme_lw_shard_stats(h, st);
+            any_flag[r] = st[0]; own_flag[r] = st[1];
             ssme_lw_destroy(h);
         }
         ssme_shard_comm_destroy(comm);
@@ -99,7 +109,8 @@ int main(int argc, char** argv) {
         if (path[r] == 1 || model >= 0)
             for (size_t i = 0; i < xs[r].size(); ++i) mism += xs[r][i] != xref[(size_t)r * (N / world) + i];
     std::printf("ref %.17g\n", ll_ref);
-    for (int r = 0; r < world; ++r) std::printf("rank %d ll %.17g path %d exchanged %lld\n", r, ll[r], path[r], exch[r]);
+    // any_left_halo: the reduced flag of the last fixed-halo pass (identical on every rank); own_left_halo: what this rank's own workgroups saw
+    for (int r = 0; r < world; ++r) std::printf("rank %d ll %.17g path %d exchanged %lld any_left_halo %d own_left_halo %d\n", r, ll[r], path[r], exch[r], any_flag[r], own_flag[r]);
     std::printf("particle_mismatches %zu\n", mism);
     return 0;
 }

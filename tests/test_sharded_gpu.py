@@ -221,3 +221,37 @@ def test_native_drivers_with_several_ranks_on_one_gpu(world, n, T, model, rs, mo
         assert paths == {2}
     if mode == 1:
         assert paths == {1}
+
+
+@pytest.mark.parametrize("model,seed", [(2, 4242), (2, 7), (2, 99), (-1, 4242)])
+def test_window_overflow_on_some_ranks_only_is_decided_globally(model, seed):
+    """VERDICT r2 / ADVICE r2 (high): below 1024 tiles no plan kernel runs, so a rank's overflow flag says only what its OWN
+    workgroups saw.  Linear-Gaussian filter with observation noise 1e-7: all the weight of a step sits on the one particle
+    next to y_t, so every rank's next window is that particle's tile -- with 4 ranks x 2 tiles and a 2-tile halo the ranks far
+    from it leave their halo and the near ones do not (never all four, never none).  Every rank must nevertheless read the
+    same reduced flag, take the exact path together (no rank blocks in a collective the others never post) and end with the
+    unsharded filter's bits.  Liu-West (model -1; observations x 40, so that the particle of highest volatility takes all
+    the weight): SSME_ERR_STATE on every rank or on none."""
+    exe = _build_thread_harness()
+    world, n, T = 4, 4 * 2 * 2048, 2          # ONE resampling step: the flags accumulate over the steps, and every step picks another tile
+    args = [exe, os.path.join(ROOT, "tests", "golden", "spy_returns.csv"), str(world), str(n), str(T), str(model),
+            "990" if model < 0 else "0", "0", str(seed)] + (["1e-7"] if model >= 0 else ["0.7", "40"])
+    out = subprocess.check_output(args, text=True, timeout=180)          # a rank left alone in a collective would hang here
+    lines = out.strip().splitlines()
+    ref = float(lines[0].split()[1])
+    ranks = [l.split() for l in lines if l.startswith("rank")]
+    assert len(ranks) == world
+    paths = [int(r[5]) for r in ranks]
+    any_flag = [int(r[9]) for r in ranks]
+    own_flag = [int(r[11]) for r in ranks]
+    assert len(set(paths)) == 1 and len(set(any_flag)) == 1             # one decision, the same on every rank
+    assert any_flag[0] == max(own_flag)
+    if model >= 0:
+        assert 0 < sum(own_flag) < world, own_flag                       # the case this test exists for: some ranks only
+        assert paths[0] == 2                                             # ... and ALL of them reran on the exact path
+        for r in ranks:
+            assert float(r[3]) == ref, (r, ref)
+        assert lines[-1] == "particle_mismatches 0"
+    else:
+        assert 0 < sum(own_flag) < world, own_flag
+        assert paths[0] == 2                                             # SSME_ERR_STATE on every rank (the harness prints 2)
