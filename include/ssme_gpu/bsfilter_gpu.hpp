@@ -17,15 +17,21 @@
 // std::function returning a dynamic matrix, default ctor + copy-assign, filter(y, z, const std::vector<func>&),
 // std::vector<dynamic_matrix> getExpectations(), and -- through the optional `Base` template parameter -- inheritance
 // from pf::bases::pf_withcov_base<float_t,dimy,dimx,dimcov>, so that the static_assert at :352 holds as written.
-// Host std::function callbacks cannot run on the device.  Each h in fs is therefore PROBED on the host at six state
-// values: a function that is constant, x, x^2 or exp(x/2) there is served by the device functionals (SSME_H_*);
-// anything else is evaluated on the host over the downloaded particles and weights (ssme_pf_download_weights) --
-// correct for every h, fast for the common ones.  gpu_options::probe_functionals = false forces the host path.
+// Host std::function callbacks cannot run on the device.  By default every h in fs is evaluated ON THE HOST over the
+// particles and weights of the member (one ssme_pf_download_weights per filter() call) -- correct for every h, of any
+// shape, stateful or not.  The device functionals (SSME_H_*: x, x^2, exp(x/2), the constant 42) are used only when the
+// caller says so: gpu_options::declared_functionals[j] = SSME_H_* declares that fs[j] of every filter() call IS that
+// functional (the swarm templates hand their functions over as std::bind objects inside std::function, so a tag on the
+// function itself would not survive; the user who writes instantiate_mod knows the swarm's functions).
+// gpu_options::probe_functionals = true (opt-in, off by default since round 3) additionally classifies undeclared functions
+// by evaluating them at six fixed states; a function that only differs from x / x^2 / exp(x/2) / a constant OUTSIDE
+// [-1.7, 3.25] (a tail indicator, a clamp) is misclassified by such a probe, which is why it is no longer the default.
 // Every model object draws its own random stream (the reference clock-seeds each object): the filter id defaults to a
 // process-wide counter.  Errors: std::invalid_argument / std::runtime_error, as the reference throws; NaN/-inf are values.
 #ifndef SSME_GPU_BSFILTER_GPU_HPP
 #define SSME_GPU_BSFILTER_GPU_HPP
 
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstddef>
@@ -35,6 +41,7 @@
 #include <sstream>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -56,10 +63,11 @@ class handle {
 public:
     handle() = default;
     handle(int model, int nparts, int nfilters, std::uint64_t seed, int resampler, int rs, int device, unsigned first_id,
-           int dtype = SSME_F64) {
+           int dtype = SSME_F64, int bank_filters = 0) {
         ssme_pf_config c{};
         c.model = model; c.n_particles = nparts; c.n_filters = nfilters; c.dtype = dtype; c.resampler = resampler;
         c.resamp_sched = rs; c.seed = seed; c.device = device; c.first_filter_id = first_id;
+        c.n_filters_total = bank_filters > nfilters ? bank_filters : 0;
         ssme_pf_handle raw = nullptr;
         check(ssme_pf_create(&c, &raw));
         h_ = std::shared_ptr<ssme_pf_s>(raw, [](ssme_pf_handle p) { if (p) ssme_pf_destroy(p); });
@@ -75,7 +83,11 @@ struct gpu_options {
     int resampler = SSME_RESAMP_MULTINOMIAL;
     int resamp_sched = 1;
     int device = 0;
-    bool probe_functionals = true;   // recognise constant / x / x^2 / exp(x/2) functionals and run them on the device
+    bool probe_functionals = false;  // opt-in: classify undeclared functionals by six probe evaluations (see the header comment)
+    std::vector<int> declared_functionals;   // [j] = SSME_H_* : fs[j] of every filter() call IS that device functional; -1 / absent = host
+    int bank_filters = 0;            // size of the whole bank of filters this model object belongs to (swarm members, replicates):
+                                     // the default tile size follows the bank (ssme_pf_config::n_filters_total), so a member gives
+                                     // the same bits in its own handle as inside a batched handle.  0 = this handle alone
 };
 
 // Filter id of a model object constructed without one: a process-wide counter, so that every object has its own random
@@ -179,14 +191,16 @@ struct functional_engine {
     // E[h_i] for every h of `hs` after the last step of single-filter handle `hd`: device functionals in one pass,
     // everything else on the host over ONE download of (x, weights).
     template <typename H>
-    static std::vector<Mat> expectations(ssme_pf_handle hd, const std::vector<H>& hs, std::size_t nparts, bool probe) {
+    static std::vector<Mat> expectations(ssme_pf_handle hd, const std::vector<H>& hs, std::size_t nparts, bool probe,
+                                         const std::vector<int>& declared = std::vector<int>()) {
         std::vector<Mat> out;
         if (hs.empty()) return out;
         std::vector<int> kind(hs.size(), -1);
         std::vector<double> scale(hs.size(), 1.0);
         std::vector<int32_t> ids;
         for (std::size_t i = 0; i < hs.size(); ++i) {
-            if (probe) kind[i] = classify(hs[i], &scale[i]);
+            if (i < declared.size() && declared[i] >= SSME_H_X && declared[i] <= SSME_H_CONST42) kind[i] = declared[i];
+            else if (probe) kind[i] = classify(hs[i], &scale[i]);
             if (kind[i] >= 0 && ids.size() == 4) kind[i] = -1;           // more than 4 device functionals: the rest on the host
             if (kind[i] >= 0) ids.push_back(kind[i]);
         }
@@ -212,6 +226,156 @@ struct functional_engine {
 };
 }  // namespace detail
 
+// ---- swarm_context: ONE launch per observation behind the UNMODIFIED Swarm / SwarmWithCovs templates ----------------------
+// The reference's swarm calls filter(y_t[, z_t], fs) -> getExpectations() -> getLogCondLike() on every member, from the
+// workers of split_data_thread_pool (pswarm_filter.h:86-92,380-388; thread_pool.h:542-554).  A member with its own handle
+// costs one launch and one wait per call: 512 members x 18 us = 9 ms per observation where the batched step takes 0.1 ms.
+// A swarm_context is the members' shared device state: created once by the user's swarm class, handed to every model its
+// instantiate_mod() constructs (member i = filter i of ONE C-ABI handle, theta row i).  The FIRST member whose filter() call
+// arrives for a new observation advances ALL members (one ssme_pf_step, one ssme_pf_get_expectations_multi for the declared
+// device functionals); every other member's call for that observation checks that it was given the same (y_t, z_t) and
+// reads its cached row.  Calls are serialised by a mutex, so the reference's concurrent workers are safe; a member may lag
+// the context by at most the observation in flight (the swarm finishes one update before it starts the next).
+// Results are those of one handle per member, to the bit (same filter ids, same theta, same tile: the tile follows the bank).
+template <typename float_t = double>
+class swarm_context {
+public:
+    // model: SSME_MODEL_SVOL_LEVERAGE (SwarmWithCovs members) or SSME_MODEL_SVOL (Swarm members); n_members = nparamparts
+    swarm_context(int model, std::size_t nparts, std::size_t n_members, gpu_options o = gpu_options())
+        : model_(model), nparts_(nparts), n_members_(n_members), opt_(o), n_theta_(model == SSME_MODEL_SVOL_LEVERAGE ? 4 : 3) {
+        if (n_members == 0) throw std::invalid_argument("a swarm needs members");
+        for (std::size_t j = 0; j < o.declared_functionals.size(); ++j) {
+            const int id = o.declared_functionals[j];
+            if (id >= SSME_H_X && id <= SSME_H_CONST42) { slot_of_func_.push_back((int)ids_.size()); ids_.push_back(id); }
+            else slot_of_func_.push_back(-1);
+        }
+        if (ids_.size() > 4) throw std::invalid_argument("at most 4 device functionals per swarm");
+        theta_.reserve(n_members * (std::size_t)n_theta_);
+    }
+    // called by a member model's constructor; theta in the C ABI's order for the model.  Returns the member's index.
+    unsigned add_member(const double* theta) {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (h_) throw std::runtime_error("swarm_context: members cannot be added after the first filter() call");
+        if (theta_.size() / (std::size_t)n_theta_ >= n_members_) throw std::runtime_error("swarm_context: more members than declared");
+        theta_.insert(theta_.end(), theta, theta + n_theta_);
+        return (unsigned)(theta_.size() / (std::size_t)n_theta_ - 1);
+    }
+    // member `i`, which has seen `member_steps` observations so far, is given (y, z); z = nullptr: no covariate
+    void filter(unsigned i, unsigned long member_steps, double y, const double* z) {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!h_) start();
+        if (i >= n_members_) throw std::invalid_argument("swarm_context: no such member");
+        if (member_steps == steps_) {                                   // first arrival for this observation: everybody moves
+            check(ssme_pf_step(h_.get(), &y, z, lcl_.data()), h_.get());
+            if (!ids_.empty()) check(ssme_pf_get_expectations_multi(h_.get(), ids_.data(), (int32_t)ids_.size(), dev_.data()), h_.get());
+            y_ = y; z_ = z ? *z : 0.0; has_z_ = z != nullptr;
+            ++steps_;
+        } else if (member_steps + 1 == steps_) {
+            const bool same = y == y_ && has_z_ == (z != nullptr) && (!z || *z == z_);
+            if (!same) throw std::invalid_argument("swarm_context: the members of one swarm must be given the same observation and covariate");
+        } else throw std::runtime_error("swarm_context: a member is more than one observation behind the swarm");
+    }
+    double log_cond_like(unsigned i) const { std::lock_guard<std::mutex> lk(mu_); return lcl_[i]; }
+    // slot of functional j among the device functionals, or -1: evaluate it on the host
+    int device_slot(std::size_t j) const { return j < slot_of_func_.size() ? slot_of_func_[j] : -1; }
+    double device_expectation(int slot, unsigned i) const { std::lock_guard<std::mutex> lk(mu_); return dev_[(std::size_t)slot * n_members_ + i]; }
+    // particles and weights of member i after the observation it has just been given (host functionals)
+    void download(unsigned i, unsigned long member_steps, std::vector<double>& x, std::vector<double>& w) const {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (member_steps != steps_) throw std::runtime_error("swarm_context: the swarm has moved on; this member's weights are gone");
+        x.resize(nparts_); w.resize(nparts_);
+        check(ssme_pf_download_weights(h_.get(), (int32_t)i, x.data(), w.data()), h_.get());
+    }
+    std::size_t nparts() const { return nparts_; }
+    std::size_t members() const { return n_members_; }
+    bool probe() const { return opt_.probe_functionals; }
+    ssme_pf_handle native() const { return h_.get(); }
+
+private:
+    void start() {
+        if (theta_.size() != n_members_ * (std::size_t)n_theta_) throw std::runtime_error("swarm_context: fewer members were constructed than declared");
+        h_ = handle(model_, (int)nparts_, (int)n_members_, opt_.seed, opt_.resampler, opt_.resamp_sched, opt_.device, 0,
+                    detail::dtype_of<float_t>(), opt_.bank_filters);
+        check(ssme_pf_set_params(h_.get(), theta_.data(), n_theta_, (int32_t)n_members_), h_.get());
+        lcl_.assign(n_members_, 0.0);
+        dev_.assign(ids_.size() * n_members_, 0.0);
+    }
+    int model_;
+    std::size_t nparts_, n_members_;
+    gpu_options opt_;
+    int n_theta_;
+    mutable std::mutex mu_;
+    handle h_;
+    std::vector<double> theta_, lcl_, dev_;
+    std::vector<int32_t> ids_;
+    std::vector<int> slot_of_func_;
+    unsigned long steps_ = 0;
+    double y_ = 0.0, z_ = 0.0;
+    bool has_z_ = false;
+};
+
+namespace detail {
+// what the two member model types share: their own handle, or a slot in a swarm_context
+template <std::size_t nparts, typename float_t, typename Mat, typename Ssv>
+class member_core {
+public:
+    member_core() = default;
+    member_core(int model, const double* theta, int n_theta, const gpu_options& o, unsigned filter_id)
+        : h_(model, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device, resolve_filter_id(filter_id), dtype_of<float_t>(),
+             o.bank_filters),
+          probe_(o.probe_functionals), declared_(o.declared_functionals) {
+        check(ssme_pf_set_params(h_.get(), theta, n_theta, 1), h_.get());
+    }
+    member_core(const std::shared_ptr<swarm_context<float_t>>& ctx, const double* theta) : ctx_(ctx) {
+        if (!ctx) throw std::invalid_argument("null swarm_context");
+        if (ctx->nparts() != nparts) throw std::invalid_argument("swarm_context was made for another particle count");
+        idx_ = ctx->add_member(theta);
+        probe_ = ctx->probe();
+    }
+    // hs: the functionals with the covariate (if any) already bound
+    template <typename H>
+    void step(double y, const double* z, const std::vector<H>& hs) {
+        if (ctx_) {
+            ctx_->filter(idx_, steps_, y, z);
+            ++steps_;
+            last_ = (float_t)ctx_->log_cond_like(idx_);
+            expectations_.clear();
+            std::vector<double> x, w;
+            for (std::size_t j = 0; j < hs.size(); ++j) {
+                int slot = ctx_->device_slot(j);
+                if (slot >= 0) {
+                    Mat m(1, 1);
+                    m(0, 0) = (float_t)ctx_->device_expectation(slot, idx_);
+                    expectations_.push_back(m);
+                    continue;
+                }
+                if (w.empty()) ctx_->download(idx_, steps_, x, w);
+                expectations_.push_back(functional_engine<float_t, Mat, Ssv>::host_expectation(hs[j], x, w));
+            }
+            return;
+        }
+        if (!h_) throw std::runtime_error("model not constructed");
+        double out = 0.0;
+        check(ssme_pf_step(h_.get(), &y, z, &out), h_.get());
+        last_ = (float_t)out;
+        expectations_ = functional_engine<float_t, Mat, Ssv>::expectations(h_.get(), hs, nparts, probe_, declared_);
+    }
+    float_t last() const { return last_; }
+    const std::vector<Mat>& expectations() const { return expectations_; }
+    ssme_pf_handle native() const { return ctx_ ? ctx_->native() : h_.get(); }
+
+private:
+    handle h_;
+    std::shared_ptr<swarm_context<float_t>> ctx_;
+    unsigned idx_ = 0;
+    unsigned long steps_ = 0;
+    bool probe_ = false;
+    std::vector<int> declared_;
+    float_t last_ = 0;
+    std::vector<Mat> expectations_;
+};
+}  // namespace detail
+
 // ---- svol_leverage (BSFilterWC): a ModType for the unmodified SwarmWithCovs ------------------------------------------
 // Template parameters: Mat = the model's dynamic_matrix (Eigen::Matrix<float_t,-1,-1> in the reference), Osv / Ssv / Cvsv =
 // observation / state / covariate vectors (Eigen::Matrix<float_t,1,1>), Base = pf::bases::pf_withcov_base<float_t,1,1,1>
@@ -225,34 +389,33 @@ public:
     using float_type = float_t;
     using dynamic_matrix = Mat;
     using func = std::function<const Mat(const Ssv&, const Cvsv&)>;     // pf_withcov_base::func; what Swarm binds (:272-275)
+    using context = swarm_context<float_t>;
     svol_leverage_gpu() = default;    // Swarm default-constructs its array of models (pswarm_filter.h:71,367)
+    // its own handle: one launch and one wait per filter() call
     svol_leverage_gpu(const float_t& phi, const float_t& mu, const float_t& sigma, const float_t& rho, unsigned /*dte*/ = 0,
                       gpu_options o = gpu_options(), unsigned filter_id = auto_filter_id)
-        : h_(SSME_MODEL_SVOL_LEVERAGE, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device,
-             detail::resolve_filter_id(filter_id), detail::dtype_of<float_t>()), probe_(o.probe_functionals) {
-        const double th[4] = {(double)phi, (double)mu, (double)sigma, (double)rho};
-        check(ssme_pf_set_params(h_.get(), th, 4, 1), h_.get());
-    }
+        : core_(SSME_MODEL_SVOL_LEVERAGE, theta4(phi, mu, sigma, rho).data(), 4, o, filter_id) {}
+    // member of a swarm_context: all members of the swarm advance in ONE launch per observation (the context decides the
+    // member's filter id: its index, in construction order -- the order of the swarm's instantiate_mod calls)
+    svol_leverage_gpu(const float_t& phi, const float_t& mu, const float_t& sigma, const float_t& rho,
+                      const std::shared_ptr<context>& ctx)
+        : core_(ctx, theta4(phi, mu, sigma, rho).data()) {}
     // BSFilterWC::filter(y_t, z_t, fs) as SwarmWithCovs::comp_func calls it (pswarm_filter.h:383)
     void filter(const Osv& yt, const Cvsv& zt, const std::vector<func>& fs = std::vector<func>()) {
-        if (!h_) throw std::runtime_error("model not constructed");
-        const double y = (double)yt(0), z = (double)zt(0);
-        double out = 0.0;
-        check(ssme_pf_step(h_.get(), &y, &z, &out), h_.get());
-        last_ = (float_t)out;
+        const double z = (double)zt(0);
         std::vector<std::function<const Mat(const Ssv&)>> hs;
         for (const func& f : fs) hs.push_back([&f, &zt](const Ssv& xv) { return f(xv, zt); });
-        expectations_ = detail::functional_engine<float_t, Mat, Ssv>::expectations(h_.get(), hs, nparts, probe_);
+        core_.step((double)yt(0), &z, hs);
     }
-    float_t getLogCondLike() const { return last_; }
-    std::vector<Mat> getExpectations() const { return expectations_; }   // E[h(x_t) | y_{1:t}], pre-resampling weights
-    ssme_pf_handle native() const { return h_.get(); }
+    float_t getLogCondLike() const { return core_.last(); }
+    std::vector<Mat> getExpectations() const { return core_.expectations(); }   // E[h(x_t) | y_{1:t}], pre-resampling weights
+    ssme_pf_handle native() const { return core_.native(); }
 
 private:
-    handle h_;
-    bool probe_ = true;
-    float_t last_ = 0;
-    std::vector<Mat> expectations_;
+    static std::array<double, 4> theta4(float_t phi, float_t mu, float_t sigma, float_t rho) {
+        return {(double)phi, (double)mu, (double)sigma, (double)rho};
+    }
+    detail::member_core<nparts, float_t, Mat, Ssv> core_;
 };
 
 // ---- svol_bs as a ModType for the unmodified Swarm (no covariates; pswarm_filter.h:23-320, comp_func :86-92) -----------
@@ -263,32 +426,23 @@ public:
     using float_type = float_t;
     using dynamic_matrix = Mat;
     using func = std::function<const Mat(const Ssv&)>;                   // pf_base::func
+    using context = swarm_context<float_t>;
     svol_bs_member_gpu() = default;
     svol_bs_member_gpu(const float_t& phi, const float_t& beta, const float_t& sigma, gpu_options o = gpu_options(),
                        unsigned filter_id = auto_filter_id)
-        : h_(SSME_MODEL_SVOL, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device, detail::resolve_filter_id(filter_id),
-             detail::dtype_of<float_t>()),
-          probe_(o.probe_functionals) {
-        const double th[3] = {(double)beta, (double)phi, (double)sigma};
-        check(ssme_pf_set_params(h_.get(), th, 3, 1), h_.get());
-    }
-    void filter(const Osv& yt, const std::vector<func>& fs = std::vector<func>()) {
-        if (!h_) throw std::runtime_error("model not constructed");
-        const double y = (double)yt(0);
-        double out = 0.0;
-        check(ssme_pf_step(h_.get(), &y, nullptr, &out), h_.get());
-        last_ = (float_t)out;
-        expectations_ = detail::functional_engine<float_t, Mat, Ssv>::expectations(h_.get(), fs, nparts, probe_);
-    }
-    float_t getLogCondLike() const { return last_; }
-    std::vector<Mat> getExpectations() const { return expectations_; }
-    ssme_pf_handle native() const { return h_.get(); }
+        : core_(SSME_MODEL_SVOL, theta3(phi, beta, sigma).data(), 3, o, filter_id) {}
+    svol_bs_member_gpu(const float_t& phi, const float_t& beta, const float_t& sigma, const std::shared_ptr<context>& ctx)
+        : core_(ctx, theta3(phi, beta, sigma).data()) {}
+    void filter(const Osv& yt, const std::vector<func>& fs = std::vector<func>()) { core_.step((double)yt(0), nullptr, fs); }
+    float_t getLogCondLike() const { return core_.last(); }
+    std::vector<Mat> getExpectations() const { return core_.expectations(); }
+    ssme_pf_handle native() const { return core_.native(); }
 
 private:
-    handle h_;
-    bool probe_ = true;
-    float_t last_ = 0;
-    std::vector<Mat> expectations_;
+    static std::array<double, 3> theta3(float_t phi, float_t beta, float_t sigma) {      // C ABI order: beta, phi, sigma
+        return {(double)beta, (double)phi, (double)sigma};
+    }
+    detail::member_core<nparts, float_t, Mat, Ssv> core_;
 };
 
 // ---- log_like_eval with replicate batching -----------------------------------------------------------------
@@ -353,9 +507,10 @@ private:
 // filter(y[, fs]) without a covariate is the call of the no-covariate LWFilter / LWFilter2 (:238, :1447): the same model
 // with the covariate term at zero.
 // Functionals: the reference's std::function<const Mat(const ssv&, const csv&, const psv&)> (no-covariate forms:
-// (const ssv&, const psv&)) with the UNTRANSFORMED parameters (:1054-1075, :2267-2290).  Each h is probed on the host; one
-// that is constant, x, x^2, exp(x/2) or one of the four parameters there runs on the device (ssme_lw_get_expectations),
-// anything else is summed on the host over one download of (x, theta, weights).  Mat = the caller's dynamic matrix
+// (const ssv&, const psv&)) with the UNTRANSFORMED parameters (:1054-1075, :2267-2290).  A functional DECLARED as a built-in
+// (gpu_options::declared_functionals[j] = 0-3: SSME_H_* of the state, 4-7: phi, mu, sigma, rho) runs on the device
+// (ssme_lw_get_expectations); anything else is summed on the host over one download of (x, theta, weights);
+// gpu_options::probe_functionals opts into classification by six probe evaluations (see the header comment).  Mat = the caller's dynamic matrix
 // (Eigen::Matrix<float_t,-1,-1> in the reference); detail::small_matrix when none is given.
 namespace detail {
 template <typename T>
@@ -396,7 +551,8 @@ public:
     using dynamic_matrix = Mat;
     svol_lw_1_par_gpu(const float_t& delta, const float_t& phi_l, const float_t& phi_u, const float_t& mu_l, const float_t& mu_u,
                       const float_t& sig_l, const float_t& sig_u, const float_t& rho_l, const float_t& rho_u, unsigned /*dte*/ = 0,
-                      gpu_options o = gpu_options(), unsigned filter_id = auto_filter_id) : probe_(o.probe_functionals) {
+                      gpu_options o = gpu_options(), unsigned filter_id = auto_filter_id)
+        : probe_(o.probe_functionals), declared_(o.declared_functionals) {
         ssme_lw_config c{};
         c.n_particles = (int)nparts; c.n_filters = 1; c.seed = o.seed; c.device = o.device;
         c.first_filter_id = detail::resolve_filter_id(filter_id);
@@ -492,7 +648,8 @@ private:
         std::vector<double> scale(fs.size(), 1.0);
         std::vector<int32_t> ids;
         for (std::size_t i = 0; i < fs.size(); ++i) {
-            if (probe_) kind[i] = classify(fs[i], z, &scale[i]);
+            if (i < declared_.size() && declared_[i] >= 0 && declared_[i] <= 7) kind[i] = declared_[i];    // 0-3 SSME_H_*, 4-7 phi, mu, sigma, rho
+            else if (probe_) kind[i] = classify(fs[i], z, &scale[i]);
             if (kind[i] >= 0) ids.push_back(kind[i]);
         }
         const std::vector<double> dev = getExpectations(ids);
@@ -531,7 +688,8 @@ private:
 
     std::shared_ptr<ssme_lw_s> h_;
     float_t last_ = 0;
-    bool probe_ = true;
+    bool probe_ = false;
+    std::vector<int> declared_;
     std::vector<Mat> expectations_;
 };
 

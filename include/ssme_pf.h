@@ -82,20 +82,26 @@ typedef struct ssme_pf_config {
     int32_t  device;           /* HIP device ordinal                                         */
     uint32_t first_filter_id;  /* global id of filter 0 of this handle; enters the Philox
                                   counter, so sharding R over GPUs keeps every stream        */
-    int32_t  tile_particles;   /* particles per tile: 2048, 1024 or 512, or 0 = chosen from (N, n_filters):
-                                  2048 for N <= 2048; else 512 while n_filters * ceil(N / 512) <= 256,
-                                  else 1024 while n_filters * ceil(N / 1024) <= 512, else 2048 (a
-                                  mid-size handle then spreads over the chip).
+    int32_t  tile_particles;   /* particles per tile: 2048, 1024 or 512, or 0 = ssme_pf_default_tile(N, bank size), where
+                                  the bank size is n_filters_total if > 0, else n_filters.
                                   Part of the arithmetic specification:
                                   weights are fixed point relative to their tile's maximum and
                                   the resampler draws one Gamma variate per tile */
-    int32_t  reserved;         /* 0 */
+    int32_t  n_filters_total;  /* 0, or the size of the WHOLE bank this handle holds a part of (replicates or swarm
+                                  members dealt to several GPUs, or one handle per member): the default tile is then
+                                  chosen from the bank, so that filter (seed, id, N) gives the same bits however the
+                                  bank is split over handles.  Ignored when tile_particles != 0.             */
 } ssme_pf_config;
 
 /* Allocates device state for R filters of N particles.  Replaces construction of the
  * model object (estimate_univ_svol.h:119), but the handle is reusable across theta. */
 int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out);
 int ssme_pf_destroy(ssme_pf_handle h);
+/* The tile size tile_particles = 0 stands for: 2048 for N <= 2048; else 512 while bank_filters * ceil(N / 512) <= 256
+ * (one workgroup per CU), else 1024 while bank_filters * ceil(N / 1024) <= 512, else 2048 -- a mid-size bank then spreads
+ * over the chip (profiles/r02_tile_sweep.txt).  It reads the BANK, not the handle: callers that split a bank over GPUs or
+ * handles pass n_filters_total (or this value as tile_particles) so that results do not depend on the split. */
+int ssme_pf_default_tile(int32_t n_particles, int32_t bank_filters);
 
 /* UNTRANSFORMED parameters, as the reference's model ctors receive them from
  * pack::get_untrans_params (univ_svol_bootstrap_filter.h:55-61).  theta is

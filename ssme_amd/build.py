@@ -52,7 +52,37 @@ def build(force=False, verbose=False, extra=(), out=None):
     """out: alternative output path (measurement builds, e.g. extra=("-DSSME_ABLATE",))."""
     if out is None and not force and not needs_build():
         return SO
-    cmd = [hipcc()] + FLAGS + list(extra) + SOURCES + ["-o", out or SO]
+    if out is None:
+        # Every rank of a torchrun launch calls lib() -> build(): one of them compiles, the others wait on the lock and then
+        # find the stamp current.  The compiler writes to a temporary file beside the target; the resource checks run on that
+        # build, and only then is the .so replaced (atomically) and the stamp written -- no rank can dlopen a half-written
+        # library or pass needs_build() between the two writes.
+        import fcntl
+        with open(SO + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if not force and not needs_build():
+                    return SO
+                tmp = SO + ".tmp%d" % os.getpid()
+                try:
+                    _compile(extra, tmp, verbose)
+                    os.replace(tmp, SO)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+                if not extra:
+                    with open(STAMP + ".tmp", "w") as f:
+                        f.write(source_hash() + "\n")
+                    os.replace(STAMP + ".tmp", STAMP)
+                return SO
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
+    _compile(extra, out, verbose)
+    return out
+
+
+def _compile(extra, target, verbose):
+    cmd = [hipcc()] + FLAGS + list(extra) + SOURCES + ["-o", target]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -78,10 +108,6 @@ def build(force=False, verbose=False, extra=(), out=None):
         scratch = st.get("ScratchSize [bytes/lane]", 0)
         if scratch != 0 and not (st.get("SGPRs Spill", 0) > 0 and scratch <= 128):
             raise RuntimeError(f"kernel {name} uses scratch memory: {st}")
-    if out is None and not extra:
-        with open(STAMP, "w") as f:
-            f.write(source_hash() + "\n")
-    return out or SO
 
 
 if __name__ == "__main__":

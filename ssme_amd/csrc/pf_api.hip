@@ -218,9 +218,9 @@ static StepArgs step_args(ssme_pf_handle h) {
 // kernel).  Smaller handles get the smallest tile that still leaves every workgroup resident at once, so that mid-size
 // filters spread over the 256 CUs: 512-particle tiles while they make at most 256 workgroups (one filter of 2^16: 128
 // workgroups instead of 32, 10.3 -> 7.4 us per step), 1024-particle tiles while those make at most 512 (one filter of
-// 2^18: 10.7 -> 8.4 us; 2^19: 11.5 -> 10.8 us), 2048 beyond (profiles/r02_tile_sweep.txt).  The rule reads the
-// handle's (N, n_filters): callers that shard filters over GPUs and want results independent of the sharding pass
-// tile_particles explicitly.
+// 2^18: 10.7 -> 8.4 us; 2^19: 11.5 -> 10.8 us), 2048 beyond (profiles/r02_tile_sweep.txt).  The rule reads N and the
+// size of the BANK of filters (ssme_pf_config::n_filters_total, else the handle's n_filters): a bank that is split over
+// GPUs or over one handle per member declares its total, so a filter's bits do not depend on the split.
 static int default_tile(int n_particles, int n_filters) {
     if (n_particles <= kTile) return kTile;
     const long R = n_filters;
@@ -486,7 +486,9 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     if (cfg->dtype != SSME_F64 && cfg->dtype != SSME_F32) return SSME_ERR_INVALID_ARG;
     if (cfg->dtype == SSME_F32 && shard_world > 0) return SSME_ERR_UNSUPPORTED;     // the sharded entry points exchange raw fp64 arrays
     if (cfg->tile_particles != 0 && cfg->tile_particles != kTile && cfg->tile_particles != kTileSmall && cfg->tile_particles != kTileMid) return SSME_ERR_INVALID_ARG;
-    const int tile = shard_world > 0 ? kTile : (cfg->tile_particles ? cfg->tile_particles : default_tile(cfg->n_particles, cfg->n_filters));
+    if (cfg->n_filters_total < 0 || (cfg->n_filters_total > 0 && cfg->n_filters_total < cfg->n_filters)) return SSME_ERR_INVALID_ARG;
+    const int tile = shard_world > 0 ? kTile : (cfg->tile_particles ? cfg->tile_particles
+                                                : default_tile(cfg->n_particles, cfg->n_filters_total > 0 ? cfg->n_filters_total : cfg->n_filters));
     const int B = (cfg->n_particles + tile - 1) / tile;
     if (B > kMaxTilesSplit) return SSME_ERR_UNSUPPORTED;   // at most 16384 tiles per filter (N <= 2^25 with 2048-particle tiles)
     ssme_pf_handle h = new (std::nothrow) ssme_pf_s();
@@ -583,6 +585,7 @@ int ssme_pf_destroy(ssme_pf_handle h) {
 }
 
 int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) { return create_impl(cfg, 0, 0, out); }
+int ssme_pf_default_tile(int32_t n_particles, int32_t bank_filters) { return default_tile(n_particles, bank_filters < 1 ? 1 : bank_filters); }
 
 // ---- particle-sharded filter: one filter of cfg->n_particles particles over `world` GPUs ------------------------------
 //   This handle owns rank `rank`'s share: B/world consecutive tiles.  Particle buffers

@@ -986,11 +986,22 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             // what kf_finalize does in a second launch -- level-2 of the weights just written, log p(y_t | y_{1:t-1}) --
             // so that a filter() call is ONE launch.  Only the tile sums / maxima cross workgroups: they are written and read
             // with device-scope accesses and ordered by the counter, so no cache write-back of the particle arrays is needed.
+            // Ordering.  The formally ordered form -- an ACQ_REL read-modify-write of the counter at agent scope -- was measured
+            // (round 3, tools/step_latency.cpp): the release half is a write-back of the XCD's whole L2 (buffer_wbl2 sc1) and the
+            // acquire half an invalidate (buffer_inv sc1), i.e. the cache write-back of the particle arrays this design exists
+            // to avoid: filter() 27.8 -> 40.0 us at N = 2^20, 41 -> 55 us for 64 filters x 2^14 (profiles/r03_step_api_handover.txt).
+            // Kept instead: agent-scope RELAXED atomic stores of the two values (global_store_dwordx2 ... sc1: written through
+            // to the memory side, past the non-coherent L2), a workgroup-scope release fence = s_waitcnt vmcnt(0) (the stores
+            // have been acknowledged before the next instruction issues), then the agent-scope relaxed atomic add (executed at
+            // the memory side); the last arriver reads with agent-scope atomic loads (global_load_dwordx2 ... sc1: not served
+            // from its own L2).  The C++ memory model gives relaxed atomics on different addresses no inter-thread order, so
+            // this leans on gfx950's in-order issue + completion wait; the instruction sequence that carries it is recorded in
+            // profiles/r03_step_api_handover.txt, and tests/test_parity_gpu.py / the soak compare every such step with the oracle.
             __shared__ int lds_last;
             if (tid == 0) {
                 int last = 1;
                 if (gridDim.x > 1) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the two stores above have completed
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt vmcnt(0): the two stores above have completed
                     last = __hip_atomic_fetch_add(a.ticket + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
                 }
                 lds_last = last;
@@ -1021,7 +1032,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                     sc->loglik = sc->loglik + ll;
                     sc->prev = resample_now ? a.logN : lse;
                     if (a.per_step) a.per_step[(size_t)r * a.Tcap + a.t] = ll;
-                    if (gridDim.x > 1) a.ticket[r] = 0;
+                    if (gridDim.x > 1) __hip_atomic_store(a.ticket + r, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch (kernel boundary orders it)
                     if (a.ll_host) a.ll_host[r] = ll;
                 }
             }

@@ -16,10 +16,15 @@ from . import _capi as capi
 from ._capi import (MODEL_LIN_GAUSS, MODEL_SVOL, MODEL_SVOL_LEVERAGE, RESAMP_MULTINOMIAL, RESAMP_MULTINOMIAL_IID,
                     RESAMP_STRATIFIED, RESAMP_SYSTEMATIC, SsmeError)
 
-__all__ = ["ParticleFilterBank", "svol_bs", "svol_leverage", "lin_gauss_bs", "log_like_eval", "svol_lw_1_par", "svol_lw_2_par", "SwarmWithCovs", "Swarm", "svol_swarm_1",
+__all__ = ["default_tile", "ParticleFilterBank", "svol_bs", "svol_leverage", "lin_gauss_bs", "log_like_eval", "svol_lw_1_par", "svol_lw_2_par", "SwarmWithCovs", "Swarm", "svol_swarm_1",
            "TR_NULL", "TR_TWICE_FISHER", "TR_LOGIT", "TR_LOG",
            "MODEL_SVOL", "MODEL_SVOL_LEVERAGE", "MODEL_LIN_GAUSS", "RESAMP_MULTINOMIAL", "RESAMP_SYSTEMATIC",
            "RESAMP_STRATIFIED", "RESAMP_MULTINOMIAL_IID", "SsmeError"]
+
+
+def default_tile(n_particles, bank_filters=1):
+    """The tile size tile = 0 stands for (ssme_pf_default_tile): a function of N and the size of the whole bank of filters."""
+    return int(capi.lib().ssme_pf_default_tile(int(n_particles), int(bank_filters)))
 
 
 class ParticleFilterBank:
@@ -30,15 +35,17 @@ class ParticleFilterBank:
     """
 
     def __init__(self, model, n_particles, n_filters=1, seed=0, resampler=RESAMP_MULTINOMIAL, resamp_sched=1,
-                 device=0, first_filter_id=0, tile=0, dtype=capi.F64):
-        """tile: particles per tile, 0 = chosen from (N, n_filters), or 2048 / 1024 / 512.
+                 device=0, first_filter_id=0, tile=0, dtype=capi.F64, n_filters_total=0):
+        """tile: particles per tile, 0 = chosen from (N, bank size), or 2048 / 1024 / 512.
+        n_filters_total: size of the whole bank when this handle holds only a part of it (filters dealt to several GPUs
+        or handles): the default tile then follows the bank, and a filter's results do not depend on the split.
         dtype: F64, or F32 = float at the boundary (inputs and outputs rounded to float, fp64 arithmetic; ssme_pf.h)."""
         self._h = C.c_void_p()
         self.model, self.n, self.r = int(model), int(n_particles), int(n_filters)
         self._last_T = 0
         cfg = capi.Config(model=model, n_particles=n_particles, n_filters=n_filters, dtype=dtype,
                           resampler=resampler, resamp_sched=resamp_sched, seed=seed, device=device,
-                          first_filter_id=first_filter_id, tile_particles=tile, reserved=0)
+                          first_filter_id=first_filter_id, tile_particles=tile, n_filters_total=n_filters_total)
         capi.check(capi.lib().ssme_pf_create(C.byref(cfg), C.byref(self._h)))
         t, b = C.c_int32(), C.c_int32()
         capi.check(capi.lib().ssme_pf_get_layout(self._h, C.byref(t), C.byref(b)))

@@ -20,6 +20,18 @@ def shard_filters(n_filters, world, rank):
     return first, count
 
 
+def sharded_bank(model, n_particles, n_filters, world, rank, seed=0, device=0, **kw):
+    """This rank's part of a bank of n_filters independent filters: filter ids and Philox streams are the global ones and
+    the tile size (part of the arithmetic specification) is chosen from the WHOLE bank (ssme_pf_config::n_filters_total), so
+    filter r gives the same bits on 1, 2, 4 or 8 GPUs.  Returns (bank or None when this rank holds no filter, first id, count)."""
+    from .filters import ParticleFilterBank
+    first, count = shard_filters(n_filters, world, rank)
+    if count == 0:
+        return None, first, 0
+    return ParticleFilterBank(model, n_particles, count, seed=seed, device=device, first_filter_id=first,
+                              n_filters_total=n_filters, **kw), first, count
+
+
 def log_mean_exp(v):
     """thread_pool.h:263-268: m + log(sum exp(v - m)) - log(n)."""
     v = np.asarray(v, dtype=np.float64)

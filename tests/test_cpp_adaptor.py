@@ -13,7 +13,7 @@ EXE = os.path.join(ROOT, "tests", "cpp", "test_adaptor")
 def _build():
     from ssme_amd import build
     so = build.build()
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", os.path.join(ROOT, "tests", "cpp", "test_adaptor.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_adaptor.cpp"),
                            "-o", EXE, so, "-Wl,-rpath," + os.path.dirname(so)])
     return EXE
 
@@ -97,6 +97,23 @@ def test_adaptor_matches_oracle(oracle, spy):
     mus = [-0.1 + 0.2 * (0.1 + 0.2 * k) for k in range(5)]
     assert abs(float(vals["uswarmmux"]) - (float(vals["swarmx"]) + sum(mus) / 5)) < 1e-9        # E[mu_i + x] per member
     assert abs(float(vals["uswarm_nocov"]) - float(vals["swarm_nocov"])) < 1e-12
+    # (10b) the same swarms with their members in ONE handle behind the unmodified templates (swarm_context): one launch per
+    # update, the numbers of the one-handle-per-member path -- log-likelihoods and device functionals to the bit, the
+    # host-summed functional (uses the member's parameters) likewise (same particles, same weights, same host loop)
+    for k in ("", "42", "x", "mux"):
+        assert float(vals["cswarm" + k]) == float(vals["uswarm" + k]), k
+    assert float(vals["cswarm_nocov"]) == float(vals["uswarm_nocov"]) and float(vals["cswarm_nocov_x"]) == float(vals["uswarm_nocov_x"])
+    assert vals["late_member"].strip() == "rejected" and vals["mismatch"].strip() == "rejected"
+    # (10c) members driven from three concurrent threads, as split_data_thread_pool does
+    assert abs(float(vals["tswarm"]) - float(vals["uswarm"])) < 1e-12 and abs(float(vals["tswarmx"]) - float(vals["uswarmx"])) < 1e-12
+    # functionals are summed on the host unless DECLARED (or the opt-in probe classifies them): the default must be right
+    # for functions the fixed probe points cannot tell from a built-in
+    assert abs(float(vals["hostdefault_42"]) - 42.0) < 1e-9
+    assert abs(float(vals["hostdefault_x"]) - float(vals["expectx"])) <= 1e-12 * abs(float(vals["expectx"]))
+    assert abs(float(vals["probe_x"]) - float(vals["expectx"])) <= 1e-12 * abs(float(vals["expectx"]))
+    tail = ((so["x"] < -3.0) * wo).sum() / wo.sum()
+    assert tail > 0 and abs(float(vals["tail_host"]) - tail) < 1e-12
+    assert float(vals["tail_probe"]) == 0.0               # what the probe makes of it: "constant 0" -- hence opt-in only
     n, first = vals["read_data"].split()
     assert int(n) == spy.size and float(first) == spy[0]
 

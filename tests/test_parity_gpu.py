@@ -264,6 +264,36 @@ def test_default_tile_rule_matches_the_oracle(sa, oracle):
     assert seen == {512, 1024, 2048}
 
 
+def test_a_filter_does_not_depend_on_how_its_bank_is_split(sa, oracle, spy):
+    """the default tile follows (N, bank size), and the tile is part of the arithmetic -- so a bank that
+    is split over GPUs / handles must declare its size (ssme_pf_config::n_filters_total, parallel.sharded_bank).  32 filters
+    of 2^14 particles: alone the default tile is 1024; a handle holding 8 of them would pick 512 by itself.  Filter 13 gives
+    the same bits in the whole bank, in every split that declares the bank, and in the oracle with the bank's tile."""
+    from ssme_amd import parallel
+    n, R, seed, T, th = 16384, 32, 5, 12, [1.0, 0.95, 0.25]
+    y = spy[:T]
+    tile = oracle.default_tile(n, R)
+    assert tile == sa.default_tile(n, R) == 1024 and sa.default_tile(n, 8) == 512
+    whole = sa.ParticleFilterBank(sa.MODEL_SVOL, n, R, seed)
+    whole.set_params(th)
+    ll = whole.run_series(y)
+    assert whole.tile == tile
+    whole.close()
+    assert ll[13] == oracle.Filter(oracle.MODEL_SVOL, n, th, seed, rep=13, tile=tile).run_series(y)[0]
+    for world in (2, 4, 8, 32):
+        parts = []
+        for rank in range(world):
+            bank, first, cnt = parallel.sharded_bank(sa.MODEL_SVOL, n, R, world, rank, seed=seed)
+            assert bank.tile == tile, (world, rank)
+            bank.set_params(th)
+            parts.append(bank.run_series(y))
+            bank.close()
+        assert_bits_equal(np.concatenate(parts), ll, f"bank split over {world} handles")
+    alone = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, seed, first_filter_id=13)      # undeclared: another tile, other bits
+    assert alone.tile == 512
+    alone.close()
+
+
 def test_split_level2_with_1024_particle_tiles(sa, oracle, spy):
     """More than 2048 tiles of 1024 particles: the level-2 plan kernel path of the middle tile size."""
     n, th = 2100000, [1.0, 0.95, 0.25]
