@@ -991,17 +991,20 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             // acquire half an invalidate (buffer_inv sc1), i.e. the cache write-back of the particle arrays this design exists
             // to avoid: filter() 27.8 -> 40.0 us at N = 2^20, 41 -> 55 us for 64 filters x 2^14 (profiles/r03_step_api_handover.txt).
             // Kept instead: agent-scope RELAXED atomic stores of the two values (global_store_dwordx2 ... sc1: written through
-            // to the memory side, past the non-coherent L2), a workgroup-scope release fence = s_waitcnt vmcnt(0) (the stores
-            // have been acknowledged before the next instruction issues), then the agent-scope relaxed atomic add (executed at
-            // the memory side); the last arriver reads with agent-scope atomic loads (global_load_dwordx2 ... sc1: not served
-            // from its own L2).  The C++ memory model gives relaxed atomics on different addresses no inter-thread order, so
-            // this leans on gfx950's in-order issue + completion wait; the instruction sequence that carries it is recorded in
-            // profiles/r03_step_api_handover.txt, and tests/test_parity_gpu.py / the soak compare every such step with the oracle.
+            // to the memory side, past the non-coherent L2), an explicit s_waitcnt vmcnt(0) (both stores acknowledged before
+            // the next instruction issues -- the compiler's workgroup-scope release fence emits NO wait outside tgsplit mode,
+            // so round 2's form left the two stores and the counter's atomic free to reach their different L2 channels in any
+            // order; seen in the ISA this round, profiles/r03_step_api_handover.txt), then the agent-scope relaxed atomic add;
+            // the last arriver reads with agent-scope atomic loads (global_load_dwordx2 ... sc1: not served from its own L2),
+            // issued only after the atomic's return value has arrived.  The C++ memory model gives relaxed atomics on different
+            // addresses no inter-thread order; this form leans on the completion wait instead of a scope-wide fence.  Cost: one
+            // thread per workgroup waits for two store acknowledgements at the end of the kernel (measured: none,
+            // profiles/r03_step_api_handover.txt).
             __shared__ int lds_last;
             if (tid == 0) {
                 int last = 1;
                 if (gridDim.x > 1) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt vmcnt(0): the two stores above have completed
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the two stores above have been acknowledged
                     last = __hip_atomic_fetch_add(a.ticket + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
                 }
                 lds_last = last;
