@@ -192,7 +192,7 @@ int ssme_pf_profile_series(ssme_pf_handle h, const double* y, const double* z, i
                            double* mean_us_out /*1*/, int32_t* launches_out /*1*/);
 
 /* Device-side primitives exposed for bit-parity tests against the oracle. */
-int ssme_pf_test_math(int32_t device, int32_t fn /*0 exp,1 log,2 sin2pi,3 cos2pi,4 sqrt,5 log (normal-only core),6 log of a uniform (table),7 exp (table form of the bootstrap filter)*/,
+int ssme_pf_test_math(int32_t device, int32_t fn /*0 exp,1 log,2 sin2pi,3 cos2pi,4 sqrt,5 log (normal-only core),6 log of a uniform (table),7 exp (table form of the bootstrap filter),8 / 9 sin / cos of 2 pi k / 2^24 (in = k),10 log of a spacing uniform,11 sqrt of a positive normal*/,
                       const double* in, double* out, int64_t n);
 int ssme_pf_test_philox(int32_t device, const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4);
 /* q = rne(exp(in) * 2^shift) as uint64, n values */

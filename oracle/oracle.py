@@ -60,9 +60,10 @@ def lib():
         L = C.CDLL(_SO)
         dp, u32p = C.POINTER(C.c_double), C.POINTER(C.c_uint32)
         L.orc_philox4x32_10.argtypes = [u32p, u32p, u32p]
-        for f in (L.orc_exp, L.orc_log, L.orc_log_u, L.orc_exp_t):
+        for f in (L.orc_exp, L.orc_log, L.orc_log_u, L.orc_log_u32, L.orc_exp_t):
             f.argtypes = [dp, dp, C.c_long]
         L.orc_sincos2pi.argtypes = [dp, dp, dp, C.c_long]
+        L.orc_sincos_k24.argtypes = [dp, dp, dp, C.c_long]
         L.orc_normals.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, dp]
         u64p = C.POINTER(C.c_uint64)
         L.orc_exp_scaled.argtypes = [dp, C.c_int, dp, C.c_long]
@@ -151,6 +152,19 @@ def exp_t(x):
 def log_u(x):
     """The table-based logarithm of the bootstrap filter's uniform draws (absolute error < 2^-51)."""
     return _map1(lib().orc_log_u, x)
+
+
+def log_u32(x):
+    """The logarithm behind the exponential spacings (32-bit uniforms, result quantised to 2^-35: absolute error < 2^-43)."""
+    return _map1(lib().orc_log_u32, x)
+
+
+def sincos_k24(k):
+    """sin, cos of 2 pi k / 2^24 for integer k in [0, 2^24): the table-driven Box-Muller angle of the hot loops."""
+    k = np.ascontiguousarray(k, dtype=np.float64)
+    s, c = np.empty_like(k), np.empty_like(k)
+    lib().orc_sincos_k24(_dp(k), _dp(s), _dp(c), k.size)
+    return s, c
 
 
 def sincos2pi(u):

@@ -176,6 +176,43 @@ double o_log_u(double x) {
     const double dk = (double)k;
     return std::fma(dk, LN2_HI, e.l) + std::fma(dk, LN2_LO, p);
 }
+// log of a 32-bit uniform for the exponential spacings, which are quantised to 2^-35 as they are formed: series to r^5, one fma
+// for k ln2 (mirror of ssme_math.h: dlog_u32; absolute error < 2^-43)
+double o_log_u32(double x) {
+    const double LN2 = 6.93147180559945286227e-01;
+    const uint64_t ux = double_to_bits(x);
+    const uint32_t hx = (uint32_t)(ux >> 32);
+    const int k = (int)(hx >> 20) - 1023;
+    const LogTabEntry e = LOG_TABLE[(hx >> 14) & 63u];
+    const double m = bits_to_double((ux & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    const double r = std::fma(m, e.c, -1.0);
+    double q = std::fma(r, 2.0000000000000001e-01, -2.5000000000000000e-01);
+    q = std::fma(q, r, 3.3333333333333331e-01);
+    q = std::fma(q, r, -5.0000000000000000e-01);
+    const double p = std::fma(r * r, q, r);
+    return std::fma((double)k, LN2, e.l + p);
+}
+// sin, cos of 2 pi k / 2^24 for the 24-bit Box-Muller angle (mirror of ssme_math.h: dsincos_k24): nearest of 64 table angles,
+// sin / cos - 1 of the remainder by short series, rotation
+struct SinCosEntry { double s, c; };
+static const SinCosEntry SINCOS_TABLE[SSME_SINCOS_TABLE_SIZE] = {SSME_SINCOS_TABLE_ROWS};
+void o_sincos_k24(uint32_t k, double* sn, double* cs) {
+    const double STEP = 3.74507028292392863750e-07;
+    const uint32_t kr = (k & 0x00ffffffu) + 0x20000u;
+    const SinCosEntry e = SINCOS_TABLE[(kr >> 18) & 63u];
+    const int d = (int)(kr & 0x3ffffu) - 0x20000;
+    const double dl = (double)d * STEP;
+    const double z = dl * dl;
+    double sp = std::fma(z, -1.9841269841269841e-04, 8.3333333333333332e-03);
+    sp = std::fma(sp, z, -1.6666666666666666e-01);
+    const double sd = std::fma(dl, sp * z, dl);
+    double cp = std::fma(z, 2.4801587301587302e-05, -1.3888888888888889e-03);
+    cp = std::fma(cp, z, 4.1666666666666664e-02);
+    cp = std::fma(cp, z, -5.0000000000000000e-01);
+    const double cm = cp * z;
+    *sn = e.s + std::fma(e.c, sd, e.s * cm);
+    *cs = e.c + std::fma(-e.s, sd, e.c * cm);
+}
 // The bootstrap filter's exp (mirror of ssme_math.h: dexp_scaled_t): 64-entry double-double table of 2^(j/64) + degree-6 series
 struct ExpTabEntry { double hi, lo; };
 static const ExpTabEntry EXP_TABLE[SSME_EXP_TABLE_SIZE] = {SSME_EXP_TABLE_ROWS};
@@ -409,7 +446,7 @@ struct Filter {
         uint32_t o[4]; philox4x32_10(ctr, key, o);
         if (bootstrap_draws) {
             const double rad = std::sqrt(-2.0 * o_log_u(u01_mid40(o[0], o[1])));
-            double sn, cs; o_sincos2pi(u01_lo24(o[1]), &sn, &cs);
+            double sn, cs; o_sincos_k24(o[1], &sn, &cs);
             return (i & 1) ? rad * sn : rad * cs;
         }
         const double u1 = u01_oc(o[0], o[1]), u2 = u01_co(o[2], o[3]);
@@ -422,7 +459,7 @@ struct Filter {
         if (bootstrap_draws) {
             const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, (uint32_t)pair_stream};
             uint32_t o[4]; philox4x32_10(ctr, key, o);
-            return -o_log_u(u01_mid32(o[2 + (i & 1)]));
+            return -o_log_u32(u01_mid32(o[2 + (i & 1)]));
         }
         uint32_t wa, wb; resamp_words(i, tt, &wa, &wb, stream);
         return -o_log(u01_oc(wa, wb));
@@ -812,7 +849,7 @@ struct LWFilter {
         uint32_t o[4]; words(i, tt, STREAM_LW_JIT, o);
         for (int h = 0; h < 2; ++h) {
             const double rad = std::sqrt(-2.0 * o_log_u(u01_mid40(o[2 * h], o[2 * h + 1])));
-            double sn, cs; o_sincos2pi(u01_lo24(o[2 * h + 1]), &sn, &cs);
+            double sn, cs; o_sincos_k24(o[2 * h + 1], &sn, &cs);
             e[2 * h] = rad * cs; e[2 * h + 1] = rad * sn;
         }
     }
@@ -1094,6 +1131,8 @@ void orc_normals(uint64_t seed, uint32_t rep, int t, int n, double* out) {
     for (int i = 0; i < n; ++i) out[i] = f.normal(i, t);
 }
 void orc_log_u(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_log_u(x[i]); }
+void orc_log_u32(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_log_u32(x[i]); }
+void orc_sincos_k24(const double* k, double* s, double* c, long n) { for (long i = 0; i < n; ++i) o_sincos_k24((uint32_t)k[i], s + i, c + i); }
 void orc_exp_t(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_exp_t(x[i]); }
 void orc_exp_scaled_t(const double* x, int sc, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_exp_scaled_t(x[i], sc); }
 void orc_exp_scaled(const double* x, int sc, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = o_exp_scaled(x[i], sc); }

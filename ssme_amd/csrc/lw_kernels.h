@@ -356,14 +356,14 @@ __device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int N, in
     __shared__ double lds_d1[16];                                                                         \
     __shared__ double lds_d2[16];                                                                         \
     __shared__ int lds_cnt[2];                                                                            \
-    __shared__ LogTabEntry lds_ltab[SSME_LOG_TABLE_SIZE];                                                 \
+    __shared__ __attribute__((aligned(16))) DrawTabs lds_dtab;                                                 \
     __shared__ ExpTabEntry lds_etab[SSME_EXP_TABLE_SIZE];                                                 \
-    load_log_table<kLwNT>(lds_ltab);                                                                      \
+    load_log_table<kLwNT>(&lds_dtab);                                                                      \
     load_exp_table<kLwNT>(lds_etab);                                                                      \
     LwLds L;                                                                                              \
     L.lds_T = reinterpret_cast<double*>(smem); L.lds_R = L.lds_T + nT2; L.lds_stage = L.lds_T + 2 * nT2;  \
     L.seg_a = lds_seg_a; L.seg_l2 = lds_seg_l2; L.d1 = lds_d1; L.cnt = lds_cnt;                           \
-    L.ltab = lds_ltab; L.etab = lds_etab;                                                                 \
+    L.ltab = lds_dtab.log; L.etab = lds_etab;                                                                 \
     __syncthreads();
 
 // ---------------------------------------------------------------------------------------
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
     for (int k = 0; k < NK; ++k) {
         const int i0 = i_first + (k * NT + tid) * 2;
         double zs[2];
-        pair_normals(draw[k].v0, draw[k].v1, lds_ltab, &zs[0], &zs[1]);
+        pair_normals(draw[k].v0, draw[k].v1, &lds_dtab, &zs[0], &zs[1]);
         double xo[2], tho[kDP][2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -763,8 +763,8 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
             {
                 // the four jitter normals of a particle from ONE call: two Box-Muller pairs, (words 0-1) and (words 2-3)
                 const u32x4 o1 = philox4x32_10((uint32_t)i, (uint32_t)a.t, rep, STREAM_LW_JIT, a.key0, a.key1);
-                pair_normals(o1.v0, o1.v1, lds_ltab, &e[0], &e[1]);
-                pair_normals(o1.v2, o1.v3, lds_ltab, &e[2], &e[3]);
+                pair_normals(o1.v0, o1.v1, &lds_dtab, &e[0], &e[1]);
+                pair_normals(o1.v2, o1.v3, &lds_dtab, &e[2], &e[3]);
             }
             double tu[kDP], thrk[kDP];
             th_load(a.thr, rowoff + (size_t)(j - win0), thrk);

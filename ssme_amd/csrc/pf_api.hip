@@ -1347,6 +1347,10 @@ __global__ void k_test_math(int fn, const double* in, double* out, long n) {
         case 4: r = dsqrt(x); break;
         case 6: r = dlog_u(x, kLogTable); break;
         case 7: r = dexp_scaled_t(x, 0, kExpTable); break;
+        case 8: dsincos_k24((uint32_t)x, kSinCosTable, &s, &c); r = s; break;
+        case 9: dsincos_k24((uint32_t)x, kSinCosTable, &s, &c); r = c; break;
+        case 10: r = dlog_u32(x, kLogTable); break;
+        case 11: r = dsqrt_pn(x); break;
         default: r = dlog_pn(x); break;
     }
     out[i] = r;

@@ -307,23 +307,30 @@ __device__ __forceinline__ u32x4 pair_words(uint32_t pair, uint32_t t, uint32_t 
     return philox4x32_10(pair, t, rep, STREAM_PROP, k0, k1);
 }
 __device__ __forceinline__ void pair_spacings(const u32x4& o, const LogTabEntry* tab, double* e0, double* e1) {
-    *e0 = -dlog_u(u01_mid32(o.v2), tab);
-    *e1 = -dlog_u(u01_mid32(o.v3), tab);
+    *e0 = -dlog_u32(u01_mid32(o.v2), tab);
+    *e1 = -dlog_u32(u01_mid32(o.v3), tab);
 }
-__device__ __forceinline__ void pair_normals(uint32_t w0, uint32_t w1, const LogTabEntry* tab, double* z0, double* z1) {
-    const double rad = dsqrt(-2.0 * dlog_u(u01_mid40(w0, w1), tab));
+// the draw tables of a hot kernel in LDS: dlog_u / dlog_u32 and dsincos_k24 (2 KiB)
+struct DrawTabs {
+    LogTabEntry log[SSME_LOG_TABLE_SIZE];
+    SinCosEntry sc[SSME_SINCOS_TABLE_SIZE];
+};
+__device__ __forceinline__ void pair_normals(uint32_t w0, uint32_t w1, const DrawTabs* tab, double* z0, double* z1) {
+    const double rad = dsqrt_pn(-2.0 * dlog_u(u01_mid40(w0, w1), tab->log));
     double sn, cs;
-    dsincos2pi(u01_lo24(w1), &sn, &cs);
+    dsincos_k24(w1, tab->sc, &sn, &cs);
     *z0 = rad * cs;
     *z1 = rad * sn;
 }
-// the tables of dlog_u and dexp_scaled_t, in device memory; every workgroup of the hot kernels copies them into LDS
-// (128 x 16 + 256 x 16 bytes) before its first use
+// the tables of dlog_u, dsincos_k24 and dexp_scaled_t, in device memory; every workgroup of the hot kernels copies them
+// into LDS (3 x 64 x 16 bytes) before its first use
 static __device__ const LogTabEntry kLogTable[SSME_LOG_TABLE_SIZE] = {SSME_LOG_TABLE_ROWS};
+static __device__ const SinCosEntry kSinCosTable[SSME_SINCOS_TABLE_SIZE] = {SSME_SINCOS_TABLE_ROWS};
 static __device__ const ExpTabEntry kExpTable[SSME_EXP_TABLE_SIZE] = {SSME_EXP_TABLE_ROWS};
 template <int NT>
-__device__ __forceinline__ void load_log_table(LogTabEntry* lds_tab) {
-    for (int i = threadIdx.x; i < SSME_LOG_TABLE_SIZE; i += NT) lds_tab[i] = kLogTable[i];
+__device__ __forceinline__ void load_log_table(DrawTabs* lds_tab) {
+    static_assert(SSME_LOG_TABLE_SIZE == SSME_SINCOS_TABLE_SIZE, "one pass fills both");
+    for (int i = threadIdx.x; i < SSME_LOG_TABLE_SIZE; i += NT) { lds_tab->log[i] = kLogTable[i]; lds_tab->sc[i] = kSinCosTable[i]; }
 }
 template <int NT>
 __device__ __forceinline__ void load_exp_table(ExpTabEntry* lds_tab) {
@@ -525,11 +532,11 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     __shared__ double lds_R3[4];         // A_b / A'_b of the staged tiles
     __shared__ double lds_d1[16];
     __shared__ double lds_d2[16];
-    __shared__ __attribute__((aligned(16))) LogTabEntry lds_ltab[SSME_LOG_TABLE_SIZE];
+    __shared__ __attribute__((aligned(16))) DrawTabs lds_dtab;
     __shared__ __attribute__((aligned(16))) ExpTabEntry lds_etab[SSME_EXP_TABLE_SIZE];
 
     const int tid = threadIdx.x;
-    load_log_table<NT>(lds_ltab);        // visible after the first barrier below (every path has one before its first draw)
+    load_log_table<NT>(&lds_dtab);        // visible after the first barrier below (every path has one before its first draw)
     load_exp_table<NT>(lds_etab);        // first used behind level2_scan's first barrier (block max)
     // (filter, tile) of this workgroup: the launch's tiles in filter-major order, a contiguous range per XCD
     const int gtile = xcd_tile_of_block((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
@@ -758,7 +765,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             const int i0 = i_first + (k * NT + tid) * 2;
             double e0, e1;
             if (ABL(a, 1)) { e0 = 1.0 + 1e-6 * (double)(i0 & 1023); e1 = 1.0; }
-            else pair_spacings(o, lds_ltab, &e0, &e1);
+            else pair_spacings(o, lds_dtab.log, &e0, &e1);
             le[k][0] = (i0 < a.N) ? __builtin_rint(e0 * 34359738368.0 /* 2^35 */) : 0.0;
             le[k][1] = (i0 + 1 < a.N) ? __builtin_rint(e1 * 34359738368.0) : 0.0;
         }
@@ -913,7 +920,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         if (ABL(a, 0)) { zn[k][0] = 0.25 + 1e-9 * (double)nw0[k]; zn[k][1] = -0.25; }
-        else pair_normals(nw0[k], nw1[k], lds_ltab, &zn[k][0], &zn[k][1]);
+        else pair_normals(nw0[k], nw1[k], &lds_dtab, &zn[k][0], &zn[k][1]);
     }
     STAMP(a, 7);
     PRIO_AT(7);

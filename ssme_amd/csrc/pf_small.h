@@ -87,11 +87,11 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
     __shared__ double lds_seg_a[16];
     __shared__ double lds_seg_c[16];
     __shared__ double lds_d2[16];
-    __shared__ __attribute__((aligned(16))) LogTabEntry lds_ltab[SSME_LOG_TABLE_SIZE];
+    __shared__ __attribute__((aligned(16))) DrawTabs lds_dtab;
     __shared__ __attribute__((aligned(16))) ExpTabEntry lds_etab[SSME_EXP_TABLE_SIZE];
 
     const int tid = threadIdx.x;
-    load_log_table<NT>(lds_ltab);
+    load_log_table<NT>(&lds_dtab);
     load_exp_table<NT>(lds_etab);
     __syncthreads();
     const int r = blockIdx.x;
@@ -148,12 +148,12 @@ __global__ __launch_bounds__(NT) void k_filter_series_small(const StepArgs a, co
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
                 const u32x4 o = pair_words((uint32_t)(k * NT + tid), (uint32_t)t, rep, key0, key1);
-                pair_normals(o.v0, o.v1, lds_ltab, &zn[k][0], &zn[k][1]);
+                pair_normals(o.v0, o.v1, &lds_dtab, &zn[k][0], &zn[k][1]);
                 qe[k][0] = 0.0; qe[k][1] = 0.0;
                 if (multinomial) {
                     const int i0 = (k * NT + tid) * 2;
                     double e0, e1;
-                    pair_spacings(o, lds_ltab, &e0, &e1);
+                    pair_spacings(o, lds_dtab.log, &e0, &e1);
                     qe[k][0] = (i0 < a.N) ? __builtin_rint(e0 * 34359738368.0 /* 2^35 */) : 0.0;
                     qe[k][1] = (i0 + 1 < a.N) ? __builtin_rint(e1 * 34359738368.0) : 0.0;
                 }
@@ -338,11 +338,11 @@ __global__ __launch_bounds__(NT) void k_filter_series_lane(const StepArgs a, con
     __shared__ double lds_seg_a[16];
     __shared__ double lds_seg_c[16];
     __shared__ double lds_d2[16];
-    __shared__ __attribute__((aligned(16))) LogTabEntry lds_ltab[SSME_LOG_TABLE_SIZE];
+    __shared__ __attribute__((aligned(16))) DrawTabs lds_dtab;
     __shared__ __attribute__((aligned(16))) ExpTabEntry lds_etab[SSME_EXP_TABLE_SIZE];
 
     const int tid = threadIdx.x;
-    load_log_table<NT>(lds_ltab);
+    load_log_table<NT>(&lds_dtab);
     load_exp_table<NT>(lds_etab);
     __syncthreads();
     const int r = blockIdx.x;
@@ -391,10 +391,10 @@ __global__ __launch_bounds__(NT) void k_filter_series_lane(const StepArgs a, con
         {
             const u32x4 o = pair_words((uint32_t)(tid >> 1), (uint32_t)t, rep, key0, key1);
             double z0, z1;
-            pair_normals(o.v0, o.v1, lds_ltab, &z0, &z1);
+            pair_normals(o.v0, o.v1, &lds_dtab, &z0, &z1);
             zn = c ? z1 : z0;
             if (multinomial) {
-                const double e = -dlog_u(u01_mid32(c ? o.v3 : o.v2), lds_ltab);
+                const double e = -dlog_u32(u01_mid32(c ? o.v3 : o.v2), lds_dtab.log);
                 const double qe = valid ? __builtin_rint(e * 34359738368.0 /* 2^35 */) : 0.0;
                 block_scan1_f64<NT>(qe, le, se, lds_seg_a);
             }

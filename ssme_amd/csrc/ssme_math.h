@@ -204,6 +204,24 @@ SSME_HD double dlog_u(double x, const LogTabEntry* tab) {
     const double dk = (double)k;
     return dfma(dk, LN2_HI, e.l) + dfma(dk, LN2_LO, p);
 }
+// The same for the EXPONENTIAL SPACINGS of the multinomial resampler (round 3): E = -log(u) is quantised to 2^-35 the moment it
+// is formed (qE = rne(E 2^35)), so the series stops at r^5 (truncation |r|^6 / 6 < 2^-44) and k ln2 is one
+// fma on the rounded constant: absolute error < 2^-43, three fp64 instructions less per spacing.  Not for the Box-Muller
+// radius (dlog_u above keeps its 2^-51).
+SSME_HD double dlog_u32(double x, const LogTabEntry* tab) {
+    const double LN2 = 6.93147180559945286227e-01;
+    const uint64_t ux = d2bits(x);
+    const uint32_t hx = (uint32_t)(ux >> 32);
+    const int k = (int)(hx >> 20) - 1023;
+    const LogTabEntry e = tab[(hx >> 14) & 63u];
+    const double m = bits2d((ux & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    const double r = dfma(m, e.c, -1.0);
+    double q = dfma_c(r, 2.0000000000000001e-01, -2.5000000000000000e-01);
+    q = dfma_c(q, r, 3.3333333333333331e-01);
+    q = dfma_c(q, r, -5.0000000000000000e-01);
+    const double p = dfma(r * r, q, r);
+    return dfma((double)k, LN2, e.l + p);
+}
 // uniforms strictly inside (0,1): midpoints of a 2^-40 / 2^-32 grid, and [0,1) on a 2^-24 grid (Box-Muller angle)
 SSME_HD double u01_mid40(uint32_t a, uint32_t b) {          // a: 32 bits, top 8 bits of b
     const uint64_t man = ((uint64_t)a << 20) | ((uint64_t)(b >> 24) << 12) | 0x800ull;
@@ -250,6 +268,49 @@ SSME_HD void dsincos2pi(double u, double* sn, double* cs) {
     *cs = ((qq + 1) & 2) ? -cc : cc;
 }
 
+// ---- sin, cos of 2 pi k / 2^24 for the 24-bit Box-Muller angle of the hot loops (round 3) -------------------------------
+// k = i 2^18 + d with the NEAREST table angle i (64 entries {sin, cos}(2 pi i / 64), nearest doubles) and a signed remainder
+// |d| <= 2^17, i.e. |delta| = 2 pi |d| / 2^24 <= 0.0491: sin(delta) to delta^7 and cos(delta) - 1 to delta^8 (truncation
+// < 5e-18), then the rotation with the small terms added last.  Absolute error < 3e-16 (2 ulp of 1); 21 instructions and
+// one 16-byte table read against 45 for the octant-reduction form (dsincos2pi, which the Gamma draws and t = 0 kernels keep).
+struct SinCosEntry { double s, c; };
+SSME_HD void dsincos_k24(uint32_t k, const SinCosEntry* tab, double* sn, double* cs) {
+    const double STEP = 3.74507028292392863750e-07;           // 2 pi / 2^24, nearest double
+    const uint32_t kr = (k & 0x00ffffffu) + 0x20000u;      // + half a table step
+    const SinCosEntry e = tab[(kr >> 18) & 63u];
+    const int d = (int)(kr & 0x3ffffu) - 0x20000;          // [-2^17, 2^17)
+    const double dl = (double)d * STEP;
+    const double z = dl * dl;
+    double sp = dfma_c(z, -1.9841269841269841e-04, 8.3333333333333332e-03);
+    sp = dfma_c(sp, z, -1.6666666666666666e-01);
+    const double sd = dfma(dl, sp * z, dl);                // sin(delta)
+    double cp = dfma_c(z, 2.4801587301587302e-05, -1.3888888888888889e-03);
+    cp = dfma_c(cp, z, 4.1666666666666664e-02);
+    cp = dfma_c(cp, z, -5.0000000000000000e-01);
+    const double cm = cp * z;                              // cos(delta) - 1
+    *sn = e.s + dfma(e.c, sd, e.s * cm);
+    *cs = e.c + dfma(-e.s, sd, e.c * cm);
+}
+
 SSME_HD double dsqrt(double x) { return __builtin_sqrt(x); }
+// sqrt of a positive NORMAL double well inside the exponent range (the Box-Muller radicand -2 log u lies in [2^-40, 56]):
+// the compiler's own v_rsq_f64 + two Goldschmidt / Newton steps without its range scaling and class fix-up (8 instructions
+// less).  Correctly rounded like dsqrt -- the host copy IS sqrt -- which tests/test_parity_gpu.py checks bit for bit.
+SSME_HD double dsqrt_pn(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = dfma(-h, g, 0.5);
+    g = dfma(g, r, g);
+    h = dfma(h, r, h);
+    const double d0 = dfma(-g, g, x);
+    g = dfma(d0, h, g);
+    const double d1 = dfma(-g, g, x);
+    return dfma(d1, h, g);
+#else
+    return __builtin_sqrt(x);
+#endif
+}
 
 }  // namespace ssme

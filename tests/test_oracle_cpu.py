@@ -61,6 +61,34 @@ def test_log_of_uniform_accuracy(oracle):
     assert np.all(err <= np.maximum(2.0 ** -51, 2 * np.spacing(np.abs(ref))))
 
 
+def test_round3_draw_functions_accuracy(oracle):
+    """The spec-r3 forms of the hot-loop draws, checked independently of the device (mpmath, 40 digits):
+    * sin / cos of the 24-bit Box-Muller angle by table: EVERY one of the 2^24 angles against libm (|error| < 4e-16 with libm's own
+      argument rounding), a sample against mpmath (|error| <= 3e-16), sin^2 + cos^2 = 1 to 5e-16;
+    * the spacing log: absolute error < 2^-43 (the spacings are quantised to 2^-35), strictly negative on the 32-bit grid."""
+    k = np.arange(0, 1 << 24, dtype=np.float64)
+    s, c = oracle.sincos_k24(k)
+    a = 2 * np.pi * k / 2.0 ** 24
+    assert np.max(np.abs(s - np.sin(a))) < 2e-15 and np.max(np.abs(c - np.cos(a))) < 2e-15
+    assert np.max(np.abs(s * s + c * c - 1)) < 5e-16
+    assert s[0] == 0.0 and c[0] == 1.0 and c[1 << 23] == -1.0 and s[1 << 22] == 1.0       # table angles come out exactly
+    mpmath = pytest.importorskip("mpmath")
+    mpmath.mp.dps = 40
+    rng = np.random.default_rng(5)
+    for kv in np.concatenate([rng.integers(0, 1 << 24, 1500), [131071, 131072, 131073, (1 << 24) - 1]]):
+        ang = 2 * mpmath.pi * int(kv) / 2 ** 24
+        sv, cv = oracle.sincos_k24(np.array([float(kv)]))
+        assert abs(mpmath.sin(ang) - mpmath.mpf(float(sv[0]))) <= 3e-16 and abs(mpmath.cos(ang) - mpmath.mpf(float(cv[0]))) <= 3e-16
+    u = np.concatenate([(rng.integers(0, 2 ** 32, 400000) + 0.5) * 2.0 ** -32, (np.arange(0, 4096) + 0.5) * 2.0 ** -32,
+                        1 - (np.arange(0, 4096) + 0.5) * 2.0 ** -32])
+    got = oracle.log_u32(u)
+    assert np.all(got < 0)
+    assert np.max(np.abs(got - np.log(u))) < 2.0 ** -43
+    # the quantised spacing differs from the one the full-precision log would give by at most one unit of 2^-35, rarely
+    q32, q = np.rint(-got * 2.0 ** 35), np.rint(-oracle.log_u(u) * 2.0 ** 35)
+    assert np.max(np.abs(q32 - q)) <= 1 and np.mean(q32 != q) < 0.01
+
+
 def test_math_special_values(oracle):
     with np.errstate(all="ignore"):
         x = np.array([-745.2, -745.0, -720.0, 709.7, 709.9, 0.0, np.inf, -np.inf])

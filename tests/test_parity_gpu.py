@@ -77,6 +77,17 @@ def test_device_math_bit_exact(sa, oracle):
         assert_bits_equal(_dev_math(3, v), c, "cos2pi")
         w = np.concatenate([rng.uniform(0, 100, 200000), np.exp(rng.uniform(-700, 700, 100000)), [0.0, 4.0, 2.0, 1e-320]])
         assert_bits_equal(_dev_math(4, w), np.sqrt(w), "sqrt (IEEE, correctly rounded)")
+        # round-3 draws: the Box-Muller angle by table (every 24-bit angle), the spacing log, the range-restricted sqrt
+        k = np.concatenate([np.arange(0, 1 << 24, 5, dtype=np.float64), rng.integers(0, 1 << 24, 300000).astype(np.float64),
+                            [0.0, 131071.0, 131072.0, 131073.0, 16777215.0, 4194304.0, 8388608.0, 12582912.0]])
+        sk, ck = oracle.sincos_k24(k)
+        assert_bits_equal(_dev_math(8, k), sk, "sin of the 24-bit angle (table)")
+        assert_bits_equal(_dev_math(9, k), ck, "cos of the 24-bit angle (table)")
+        u32 = np.concatenate([(rng.integers(0, 1 << 32, 400000).astype(np.float64) + 0.5) * 2.0 ** -32, (np.arange(0, 4096) + 0.5) * 2.0 ** -32,
+                              1 - (np.arange(0, 4096) + 0.5) * 2.0 ** -32])
+        assert_bits_equal(_dev_math(10, u32), oracle.log_u32(u32), "log of a spacing uniform")
+        rad = np.concatenate([-2.0 * oracle.log_u(uu[(uu > 0) & (uu < 1)]), rng.uniform(2.0 ** -40, 60, 300000), np.exp(rng.uniform(-28, 4.1, 300000))])
+        assert_bits_equal(_dev_math(11, rad), np.sqrt(rad), "sqrt of a Box-Muller radicand == IEEE sqrt")
 
 
 def test_device_quantize_bit_exact(sa, oracle):
