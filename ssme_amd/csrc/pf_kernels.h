@@ -504,6 +504,32 @@ __device__ __forceinline__ void prio_at(int mode, int idx) {
 // then the Box-Muller radii are computed while they arrive; the ancestor states are requested,
 // then the Box-Muller angles are computed while they arrive.
 // ---------------------------------------------------------------------------------------
+// The count-searches of a thread in the staged tiles, all NQ of them descending TOGETHER, one level per round: a round is NQ
+// independent ds_read_b64 (position = absolute LDS byte address, the level's offset in the immediate field), ONE wait, then per
+// search compare + select + add -- 3 VALU instructions per probe and log2(TILE) dependent LDS round trips per thread.
+// Written as inline assembly because the compiler, given the same loop in C++, either spends a fourth instruction per probe
+// on the address or serialises the NQ chains (44 dependent round trips; both seen in the ISA, round 3).  The wait names the
+// loaded values as in/out operands, so nothing that consumes them can be scheduled above it.
+template <int STEP, int NQ>
+struct lds_count_search {
+    static __device__ __forceinline__ void run(uint32_t (&pa)[NQ], const double (&t)[NQ]) {
+        static_assert(NQ == 2 || NQ == 4 || NQ == 8, "one, two or four particle pairs per thread");
+        double v[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(v[q]) : "v"(pa[q]), "n"((STEP - 1) * 8) : "memory");
+        if constexpr (NQ == 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+        else if constexpr (NQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]));
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) pa[q] = (v[q] < t[q]) ? pa[q] + (uint32_t)(STEP * 8) : pa[q];
+        lds_count_search<STEP / 2, NQ>::run(pa, t);
+    }
+};
+template <int NQ>
+struct lds_count_search<0, NQ> {
+    static __device__ __forceinline__ void run(uint32_t (&)[NQ], const double (&)[NQ]) {}
+};
+
 // 16-byte store of a particle pair.  stream = 1: non-temporal, the lines leave the XCD's L2 as they are written.  A launch
 // whose workgroups are all resident at once ends with every L2 full of dirty lines (2 MB per XCD at N = 2^20), and the
 // write-back at the end of the kernel is then serial time: 15.9 -> 14.3 us per step at N = 2^20.  Grids of several
@@ -522,9 +548,11 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     static_assert(NK >= 1 && NK * NT * 2 == TILE, "tile = 2 NT NK particles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nT2 = (BIG || a.Bpow2 < 2) ? 2 : a.Bpow2;      // BIG: level-2 comes from k_level2_plan, no tables in LDS
-    double* lds_T = reinterpret_cast<double*>(smem);             // [Bpow2] inclusive prefixes of A'
+    // the staged tiles come FIRST: their LDS address is then a compile-time constant and every search probe is a
+    // ds_read_b64 with the level's offset in its immediate field (the level-2 tables behind them are indexed at run time anyway)
+    double* lds_stage = reinterpret_cast<double*>(smem);         // [3][TILE] staged cdf tiles, 16-byte aligned
+    double* lds_T = lds_stage + kStageTiles * TILE;              // [Bpow2] inclusive prefixes of A'
     double* lds_R = lds_T + nT2;                                 // [Bpow2] A_b / A'_b
-    double* lds_stage = lds_T + 2 * nT2;                         // [3][TILE] staged cdf tiles, 16-byte aligned
     __shared__ double lds_seg_a[16];
     __shared__ double lds_seg_l2[64];
     __shared__ double lds_seg_c[16];
@@ -846,46 +874,69 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             PRIO_AT(5);
             // All 2*NK count-searches of a thread descend together, one level per iteration: the probes of a level are
             // independent LDS reads, so the phase costs log2(2048) = 11 dependent LDS round trips instead of one chain
-            // per particle (this phase is bound by LDS latency, not by issue slots).
+            // per particle.  A position is a BYTE offset into the staged tiles with the tile select folded in, so a probe is
+            // ds_read_b64 (constant offset field) + compare + add + select: no address arithmetic per probe (round 3: -44
+            // instructions per wave).  The target's tile among the <= 3 staged ones is a uniform case split on `span`:
+            // two staged tiles (the common case) need one compare and three selects per particle instead of two and nine.
             double tloc[NK][2];
-            int base[NK][2], pos[NK][2];
+            uint32_t pb[NK][2];
+            // positions as absolute 32-bit LDS addresses (the staged tiles' own address folded in once, here)
+            typedef __attribute__((address_space(3))) const double lds_cdouble;
+            const uint32_t stage_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cdouble*)lds_stage;
+            if (span == 1) {
 #pragma unroll
-            for (int k = 0; k < NK; ++k) {
+                for (int k = 0; k < NK; ++k) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const double target = tau[k][c];
-                    int sel = (T0 < target ? 1 : 0) + (T1 < target ? 1 : 0);
-                    sel = sel < span - 1 ? sel : span - 1;
-                    const double Pb = sel == 0 ? Pm : (sel == 1 ? T0 : T1);
-                    const double Rb = sel == 0 ? R0 : (sel == 1 ? R1 : R2);
-                    tloc[k][c] = __builtin_ceil((target - Pb) * Rb);
-                    base[k][c] = sel * TILE;
-                    pos[k][c] = 0;
+                    for (int c = 0; c < 2; ++c) { tloc[k][c] = __builtin_ceil((tau[k][c] - Pm) * R0); pb[k][c] = stage_a; }
+                }
+            } else if (span == 2) {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const bool up = T0 < tau[k][c];
+                        tloc[k][c] = __builtin_ceil((tau[k][c] - (up ? T0 : Pm)) * (up ? R1 : R0));
+                        pb[k][c] = up ? stage_a + (uint32_t)(TILE * 8) : stage_a;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const double target = tau[k][c];
+                        int sel = (T0 < target ? 1 : 0) + (T1 < target ? 1 : 0);
+                        sel = sel < span - 1 ? sel : span - 1;
+                        const double Pb = sel == 0 ? Pm : (sel == 1 ? T0 : T1);
+                        const double Rb = sel == 0 ? R0 : (sel == 1 ? R1 : R2);
+                        tloc[k][c] = __builtin_ceil((target - Pb) * Rb);
+                        pb[k][c] = stage_a + (uint32_t)sel * (uint32_t)(TILE * 8);
+                    }
                 }
             }
             if (ABL(a, 2)) {
 #pragma unroll
-                for (int k = 0; k < NK; ++k) { pos[k][0] = (int)(d2bits(tloc[k][0]) >> 20) & 2047; pos[k][1] = (int)(d2bits(tloc[k][1]) >> 20) & 2047; }
+                for (int k = 0; k < NK; ++k) { pb[k][0] += ((uint32_t)(d2bits(tloc[k][0]) >> 20) & 2047u) * 8u; pb[k][1] += ((uint32_t)(d2bits(tloc[k][1]) >> 20) & 2047u) * 8u; }
             } else {
+                uint32_t pa[2 * NK];
+                double tq[2 * NK];
 #pragma unroll
-                for (int step = TILE >> 1; step >= 1; step >>= 1) {
+                for (int k = 0; k < NK; ++k) { pa[2 * k] = pb[k][0]; pa[2 * k + 1] = pb[k][1]; tq[2 * k] = tloc[k][0]; tq[2 * k + 1] = tloc[k][1]; }
+                lds_count_search<TILE / 2, 2 * NK>::run(pa, tq);
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) {
-#pragma unroll
-                        for (int c = 0; c < 2; ++c)
-                            if (lds_stage[base[k][c] + pos[k][c] + step - 1] < tloc[k][c]) pos[k][c] += step;
-                    }
-                }
+                for (int k = 0; k < NK; ++k) { pb[k][0] = pa[2 * k]; pb[k][1] = pa[2 * k + 1]; }
             }
+            // gather: the ancestor's state at a 32-bit byte offset from a uniform base (no 64-bit address arithmetic per lane)
+            const unsigned char* xbase = reinterpret_cast<const unsigned char*>(xin_r - win0);
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    int anc = bb_min * TILE + base[k][c] + pos[k][c];
+                    int anc = bb_min * TILE + (int)((pb[k][c] - stage_a) >> 3);
                     anc = anc < a.N - 1 ? anc : a.N - 1;
                     const int i = i_first + (k * NT + tid) * 2 + c;
                     if (anc_p && i < a.N) anc_p[rowoff + i - out0] = (uint32_t)anc;
-                    xin[k][c] = xin_r[anc - win0];
+                    xin[k][c] = *reinterpret_cast<const double*>(xbase + ((uint32_t)anc << 3));
                     lw_old[k][c] = 0.0;
                 }
             }
