@@ -178,11 +178,21 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int lane) {
 }
 
 // max over the wave of non-NaN doubles (lane 63 holds it after the scan; broadcast by readlane)
+// Inside a row of 16 lanes the reduction is a BUTTERFLY (quad_perm xor 1, xor 2, row_half_mirror, row_mirror): every lane has
+// a source lane, so the DPP moves need no fill value -- 3 instructions per step instead of 5 with the -inf fill of a shifted
+// scan; only the two cross-row steps (row_bcast:15 / :31) keep it.  A maximum does not depend on the order: same bits.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_perm(double v) {       // full permutations inside a row: no fill needed
+    const u64 b = d2bits(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
+    return bits2d(((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo);
+}
 __device__ __forceinline__ double wave_max_f64(double v) {
-    v = dmaxnum(v, dpp_f64_neginf<0x111, 0xF>(v));
-    v = dmaxnum(v, dpp_f64_neginf<0x112, 0xF>(v));
-    v = dmaxnum(v, dpp_f64_neginf<0x114, 0xF>(v));
-    v = dmaxnum(v, dpp_f64_neginf<0x118, 0xF>(v));
+    v = dmaxnum(v, dpp_f64_perm<0xB1>(v));            // quad_perm [1,0,3,2]
+    v = dmaxnum(v, dpp_f64_perm<0x4E>(v));            // quad_perm [2,3,0,1]
+    v = dmaxnum(v, dpp_f64_perm<0x141>(v));           // row_half_mirror
+    v = dmaxnum(v, dpp_f64_perm<0x140>(v));           // row_mirror: every lane of a row holds the row's maximum
     v = dmaxnum(v, dpp_f64_neginf<0x142, 0xA>(v));
     v = dmaxnum(v, dpp_f64_neginf<0x143, 0xC>(v));
     return bits2d(readlane_u64(d2bits(v), 63));
@@ -586,6 +596,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     double* const logw_p = HOT ? nullptr : a.logw;
     const int i_first = b * TILE;
     const int nvalid = (a.N - i_first) < TILE ? (a.N - i_first) : TILE;    // valid outputs in this tile (>= 1)
+    const bool ragged = nvalid < TILE;                                     // uniform: this tile holds particles beyond N
 
     STAMP(a, 0);
     PRIO_AT(0);
@@ -764,16 +775,18 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             }
         }
         if (span <= kStageTiles) {
-            const double* src = cdf_r + (size_t)(bb_min - a.win_tile0) * TILE + tid * 2;
+            // a uniform base (scalar registers) plus a 32-bit lane offset: no 64-bit address arithmetic per lane
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(cdf_r + (size_t)(bb_min - a.win_tile0) * TILE);
+            const uint32_t lane_off = (uint32_t)tid * 16u;
 #pragma unroll
-            for (int k = 0; k < NK; ++k) stg0[k] = *reinterpret_cast<const double2*>(src + k * NT * 2);
+            for (int k = 0; k < NK; ++k) stg0[k] = *reinterpret_cast<const double2*>(src + (lane_off + (uint32_t)(k * NT * 16)));
             if (span >= 2) {
 #pragma unroll
-                for (int k = 0; k < NK; ++k) stg1[k] = *reinterpret_cast<const double2*>(src + TILE + k * NT * 2);
+                for (int k = 0; k < NK; ++k) stg1[k] = *reinterpret_cast<const double2*>(src + (lane_off + (uint32_t)(TILE * 8 + k * NT * 16)));
             }
             if (span >= 3) {
 #pragma unroll
-                for (int k = 0; k < NK; ++k) stg2[k] = *reinterpret_cast<const double2*>(src + 2 * TILE + k * NT * 2);
+                for (int k = 0; k < NK; ++k) stg2[k] = *reinterpret_cast<const double2*>(src + (lane_off + (uint32_t)(2 * TILE * 8 + k * NT * 16)));
             }
         }
     }
@@ -794,8 +807,13 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             double e0, e1;
             if (ABL(a, 1)) { e0 = 1.0 + 1e-6 * (double)(i0 & 1023); e1 = 1.0; }
             else pair_spacings(o, lds_dtab.log, &e0, &e1);
-            le[k][0] = (i0 < a.N) ? __builtin_rint(e0 * 34359738368.0 /* 2^35 */) : 0.0;
-            le[k][1] = (i0 + 1 < a.N) ? __builtin_rint(e1 * 34359738368.0) : 0.0;
+            le[k][0] = __builtin_rint(e0 * 34359738368.0 /* 2^35 */);
+            le[k][1] = __builtin_rint(e1 * 34359738368.0);
+            if (ragged) {                 // only the last tile of a filter whose N is not a multiple of the tile: a uniform branch
+                asm volatile("");         // (kept a branch: as selects these masks cost every tile 12 instructions per particle pair)
+                if (!(i0 < a.N)) le[k][0] = 0.0;
+                if (!(i0 + 1 < a.N)) le[k][1] = 0.0;
+            }
         }
     }
     if (multinomial) {
@@ -988,13 +1006,20 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         for (int c = 0; c < 2; ++c) {
             const double xn = first_step ? zn[k][c] * mc.a2 : model_prop<MODEL>(mc, xin[k][c], zn[k][c], zcov, lds_etab);
             const double l = lw_old[k][c] + (ABL(a, 3) ? -0.5 * xn * xn : model_logg<MODEL>(mc, y, xn, lds_etab));
-            const bool valid = (i0 + c) < a.N;
-            xo[c] = valid ? xn : 0.0;
-            lg[k][c] = valid ? l : -dinf();
-            if (valid) { nan = nan || (l != l); mx = (l > mx) ? l : mx; }
+            xo[c] = xn;
+            lg[k][c] = l;
         }
+        if (ragged) {                     // particles beyond N: state 0, log-weight -inf (weight 0, no part in the maximum)
+            asm volatile("");
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (!((i0 + c) < a.N)) { xo[c] = 0.0; lg[k][c] = -dinf(); }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { const double l = lg[k][c]; nan = nan || (l != l); mx = (l > mx) ? l : mx; }
         const size_t idx = rowoff + (size_t)(i0 - out0);
-        store_pair(a.x_out + idx, xo[0], xo[1], a.stream_stores);
+        store_pair(reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(a.x_out + rowoff + (size_t)(i_first - out0)) + (uint32_t)(k * NT + tid) * 16u),
+                   xo[0], xo[1], a.stream_stores);
         if (logw_p) *reinterpret_cast<double2*>(logw_p + idx) = make_double2(lg[k][0], lg[k][1]);
     }
     STAMP(a, 8);
@@ -1007,11 +1032,11 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     double q[NK][2], inc[NK][2], total;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const int i0 = i_first + (k * NT + tid) * 2;
         if (ABL(a, 4)) { q[k][0] = (double)(d2bits(lg[k][0] - mb) >> 24); q[k][1] = (double)(d2bits(lg[k][1] - mb) >> 24); }
         else {
-            q[k][0] = (i0 < a.N) ? __builtin_rint(dexp_scaled_t(lg[k][0] - mb, kTileShift, lds_etab)) : 0.0;
-            q[k][1] = (i0 + 1 < a.N) ? __builtin_rint(dexp_scaled_t(lg[k][1] - mb, kTileShift, lds_etab)) : 0.0;
+            // (a particle beyond N carries log-weight -inf: the clamped exp makes its q exactly 0, no mask needed)
+            q[k][0] = __builtin_rint(dexp_scaled_t(lg[k][0] - mb, kTileShift, lds_etab));
+            q[k][1] = __builtin_rint(dexp_scaled_t(lg[k][1] - mb, kTileShift, lds_etab));
         }
     }
     if (ABL(a, 5)) {
@@ -1023,8 +1048,8 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     PRIO_AT(12);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const int i0 = i_first + (k * NT + tid) * 2;
-        store_pair(a.cdf_out + rowoff + (i0 - out0), inc[k][0], inc[k][1], a.stream_stores);
+        store_pair(reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(a.cdf_out + rowoff + (size_t)(i_first - out0)) + (uint32_t)(k * NT + tid) * 16u),
+                   inc[k][0], inc[k][1], a.stream_stores);
     }
     STAMP(a, 10);
     PRIO_AT(10);
