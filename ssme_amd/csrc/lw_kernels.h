@@ -216,8 +216,13 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
         const int i0 = i_first + (k * NT + tid) * 2;
         double e0, e1;
         pair_spacings(draw[k], L.ltab, &e0, &e1);          // words 2-3 of the pair's draw (32-bit uniforms, table log)
-        qe[k][0] = (i0 < N) ? __builtin_rint(e0 * 34359738368.0) : 0.0;
-        qe[k][1] = (i0 + 1 < N) ? __builtin_rint(e1 * 34359738368.0) : 0.0;
+        qe[k][0] = __builtin_rint(e0 * 34359738368.0);
+        qe[k][1] = __builtin_rint(e1 * 34359738368.0);
+        if (i_first + kTile > N) {        // uniform: only the ragged last tile masks the particles beyond N
+            asm volatile("");
+            if (!(i0 < N)) qe[k][0] = 0.0;
+            if (!(i0 + 1 < N)) qe[k][1] = 0.0;
+        }
     }
     block_scan_f64<NT, NK>(qe, le, se, L.seg_a);
     const double ratio = gam / se;
@@ -249,37 +254,14 @@ __device__ __forceinline__ void lw_select(const double* tsum, const double* tmax
         const double Pm = bb_min ? (BIG ? v.T[bb_min - 1] : L.lds_T[bb_min - 1]) : 0.0;
         const double R0 = BIG ? v.R[bb_min] : L.lds_R[bb_min], R1 = BIG ? v.R[b1] : L.lds_R[b1], R2 = BIG ? v.R[b2] : L.lds_R[b2];
         __syncthreads();
-        // the four count-searches of a thread descend together (11 dependent LDS round trips; see k_filter_step)
-        double tloc[NK][2];
-        int base[NK][2], pos[NK][2];
+        // the four count-searches of a thread descend together (staged_search, pf_kernels.h)
+        int soff[NK][2];
+        staged_search<kTile, NK>(tau, span, Pm, T0, T1, R0, R1, R2, L.lds_stage, soff);
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const double target = tau[k][c];
-                int sel = (T0 < target ? 1 : 0) + (T1 < target ? 1 : 0);
-                sel = sel < span - 1 ? sel : span - 1;
-                const double Pb = sel == 0 ? Pm : (sel == 1 ? T0 : T1);
-                const double Rb = sel == 0 ? R0 : (sel == 1 ? R1 : R2);
-                tloc[k][c] = __builtin_ceil((target - Pb) * Rb);
-                base[k][c] = sel * kTile;
-                pos[k][c] = 0;
-            }
-        }
-#pragma unroll
-        for (int step = kTile >> 1; step >= 1; step >>= 1) {
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-                    if (L.lds_stage[base[k][c] + pos[k][c] + step - 1] < tloc[k][c]) pos[k][c] += step;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int a = bb_min * kTile + base[k][c] + pos[k][c];
+                const int a = bb_min * kTile + soff[k][c];
                 idx[k][c] = a < N - 1 ? a : N - 1;
             }
         }
@@ -317,28 +299,25 @@ __device__ __forceinline__ void lw_level2_only(const double* tsum, const double*
 }
 
 // log-weights lg[k][c] of this tile -> tile max, fixed-point weights, exact tile scan; stores cdf / tile sum / tile max
-__device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int N, int i_first, double* cdf_row, double* tsum_row,
+__device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int /*N*/, int i_first, double* cdf_row, double* tsum_row,
                                              double* tmax_row, int b, double* lds_d, double* lds_seg, const ExpTabEntry* etab, int tile0 = 0) {
     constexpr int NT = kLwNT, NK = 2;
     const int tid = threadIdx.x;
     __builtin_amdgcn_s_setprio(0);
     double mx = -dinf();
     bool nan = false;
+    // (callers give particles beyond N the log-weight -inf: no part in the maximum, and the clamped exp makes their q exactly 0)
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int i = i_first + (k * NT + tid) * 2 + c;
-            if (i < N) { const double l = lg[k][c]; nan = nan || (l != l); mx = (l > mx) ? l : mx; }
-        }
+        for (int c = 0; c < 2; ++c) { const double l = lg[k][c]; nan = nan || (l != l); mx = (l > mx) ? l : mx; }
     }
     const double mb = block_max_nanprop<NT>(mx, nan, lds_d);
     double q[NK][2], inc[NK][2], total;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const int i0 = i_first + (k * NT + tid) * 2;
-        q[k][0] = (i0 < N) ? __builtin_rint(dexp_scaled_t(lg[k][0] - mb, kTileShift, etab)) : 0.0;
-        q[k][1] = (i0 + 1 < N) ? __builtin_rint(dexp_scaled_t(lg[k][1] - mb, kTileShift, etab)) : 0.0;
+        q[k][0] = __builtin_rint(dexp_scaled_t(lg[k][0] - mb, kTileShift, etab));
+        q[k][1] = __builtin_rint(dexp_scaled_t(lg[k][1] - mb, kTileShift, etab));
     }
     block_scan_f64<NT, NK>(q, inc, total, lds_seg);
 #pragma unroll
@@ -361,7 +340,7 @@ __device__ __forceinline__ void lw_store_cdf(const double (&lg)[2][2], int N, in
     load_log_table<kLwNT>(&lds_dtab);                                                                      \
     load_exp_table<kLwNT>(lds_etab);                                                                      \
     LwLds L;                                                                                              \
-    L.lds_T = reinterpret_cast<double*>(smem); L.lds_R = L.lds_T + nT2; L.lds_stage = L.lds_T + 2 * nT2;  \
+    L.lds_stage = reinterpret_cast<double*>(smem); L.lds_T = L.lds_stage + kStageTiles * kTile; L.lds_R = L.lds_T + nT2;  \
     L.seg_a = lds_seg_a; L.seg_l2 = lds_seg_l2; L.d1 = lds_d1; L.cnt = lds_cnt;                           \
     L.ltab = lds_dtab.log; L.etab = lds_etab;                                                                 \
     __syncthreads();
@@ -671,7 +650,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
         // area (B <= 512 tiles x 14 doubles = at most the 56 KB of lds_T + lds_R + three staged tiles), then every lane
         // walks its chunk there.  (Read straight from global memory each lane touches its own cache line per tile:
         // 8192 line accesses per workgroup, +8 us per launch.)
-        double* lds_momall = L.lds_T;
+        double* lds_momall = L.lds_stage;        // the start of the dynamic LDS: staged tiles | T' | A/A'
         const double* gm = a.mom + (size_t)r * a.B * 16;
         {
             // all loads of a thread are issued before its first LDS store (a rolled loop waits for every load in turn);

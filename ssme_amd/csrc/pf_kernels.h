@@ -540,6 +540,60 @@ struct lds_count_search<0, NQ> {
     static __device__ __forceinline__ void run(uint32_t (&)[NQ], const double (&)[NQ]) {}
 };
 
+// The staged search of one thread: targets tau (integers in the filter's global fixed point) -> positions among the `span`
+// (<= 3) cdf tiles staged in LDS at lds_stage, returned as ELEMENT offsets from the first staged tile (0 .. span TILE - 1).
+// Pm / T0 / T1: inclusive prefixes T' of the tile before the first staged tile and of the first two staged tiles;
+// R0..R2: A / A' of the staged tiles.  Shared by k_filter_step and the Liu-West selection (lw_select).
+// A position is an absolute LDS byte address with the tile select folded in, so a probe is ds_read_b64 (constant offset
+// field) + compare + add + select.  The target's tile is a uniform case split on `span`: two staged tiles (the common case)
+// need one compare and three selects per particle instead of two and nine.
+template <int TILE, int NK>
+__device__ __forceinline__ void staged_search(const double (&tau)[NK][2], int span, double Pm, double T0, double T1, double R0, double R1,
+                                              double R2, const double* lds_stage, int (&off)[NK][2]) {
+    double tloc[NK][2];
+    uint32_t pb[NK][2];
+    typedef __attribute__((address_space(3))) const double lds_cdouble;
+    const uint32_t stage_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cdouble*)lds_stage;
+    if (span == 1) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { tloc[k][c] = __builtin_ceil((tau[k][c] - Pm) * R0); pb[k][c] = stage_a; }
+        }
+    } else if (span == 2) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bool up = T0 < tau[k][c];
+                tloc[k][c] = __builtin_ceil((tau[k][c] - (up ? T0 : Pm)) * (up ? R1 : R0));
+                pb[k][c] = up ? stage_a + (uint32_t)(TILE * 8) : stage_a;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const double target = tau[k][c];
+                int sel = (T0 < target ? 1 : 0) + (T1 < target ? 1 : 0);
+                sel = sel < span - 1 ? sel : span - 1;
+                const double Pb = sel == 0 ? Pm : (sel == 1 ? T0 : T1);
+                const double Rb = sel == 0 ? R0 : (sel == 1 ? R1 : R2);
+                tloc[k][c] = __builtin_ceil((target - Pb) * Rb);
+                pb[k][c] = stage_a + (uint32_t)sel * (uint32_t)(TILE * 8);
+            }
+        }
+    }
+    uint32_t pa[2 * NK];
+    double tq[2 * NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { pa[2 * k] = pb[k][0]; pa[2 * k + 1] = pb[k][1]; tq[2 * k] = tloc[k][0]; tq[2 * k + 1] = tloc[k][1]; }
+    lds_count_search<TILE / 2, 2 * NK>::run(pa, tq);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { off[k][0] = (int)((pa[2 * k] - stage_a) >> 3); off[k][1] = (int)((pa[2 * k + 1] - stage_a) >> 3); }
+}
+
 // 16-byte store of a particle pair.  stream = 1: non-temporal, the lines leave the XCD's L2 as they are written.  A launch
 // whose workgroups are all resident at once ends with every L2 full of dirty lines (2 MB per XCD at N = 2^20), and the
 // write-back at the end of the kernel is then serial time: 15.9 -> 14.3 us per step at N = 2^20.  Grids of several
@@ -890,67 +944,19 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             const double R0 = BIG ? l2R[bb_min] : lds_R3[0], R1 = BIG ? l2R[b1] : lds_R3[1], R2 = BIG ? l2R[b2] : lds_R3[2];
             STAMP(a, 5);
             PRIO_AT(5);
-            // All 2*NK count-searches of a thread descend together, one level per iteration: the probes of a level are
-            // independent LDS reads, so the phase costs log2(2048) = 11 dependent LDS round trips instead of one chain
-            // per particle.  A position is a BYTE offset into the staged tiles with the tile select folded in, so a probe is
-            // ds_read_b64 (constant offset field) + compare + add + select: no address arithmetic per probe (round 3: -44
-            // instructions per wave).  The target's tile among the <= 3 staged ones is a uniform case split on `span`:
-            // two staged tiles (the common case) need one compare and three selects per particle instead of two and nine.
-            double tloc[NK][2];
-            uint32_t pb[NK][2];
-            // positions as absolute 32-bit LDS addresses (the staged tiles' own address folded in once, here)
-            typedef __attribute__((address_space(3))) const double lds_cdouble;
-            const uint32_t stage_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cdouble*)lds_stage;
-            if (span == 1) {
-#pragma unroll
-                for (int k = 0; k < NK; ++k) {
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) { tloc[k][c] = __builtin_ceil((tau[k][c] - Pm) * R0); pb[k][c] = stage_a; }
-                }
-            } else if (span == 2) {
-#pragma unroll
-                for (int k = 0; k < NK; ++k) {
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const bool up = T0 < tau[k][c];
-                        tloc[k][c] = __builtin_ceil((tau[k][c] - (up ? T0 : Pm)) * (up ? R1 : R0));
-                        pb[k][c] = up ? stage_a + (uint32_t)(TILE * 8) : stage_a;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < NK; ++k) {
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const double target = tau[k][c];
-                        int sel = (T0 < target ? 1 : 0) + (T1 < target ? 1 : 0);
-                        sel = sel < span - 1 ? sel : span - 1;
-                        const double Pb = sel == 0 ? Pm : (sel == 1 ? T0 : T1);
-                        const double Rb = sel == 0 ? R0 : (sel == 1 ? R1 : R2);
-                        tloc[k][c] = __builtin_ceil((target - Pb) * Rb);
-                        pb[k][c] = stage_a + (uint32_t)sel * (uint32_t)(TILE * 8);
-                    }
-                }
-            }
+            // all 2 NK count-searches of the thread descend together (staged_search)
+            int soff[NK][2];
             if (ABL(a, 2)) {
 #pragma unroll
-                for (int k = 0; k < NK; ++k) { pb[k][0] += ((uint32_t)(d2bits(tloc[k][0]) >> 20) & 2047u) * 8u; pb[k][1] += ((uint32_t)(d2bits(tloc[k][1]) >> 20) & 2047u) * 8u; }
-            } else {
-                uint32_t pa[2 * NK];
-                double tq[2 * NK];
-#pragma unroll
-                for (int k = 0; k < NK; ++k) { pa[2 * k] = pb[k][0]; pa[2 * k + 1] = pb[k][1]; tq[2 * k] = tloc[k][0]; tq[2 * k + 1] = tloc[k][1]; }
-                lds_count_search<TILE / 2, 2 * NK>::run(pa, tq);
-#pragma unroll
-                for (int k = 0; k < NK; ++k) { pb[k][0] = pa[2 * k]; pb[k][1] = pa[2 * k + 1]; }
-            }
+                for (int k = 0; k < NK; ++k) { soff[k][0] = (int)(d2bits(tau[k][0]) >> 20) & 2047; soff[k][1] = (int)(d2bits(tau[k][1]) >> 20) & 2047; }
+            } else staged_search<TILE, NK>(tau, span, Pm, T0, T1, R0, R1, R2, lds_stage, soff);
             // gather: the ancestor's state at a 32-bit byte offset from a uniform base (no 64-bit address arithmetic per lane)
             const unsigned char* xbase = reinterpret_cast<const unsigned char*>(xin_r - win0);
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    int anc = bb_min * TILE + (int)((pb[k][c] - stage_a) >> 3);
+                    int anc = bb_min * TILE + soff[k][c];
                     anc = anc < a.N - 1 ? anc : a.N - 1;
                     const int i = i_first + (k * NT + tid) * 2 + c;
                     if (anc_p && i < a.N) anc_p[rowoff + i - out0] = (uint32_t)anc;
