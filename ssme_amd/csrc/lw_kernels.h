@@ -49,6 +49,11 @@ struct LwArgs {
     double* mom;                                // [R][B][16] tile partial sums of the 14 moments
     double* prop;                               // [R][16]: theta-bar[4], L (lower triangle, row-major)[10]
     uint32_t *anc, *kidx;                       // debug: resampling ancestors / k indices, or null
+    uint32_t* ancbuf;                           // compose = 1: [R][Npad] resampling ancestors of this step (stage 1 -> stage 2)
+    int32_t compose;                            // 1 (unsharded handles): stage 1 does not materialise the resampled population; stage 2
+                                                // gathers (x, theta) of particle ancbuf[k_i] from the population the step started from
+                                                // (xB / thB) and writes the new one into xr / thr -- the host then swaps the two pairs.
+                                                // 40 of 208 bytes per particle-step less (the resampled (x, theta) written and re-read)
     LwScalars* scal;
     const double *y, *z;
     double y_now, z_now;                        // step API: this call's observation / covariate in the kernel arguments (by_value = 1)
@@ -491,9 +496,13 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
                 for (int e = 0; e <= d; ++e) { const double v = valid ? tt[d][c] * tt[e][c] : 0.0; fold[q][c] = (k == 0) ? v : fold[q][c] + v; ++q; }
             }
         }
-        *reinterpret_cast<double2*>(a.xr + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
         *reinterpret_cast<double2*>(a.lw1 + rowoff + (i0 - out0)) = make_double2(g1[0], g1[1]);
-        th_store_pair(a.thr, rowoff + (size_t)(i0 - out0), tt);
+        if (a.compose) {
+            *reinterpret_cast<uint2*>(a.ancbuf + rowoff + (i0 - out0)) = make_uint2((uint32_t)anc[k][0], (uint32_t)anc[k][1]);
+        } else {
+            *reinterpret_cast<double2*>(a.xr + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
+            th_store_pair(a.thr, rowoff + (size_t)(i0 - out0), tt);
+        }
     }
     // wave tree per 128-element segment of the folded half tile, then the 8 segments in order
 #pragma unroll
@@ -736,7 +745,11 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
         for (int c = 0; c < 2; ++c) {
             const int i = i0 + c;
             const int j = kk[k][c];
-            const double xk = a.xr[rowoff + (j - win0)];
+            // compose: the particle that continues is ancestor ancbuf[j] of the population the step started from
+            const int js = a.compose ? (int)a.ancbuf[rowoff + j] : j;
+            const double* xsrc = a.compose ? a.xB : a.xr;
+            const double* thsrc = a.compose ? a.thB : a.thr;
+            const double xk = xsrc[rowoff + (js - win0)];
             const double lw1k = a.lw1[rowoff + (j - win0)];
             double e[kDP];
             {
@@ -746,7 +759,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
                 pair_normals(o1.v2, o1.v3, &lds_dtab, &e[2], &e[3]);
             }
             double tu[kDP], thrk[kDP];
-            th_load(a.thr, rowoff + (size_t)(j - win0), thrk);
+            th_load(thsrc, rowoff + (size_t)(js - win0), thrk);
             int q = kDP;
 #pragma unroll
             for (int d = 0; d < kDP; ++d) {
@@ -766,9 +779,11 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
             if (a.kidx && i < a.N) a.kidx[rowoff + (i - out0)] = (uint32_t)j;
             if (i >= a.N) { xo[c] = 0.0; lg[k][c] = -dinf(); }
         }
-        *reinterpret_cast<double2*>(a.xB + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
+        double* xdst = a.compose ? a.xr : a.xB;          // compose: the other population pair (the host swaps them after the launch)
+        double* thdst = a.compose ? a.thr : a.thB;
+        *reinterpret_cast<double2*>(xdst + rowoff + (i0 - out0)) = make_double2(xo[0], xo[1]);
         if (a.lwB) *reinterpret_cast<double2*>(a.lwB + rowoff + (i0 - out0)) = make_double2(lg[k][0], lg[k][1]);
-        th_store_pair(a.thB, rowoff + (size_t)(i0 - out0), tho);
+        th_store_pair(thdst, rowoff + (size_t)(i0 - out0), tho);
     }
     lw_store_cdf(lg, a.N, i_first, a.cdfB + rowoff, a.tsumB + (size_t)r * a.Bs, a.tmaxB + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, lds_etab, a.tile0);
 }

@@ -1535,6 +1535,7 @@ struct ssme_lw_s {
     double *ybuf, *zbuf, *per_step, *scratch;
     double *gamA, *pgamA, *gtotA, *gamB, *pgamB, *gtotB;
     uint32_t *anc, *kidx, *keybuf;
+    uint32_t* ancbuf;        // unsharded handles: this step's resampling ancestors, stage 1 -> stage 2 (compose mode, lw_kernels.h)
     int shard_rank, shard_world;     // particle-sharded filter (world = 0: unsharded)
     int th_plane_tiles;              // sharded: rows (tiles) per theta plane of the caller's OUTPUT buffers (default B / world)
     hipStream_t own_stream;
@@ -1574,6 +1575,7 @@ static LwArgs lw_args(ssme_lw_handle h) {
     a.cdfA = h->cdfA; a.tsumA = h->tsumA; a.tmaxA = h->tmaxA; a.cdfB = h->cdfB; a.tsumB = h->tsumB; a.tmaxB = h->tmaxB;
     a.mom = h->mom; a.prop = h->prop;
     a.anc = (h->debug & 1) ? h->anc : nullptr; a.kidx = (h->debug & 1) ? h->kidx : nullptr;
+    a.ancbuf = h->ancbuf; a.compose = (h->shard_world == 0 && h->ancbuf) ? 1 : 0;
     a.scal = h->scal; a.y = h->ybuf; a.z = h->zbuf; a.per_step = nullptr;
     a.gamA = h->gamA; a.pgamA = h->pgamA; a.gtotA = h->gtotA; a.gamB = h->gamB; a.pgamB = h->pgamB; a.gtotB = h->gtotB;
     a.N = h->N; a.Npad = h->Npad; a.B = h->B; a.Bs = h->Bs; a.Bpow2 = h->Bpow2; a.rshift = h->rshift; a.R = h->R;
@@ -1669,6 +1671,7 @@ static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record
         hipLaunchKernelGGL(k_lw_mom_totals, dim3(kNMom, h->R), dim3(64), 0, h->stream, a);
         hipLaunchKernelGGL(k_lw_mid<true>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
         hipLaunchKernelGGL(k_lw_stage2<true>, grid, dim3(kLwNT), h->lds_bytes_big, h->stream, a);
+        if (a.compose) { std::swap(h->xB, h->xr); std::swap(h->thB, h->thr); }      // the new population is where stage 2 wrote it
     } else {
         // two launches when the tile partials ([B][14] doubles) fit the window area of stage 2's LDS: every workgroup of stage 2
         // then takes theta-bar and the Cholesky factor from them itself
@@ -1680,6 +1683,7 @@ static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record
             hipLaunchKernelGGL(k_lw_mid<false>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
         }
         hipLaunchKernelGGL(k_lw_stage2<false>, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
+        if (a.compose) { std::swap(h->xB, h->xr); std::swap(h->thB, h->thr); }
     }
 }
 static void lw_enqueue_finalize(ssme_lw_handle h, int t, bool record, double* ll_host = nullptr) {
@@ -1712,7 +1716,7 @@ int ssme_lw_destroy(ssme_lw_handle h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     h->stream = h->own_stream;
     void* bufs[] = {h->xB, h->thB, h->xr, h->thr, h->lw1, h->cdfA, h->tsumA, h->tmaxA, h->cdfB, h->tsumB, h->tmaxB, h->mom, h->prop, h->momtot,
-                    h->ybuf, h->zbuf, h->per_step, h->scratch, h->gamA, h->pgamA, h->gtotA, h->gamB, h->pgamB, h->gtotB, h->anc,
+                    h->ybuf, h->zbuf, h->per_step, h->scratch, h->gamA, h->pgamA, h->gtotA, h->gamB, h->pgamB, h->gtotB, h->anc, h->ancbuf,
                     h->kidx, h->scal, h->keybuf, h->plan_dev, h->l2_work, h->l2T[0], h->l2T[1], h->l2R[0], h->l2R[1], h->l2lo[0], h->l2lo[1],
                     h->l2hi[0], h->l2hi[1], h->l2s[0], h->l2s[1], h->lwB, h->wscratch,
                     h->sh_xB, h->sh_thB, h->sh_cdfB, h->sh_xr, h->sh_thr, h->sh_g1, h->sh_cdfA, h->sh_locB, h->sh_locA, h->sh_allB_s, h->sh_allB_m,
@@ -1782,6 +1786,8 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
             for (auto p : big4) { LWCHK(hipMalloc(p, sizeof(double) * np * kDP)); LWCHK(hipMemset(*p, 0, sizeof(double) * np * kDP)); }
             double** small[] = {&h->tsumA, &h->tmaxA, &h->tsumB, &h->tmaxB};
             for (auto p : small) { LWCHK(hipMalloc(p, sizeof(double) * nb)); LWCHK(hipMemset(*p, 0, sizeof(double) * nb)); }
+            LWCHK(hipMalloc(&h->ancbuf, sizeof(uint32_t) * np));
+            LWCHK(hipMemset(h->ancbuf, 0, sizeof(uint32_t) * np));
         } else {
             LWCHK(hipMalloc(&h->plan_dev, sizeof(int32_t) * 2 * h->shard_world));
             LWCHK(hipHostMalloc(reinterpret_cast<void**>(&h->plan_pin), sizeof(int32_t) * 2 * h->shard_world, hipHostMallocDefault));
