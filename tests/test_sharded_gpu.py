@@ -198,7 +198,10 @@ def _build_thread_harness():
     (2, 2 * 300 * 2048, 4, 0, 0, 1),                                       # 600 tiles: in-kernel level-2, window check in the step kernel
     (2, 2 * 600 * 2048, 4, 0, 0, 1), (4, 4 * 300 * 2048, 4, 0, 1, 0),      # more than 1024 tiles: split level-2 plans + window check kernel
     (8, 8 * 4 * 2048, 8, 0, 0, 0), (8, 8 * 2 * 2048, 6, 1, 0, 1),          # eight ranks, as a full node would run
-    (2, 16384, 10, -1, 990, 0), (4, 65536, 8, -1, 950, 0), (2, 2 * 600 * 2048, 3, -1, 990, 0), (8, 8 * 2 * 2048, 6, -1, 990, 0)])      # Liu-West
+    (2, 16384, 10, -1, 990, 0), (4, 65536, 8, -1, 950, 0), (2, 2 * 600 * 2048, 3, -1, 990, 0), (8, 8 * 2 * 2048, 6, -1, 990, 0),      # Liu-West
+    # BASELINE.json configs[4] at its REAL shape: 8 ranks x 2^21 particles of Liu-West (N = 2^24, 8192 tiles: split level-2 plans,
+    # window check kernel, moment totals by k_lw_mom_totals), three steps -- what an 8-GPU node will run, here on one GPU
+    (8, 8 * 1024 * 2048, 3, -1, 990, 0)])
 def test_native_drivers_with_several_ranks_on_one_gpu(world, n, T, model, rs, mode):
     """The C++ shard drivers with 2-6 ranks: the ranks are host threads sharing the GPU and RCCL is replaced by
     tests/cpp/mock_rccl.cpp (same stream ordering and send/recv matching; RCCL itself refuses two ranks per device).
