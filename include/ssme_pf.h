@@ -42,8 +42,12 @@ enum {
                                      theta = (beta, phi, sigma)  [sigma = sqrt(ss), :58-60] */
     SSME_MODEL_SVOL_LEVERAGE = 1, /* svol_leverage, test/test_pswarm.cpp:80-134;
                                      theta = (phi, mu, sigma, rho); covariate z_t = y_{t-1} */
-    SSME_MODEL_LIN_GAUSS = 2      /* x' = phi x + sigma e, y ~ N(x, tau^2); theta = (phi, sigma, tau).
+    SSME_MODEL_LIN_GAUSS = 2,     /* x' = phi x + sigma e, y ~ N(x, tau^2); theta = (phi, sigma, tau).
                                      Not in the reference: exact-Kalman correctness anchor.  */
+    SSME_MODEL_USER0 = 3          /* the model compiled in from a user header (ssme_amd/csrc/model_api.h: the counterpart of
+                                     deriving a class from BSFilter and overriding fSamp / logGEv / q1Samp,
+                                     example/univ_svol_bootstrap_filter.h:37-41); SSME_ERR_UNSUPPORTED in a library
+                                     built without one.  theta has ssme_pf_user_model_n_theta() entries.  */
 };
 
 /* resamplers (pf::resamplers::*, in-tree twin include/ssme/liu_west_filter.h:91-145) */
@@ -102,6 +106,8 @@ int ssme_pf_destroy(ssme_pf_handle h);
  * over the chip (profiles/r02_tile_sweep.txt).  It reads the BANK, not the handle: callers that split a bank over GPUs or
  * handles pass n_filters_total (or this value as tile_particles) so that results do not depend on the split. */
 int ssme_pf_default_tile(int32_t n_particles, int32_t bank_filters);
+/* Length of theta for SSME_MODEL_USER0, or 0 when this library was built without a user model. */
+int ssme_pf_user_model_n_theta(void);
 
 /* UNTRANSFORMED parameters, as the reference's model ctors receive them from
  * pack::get_untrans_params (univ_svol_bootstrap_filter.h:55-61).  theta is

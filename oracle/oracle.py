@@ -224,6 +224,33 @@ def default_tile(n, n_filters=1):
     return 2048
 
 
+class UserModelFilter:
+    """Kernel-matched oracle filter (mode B) whose MODEL is given by Python callbacks -- the mirror of the device's model
+    extension point (ssme_amd/csrc/model_api.h, SSME_MODEL_USER0): prop(x, zn, zcov) -> x', logg(y, x) -> log g, init_sd = the
+    standard deviation of the t = 0 draw.  The callbacks restate the user model's operation sequence with THIS module's
+    libm-free functions (exp_t, log, ...), independently of the device header."""
+
+    def __init__(self, n, seed, init_sd, prop, logg, rep=0, resampler=RESAMP_MULTINOMIAL, resamp_sched=1, tile=None, bad=False):
+        self.n = int(n)
+        self.tile = default_tile(self.n) if tile is None else int(tile)
+        self.nt = (self.n + self.tile - 1) // self.tile
+        L = lib()
+        self._prop = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_double)(prop)      # kept alive with the object
+        self._logg = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double)(logg)
+        L.orc_pf_create_user.restype = C.c_void_p
+        L.orc_pf_create_user.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_double, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_int]
+        self._h = L.orc_pf_create_user(self.n, resampler, resamp_sched, seed, rep, float(init_sd), int(bool(bad)),
+                                       C.cast(self._prop, C.c_void_p), C.cast(self._logg, C.c_void_p), self.tile)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_pf_destroy(self._h)
+            self._h = None
+
+    step = None      # filled in below from Filter (same handle type)
+
+
 class Filter:
     """Kernel-matched oracle filter (mode B), one replicate.  tile: particles per tile (None: the device's default by N)."""
 
@@ -381,3 +408,8 @@ def lw_ref_run(n, y, z, seed=1, delta=0.99, transforms=LW_TRANSFORMS, lo=LW_PRIO
     ll = lib().orc_lw_ref_run(n, _i32p(tr), _dp(lo), _dp(hi), float(delta), _dp(y), _dp(z), y.size, seed, _dp(per), _dp(means),
                               int(form), int(resamp_sched))
     return ll, per, means
+
+
+for _name in ("reset", "step", "loglik", "run_series", "state", "expectation"):
+    if hasattr(Filter, _name):
+        setattr(UserModelFilter, _name, getattr(Filter, _name))

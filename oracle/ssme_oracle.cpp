@@ -289,13 +289,20 @@ const double POS_INF = std::numeric_limits<double>::infinity();
 // Models (kernel-matched form).  theta is UNTRANSFORMED, as the reference's model ctors
 // receive it after pack::get_untrans_params (univ_svol_bootstrap_filter.h:55-61).
 // ---------------------------------------------------------------------------------------
-enum { MODEL_SVOL = 0, MODEL_SVOL_LEVERAGE = 1, MODEL_LIN_GAUSS = 2 };
+enum { MODEL_SVOL = 0, MODEL_SVOL_LEVERAGE = 1, MODEL_LIN_GAUSS = 2, MODEL_USER0 = 3 };
 enum { RESAMP_MULTINOMIAL = 0, RESAMP_SYSTEMATIC = 1, RESAMP_STRATIFIED = 2, RESAMP_MULTINOMIAL_IID = 3 };
+
+// MODEL_USER0: the device's model extension point (ssme_amd/csrc/model_api.h) mirrored by CALLBACKS -- the test that defines a
+// user model for the device restates it independently (in Python, through ctypes) and hands the restatement in here
+typedef double (*user_prop_fn)(double x, double zn, double zcov);
+typedef double (*user_logg_fn)(double y, double x);
 
 struct ModelConst {          // derived once per replicate on the host, in this op order
     int model;
     double a0, a1, a2, a3, a4, a5;  // meaning depends on model, see derive()
     int bad;                        // 1 -> logG == -inf (e.g. beta <= 0)
+    user_prop_fn u_prop = nullptr;  // MODEL_USER0 only
+    user_logg_fn u_logg = nullptr;
 };
 
 ModelConst derive(int model, const double* th) {
@@ -332,6 +339,7 @@ inline double m_init(const ModelConst& c, double zn) { return zn * c.a2; }
 
 // fSamp (univ_svol_bootstrap_filter.h:74-79; test_pswarm.cpp:90-97)
 inline double m_prop(const ModelConst& c, double x, double zn, double zcov) {
+    if (c.model == MODEL_USER0) return c.u_prop(x, zn, zcov);
     if (c.model == MODEL_SVOL_LEVERAGE) {
         const double e = o_exp_t(-0.5 * x);
         const double mean = (c.a1 + c.a0 * (x - c.a1)) + (c.a4 * zcov) * e;
@@ -346,6 +354,7 @@ inline double m_prop(const ModelConst& c, double x, double zn, double zcov) {
 // evalUnivNorm returns -inf when s <= 0 [pf-recollection]; mirrored by `bad` and by the
 // underflow guard (s == 0 in fp64 when log s < -745.13).
 inline double m_logg(const ModelConst& c, double y, double x) {
+    if (c.model == MODEL_USER0) return c.bad ? NEG_INF : c.u_logg(y, x);
     if (c.model == MODEL_LIN_GAUSS) {
         if (c.bad) return NEG_INF;
         const double d = (y - x) * c.a4;
@@ -1148,6 +1157,16 @@ void orc_quantize(const double* x, int sc, uint64_t* q, long n) { for (long i = 
 
 void* orc_pf_create(int model, int N, int resamp, int rs, uint64_t seed, uint32_t rep, const double* theta, int tile) {
     Filter* f = new Filter(); f->bootstrap_draws = true; f->tile = tile; f->init(model, N, resamp, rs, seed, rep, theta); return f;
+}
+// a filter whose model is given by callbacks (MODEL_USER0): init_sd = the sd of the t = 0 draw x_0 = init_sd * z; bad: logG = -inf
+void* orc_pf_create_user(int N, int resamp, int rs, uint64_t seed, uint32_t rep, double init_sd, int bad, user_prop_fn prop, user_logg_fn logg, int tile) {
+    Filter* f = new Filter(); f->bootstrap_draws = true; f->tile = tile;
+    const double th[3] = {1.0, 0.5, 0.1};                  // placeholder for init(): the constants are replaced below
+    f->init(MODEL_SVOL, N, resamp, rs, seed, rep, th);
+    f->model = MODEL_USER0;
+    f->mc = ModelConst{};
+    f->mc.model = MODEL_USER0; f->mc.a2 = init_sd; f->mc.bad = bad; f->mc.u_prop = prop; f->mc.u_logg = logg;
+    return f;
 }
 void orc_pf_destroy(void* h) { delete (Filter*)h; }
 void orc_pf_reset(void* h) { ((Filter*)h)->reset(); }

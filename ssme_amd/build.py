@@ -110,5 +110,26 @@ def _compile(extra, target, verbose):
             raise RuntimeError(f"kernel {name} uses scratch memory: {st}")
 
 
+def build_user_model(header, name, verbose=False):
+    """The library with ONE user model compiled in as SSME_MODEL_USER0 (ssme_amd/csrc/model_api.h): header = a C++ header
+    defining `struct ssme_user_model0`.  Returns build/user/libssme_pf_<name>.so; use it with SSME_PF_LIB=<that path>."""
+    header = os.path.abspath(header)
+    if not os.path.exists(header):
+        raise FileNotFoundError(header)
+    out_dir = os.path.join(os.path.dirname(HERE), "build", "user")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, f"libssme_pf_{name}.so")
+    import hashlib
+    with open(header, "rb") as f:
+        tag = hashlib.sha256(f.read() + source_hash().encode()).hexdigest()
+    stamp = out + ".srchash"
+    if os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == tag:
+        return out
+    build(force=True, verbose=verbose, extra=(f'-DSSME_USER_MODEL_HEADER="{header}"',), out=out)
+    with open(stamp, "w") as f:
+        f.write(tag + "\n")
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)

@@ -133,6 +133,9 @@ static int ceil_log2(int n) { int k = 0; while ((1ll << k) < n) ++k; return k; }
 // Derived constants; operation order mirrors oracle/ssme_oracle.cpp derive().
 static ModelConst derive(int model, const double* th) {
     ModelConst c{};
+#if SSME_HAS_USER_MODEL
+    if (model == SSME_MODEL_USER0) return ssme_user_model0::derive(th);
+#endif
     if (model == SSME_MODEL_SVOL) {            // (beta, phi, sigma)
         const double beta = th[0], phi = th[1], sigma = th[2];
         c.a0 = phi; c.a1 = sigma;
@@ -159,7 +162,12 @@ static ModelConst derive(int model, const double* th) {
 }
 
 constexpr int kStepGammaChunk = 64;
-static int n_theta_of(int model) { return model == SSME_MODEL_SVOL_LEVERAGE ? 4 : 3; }
+static int n_theta_of(int model) {
+#if SSME_HAS_USER_MODEL
+    if (model == SSME_MODEL_USER0) return ssme_user_model0::n_theta;
+#endif
+    return model == SSME_MODEL_SVOL_LEVERAGE ? 4 : 3;
+}
 static bool logw_needed(ssme_pf_handle h) { return h->keep_logw || h->cfg.resamp_sched > 1; }
 
 // arguments of the step that reads buffers `cur` and writes `cur ^ 1`
@@ -290,6 +298,9 @@ static void launch_step_on(ssme_pf_handle h, const StepArgs& a, dim3 grid) {
     switch (h->cfg.model) {
         case SSME_MODEL_SVOL: launch_step_grid<MODEL_SVOL>(h, a, grid); break;
         case SSME_MODEL_SVOL_LEVERAGE: launch_step_grid<MODEL_SVOL_LEVERAGE>(h, a, grid); break;
+#if SSME_HAS_USER_MODEL
+        case SSME_MODEL_USER0: launch_step_grid<MODEL_USER0>(h, a, grid); break;
+#endif
         default: launch_step_grid<MODEL_LIN_GAUSS>(h, a, grid); break;
     }
 }
@@ -387,6 +398,9 @@ static void enqueue_series_small(ssme_pf_handle h, int T, bool has_z) {
     switch (h->cfg.model) {
         case SSME_MODEL_SVOL: launch_small_m<MODEL_SVOL>(h, a, T); break;
         case SSME_MODEL_SVOL_LEVERAGE: launch_small_m<MODEL_SVOL_LEVERAGE>(h, a, T); break;
+#if SSME_HAS_USER_MODEL
+        case SSME_MODEL_USER0: launch_small_m<MODEL_USER0>(h, a, T); break;
+#endif
         default: launch_small_m<MODEL_LIN_GAUSS>(h, a, T); break;
     }
     h->cur = 1;
@@ -480,7 +494,8 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     if (!cfg || !out) return SSME_ERR_INVALID_ARG;
     *out = nullptr;
     if (cfg->n_particles < 1 || cfg->n_filters < 1 || cfg->n_filters > 65535) return SSME_ERR_INVALID_ARG;
-    if (cfg->model < 0 || cfg->model > SSME_MODEL_LIN_GAUSS) return SSME_ERR_INVALID_ARG;
+    if (cfg->model == SSME_MODEL_USER0 && !SSME_HAS_USER_MODEL) return SSME_ERR_UNSUPPORTED;   // this library was built without a user model (model_api.h)
+    if (cfg->model < 0 || cfg->model > SSME_MODEL_USER0) return SSME_ERR_INVALID_ARG;
     if (cfg->resampler < 0 || cfg->resampler > SSME_RESAMP_MULTINOMIAL_IID) return SSME_ERR_INVALID_ARG;
     if (cfg->resamp_sched < 1) return SSME_ERR_INVALID_ARG;
     if (cfg->dtype != SSME_F64 && cfg->dtype != SSME_F32) return SSME_ERR_INVALID_ARG;
@@ -585,6 +600,13 @@ int ssme_pf_destroy(ssme_pf_handle h) {
 }
 
 int ssme_pf_create(const ssme_pf_config* cfg, ssme_pf_handle* out) { return create_impl(cfg, 0, 0, out); }
+int ssme_pf_user_model_n_theta(void) {
+#if SSME_HAS_USER_MODEL
+    return ssme_user_model0::n_theta;
+#else
+    return 0;
+#endif
+}
 int ssme_pf_default_tile(int32_t n_particles, int32_t bank_filters) { return default_tile(n_particles, bank_filters < 1 ? 1 : bank_filters); }
 
 // ---- particle-sharded filter: one filter of cfg->n_particles particles over `world` GPUs ------------------------------

@@ -21,6 +21,7 @@
 // tree, search strategy and block shape.
 #pragma once
 #include "ssme_math.h"
+#include "model_api.h"
 
 namespace ssme {
 
@@ -39,7 +40,6 @@ constexpr int kStageTiles = 3;             // cdf tiles staged in LDS per output
 constexpr int kEShift = 35;                // exponential spacings: qE = rne(E * 2^35)
 constexpr int kTileShift = 41;             // tile-local fixed point: q = rne(exp(logw - m_tile) * 2^41), tile sums <= 2^52
 
-enum { MODEL_SVOL = 0, MODEL_SVOL_LEVERAGE = 1, MODEL_LIN_GAUSS = 2 };
 enum { RESAMP_MULTINOMIAL = 0, RESAMP_SYSTEMATIC = 1, RESAMP_STRATIFIED = 2, RESAMP_MULTINOMIAL_IID = 3 };
 
 #define SSME_HALF_LOG_2PI 0.91893853320467274178
@@ -52,13 +52,6 @@ enum { RESAMP_MULTINOMIAL = 0, RESAMP_SYSTEMATIC = 1, RESAMP_STRATIFIED = 2, RES
 #define ABL(a, bit) 0
 #define STAMP(a, i) do {} while (0)
 #endif
-
-// Derived per-filter constants (host computes them with the same ssme_math functions).
-struct ModelConst {
-    double a0, a1, a2, a3, a4;
-    int32_t bad;
-    int32_t pad;
-};
 
 // Per-filter scalars living in device memory.
 struct FilterScalars {
@@ -255,6 +248,9 @@ __device__ __forceinline__ void block_scan_f64(const double (&q)[NK][2], double 
 // ---------------------------------------------------------------------------------------
 template <int MODEL>
 __device__ __forceinline__ double model_prop(const ModelConst& c, double x, double zn, double zcov, const ExpTabEntry* etab) {
+#if SSME_HAS_USER_MODEL
+    if constexpr (MODEL == MODEL_USER0) return ssme_user_model0::prop(c, x, zn, zcov, etab);      // model_api.h
+#endif
     if (MODEL == MODEL_SVOL_LEVERAGE) {   // test/test_pswarm.cpp:90-97
         const double e = dexp_scaled_t(-0.5 * x, 0, etab);
         const double mean = (c.a1 + c.a0 * (x - c.a1)) + (c.a4 * zcov) * e;
@@ -265,6 +261,9 @@ __device__ __forceinline__ double model_prop(const ModelConst& c, double x, doub
 
 template <int MODEL>
 __device__ __forceinline__ double model_logg(const ModelConst& c, double y, double x, const ExpTabEntry* etab) {
+#if SSME_HAS_USER_MODEL
+    if constexpr (MODEL == MODEL_USER0) return c.bad ? -dinf() : ssme_user_model0::logg(c, y, x, etab);
+#endif
     if (MODEL == MODEL_LIN_GAUSS) {
         const double d = (y - x) * c.a4;
         const double v = (-c.a3 - SSME_HALF_LOG_2PI) - 0.5 * (d * d);

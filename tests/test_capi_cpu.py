@@ -40,7 +40,7 @@ def test_strerror_and_null_handling():
 
 
 @pytest.mark.parametrize("field,value,status", [
-    ("n_particles", 0, 1), ("n_filters", 0, 1), ("model", 9, 1), ("resampler", 7, 1), ("resamp_sched", 0, 1),
+    ("n_particles", 0, 1), ("n_filters", 0, 1), ("model", 9, 1), ("model", 3, 3), ("resampler", 7, 1), ("resamp_sched", 0, 1),
     ("dtype", 2, 1), ("n_particles", (1 << 25) + 1, 3),
 ])
 def test_create_validates_config(field, value, status):
@@ -51,6 +51,22 @@ def test_create_validates_config(field, value, status):
     h = C.c_void_p()
     assert _capi.lib().ssme_pf_create(C.byref(cfg), C.byref(h)) == status
     assert not h.value
+
+
+def test_user_model_extension_point_builds():
+    """ssme_amd/csrc/model_api.h: a library with a user model compiled in (tests/models/svol_student_t.h) builds with the same
+    resource checks as the stock one (no scratch, no spills), exports the whole C ABI and reports the model's theta length;
+    the stock library reports none and refuses the model id (no GPU needed for either)."""
+    from ssme_amd import build, _capi
+    so = build.build_user_model(os.path.join(ROOT, "tests", "models", "svol_student_t.h"), "student_t")
+    L = C.CDLL(so)
+    for n in _header_functions():
+        assert hasattr(L, n)
+    assert L.ssme_pf_user_model_n_theta() == 4
+    assert _capi.lib().ssme_pf_user_model_n_theta() == 0
+    cfg = _capi.Config(model=_capi.MODEL_USER0, n_particles=100, n_filters=1, dtype=0, resampler=0, resamp_sched=1, seed=1, device=0)
+    h = C.c_void_p()
+    assert _capi.lib().ssme_pf_create(C.byref(cfg), C.byref(h)) == _capi.ERR_UNSUPPORTED
 
 
 def test_no_cpu_fallback_without_gpu():

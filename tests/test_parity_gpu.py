@@ -5,8 +5,12 @@ Bar: particles, log-weights, the exact integer cdf and AN
 per-step and series log-likelihood |delta| <= 1e-9 (observed 0: the device math mirrors the oracle's
 IEEE operation sequence).  At BASELINE sizes: size-independent properties (Kalman anchor, replicate
 independence, graph == eager, step API == series API)."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -303,6 +307,56 @@ def test_a_filter_does_not_depend_on_how_its_bank_is_split(sa, oracle, spy):
     alone = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, seed, first_filter_id=13)      # undeclared: another tile, other bits
     assert alone.tile == 512
     alone.close()
+
+
+def _student_t_oracle(oracle, n, seed, rep, resampler, tile, th=(1.1, 0.95, 0.25, 7.0)):
+    """tests/models/svol_student_t.h restated with the oracle's own libm-free functions (the operation order is the header's)."""
+    import ctypes, math
+    libm = ctypes.CDLL("libm.so.6")               # the header's std::lgamma is libm's (CPython's math.lgamma is its own code)
+    libm.lgamma.restype = ctypes.c_double
+    libm.lgamma.argtypes = [ctypes.c_double]
+    beta, phi, sigma, nu = th
+    e1 = lambda f, v: float(f(np.array([v]))[0])
+    a2 = sigma / math.sqrt(1.0 - phi * phi)
+    a3 = ((libm.lgamma(0.5 * (nu + 1.0)) - libm.lgamma(0.5 * nu)) - 0.5 * e1(oracle.log, nu * math.pi)) - e1(oracle.log, beta)
+    a4 = 1.0 / (nu * (beta * beta))
+    a5 = 0.5 * (nu + 1.0)
+    prop = lambda x, zn, zcov: phi * x + zn * sigma
+    logg = lambda y, x: (a3 - 0.5 * x) - a5 * e1(oracle.log, 1.0 + ((y * y) * a4) * e1(oracle.exp_t, -x))
+    return oracle.UserModelFilter(n, seed, a2, prop, logg, rep=rep, resampler=resampler, tile=tile)
+
+
+@pytest.mark.parametrize("n,rs,tile", [(1500, 0, 2048), (6000, 0, 512), (6000, 1, 2048)])
+def test_user_model_extension_point_bit_exact_vs_oracle(sa, oracle, spy, tmp_path, n, rs, tile):
+    """a FOURTH model (SVOL with Student-t observations, tests/models/svol_student_t.h) compiled in through the
+    extension point of ssme_amd/csrc/model_api.h -- one header, no kernel edited -- runs as SSME_MODEL_USER0 through the C ABI
+    (one-tile series kernel, tiled step kernel, both resamplers) and agrees with the oracle's callback-driven restatement to
+    the bit: particles, log-weights, integer cdf, ancestors, per-step and series log-likelihood.  The stock library refuses
+    the model id (SSME_ERR_UNSUPPORTED)."""
+    import subprocess, sys
+    from ssme_amd import build, _capi
+    with pytest.raises(_capi.SsmeError) as ei:
+        sa.ParticleFilterBank(sa.MODEL_USER0, 1000, 1, 1)
+    assert ei.value.status == _capi.ERR_UNSUPPORTED and _capi.lib().ssme_pf_user_model_n_theta() == 0
+    so = build.build_user_model(os.path.join(ROOT, "tests", "models", "svol_student_t.h"), "student_t")
+    out = str(tmp_path / "um.npz")
+    T, seed = 10, 33
+    env = dict(os.environ, SSME_PF_LIB=so)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tests", "user_model_worker.py"), out, str(n), str(T), str(seed), str(rs), str(tile)],
+                   env=env, check=True, timeout=600)
+    r = np.load(out)
+    of = _student_t_oracle(oracle, n, seed, 1, rs, tile)
+    lls = [of.step(spy[t]) for t in range(T)]
+    assert_bits_equal(r["lls"], lls, "user model: per-step log conditional likelihoods")
+    so_ = of.state()
+    assert_bits_equal(r["x"], so_["x"], "user model: particles")
+    assert_bits_equal(r["logw"], so_["logw"], "user model: log-weights")
+    np.testing.assert_array_equal(r["cdf"], so_["cdf"])
+    np.testing.assert_array_equal(r["anc"], so_["anc"])
+    for rep in range(2):
+        ll, per = _student_t_oracle(oracle, n, seed, rep, rs, tile).run_series(spy[:T])
+        assert r["series"][rep] == ll
+        assert_bits_equal(r["per_step"][rep], per, "user model: series per-step")
 
 
 def test_split_level2_with_1024_particle_tiles(sa, oracle, spy):
