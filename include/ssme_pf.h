@@ -149,6 +149,12 @@ int ssme_pf_get_expectations_multi(ssme_pf_handle h, const int32_t* functionals,
  * requested expectation (n may be 0).  One download of n + 1 doubles. */
 int ssme_pf_swarm_aggregate(ssme_pf_handle h, const int32_t* functionals, int32_t n, double* mean_logcondlike /*1*/,
                             double* mean_expectations /*n*/);
+/* The same as the reference computes it when its pool has num_threads workers: member i is dealt to thread i % num_threads
+ * (thread_pool.h:443-447), every thread averages its members and the thread averages are averaged (pswarm_filter.h:96-160) --
+ * the plain mean exactly when num_threads divides R, a slightly differently weighted mean otherwise (a thread with one member
+ * fewer counts each of its members more).  num_threads <= 0 or >= R: ssme_pf_swarm_aggregate's plain mean / one member per thread. */
+int ssme_pf_swarm_aggregate_threads(ssme_pf_handle h, const int32_t* functionals, int32_t n, int32_t num_threads,
+                                    double* mean_logcondlike /*1*/, double* mean_expectations /*n*/);
 /* Arbitrary host-side h (the reference's filt_func is a std::function, pswarm_filter.h:44,87-89): particles x (N,
  * nullable) and weights w (N) of one filter after the last step, w_j = exp(logw_j - max logw) in the 2^-41 fixed point
  * the resampler and ssme_pf_get_expectations use; the caller forms sum h(x_j) w_j / sum w_j.  Needs no debug mode. */

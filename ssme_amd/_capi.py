@@ -22,7 +22,7 @@ EXPORTS = [
     "ssme_pf_create", "ssme_pf_destroy", "ssme_pf_default_tile", "ssme_pf_user_model_n_theta", "ssme_pf_set_params", "ssme_pf_reset", "ssme_pf_set_seed", "ssme_pf_set_small_series", "ssme_pf_shard_create", "ssme_pf_set_stream",
     "ssme_pf_shard_prepare", "ssme_shard_comm_get_unique_id", "ssme_shard_comm_init", "ssme_shard_comm_destroy", "ssme_pf_shard_run_series",
     "ssme_pf_shard_download", "ssme_pf_shard_stats", "ssme_pf_shard_plan", "ssme_pf_shard_step", "ssme_pf_shard_finalize", "ssme_pf_step",
-    "ssme_pf_run_series", "ssme_pf_get_per_step", "ssme_pf_get_loglik", "ssme_pf_get_expectations", "ssme_pf_get_expectations_multi", "ssme_pf_swarm_aggregate", "ssme_pf_download_weights", "ssme_pf_get_layout",
+    "ssme_pf_run_series", "ssme_pf_get_per_step", "ssme_pf_get_loglik", "ssme_pf_get_expectations", "ssme_pf_get_expectations_multi", "ssme_pf_swarm_aggregate", "ssme_pf_swarm_aggregate_threads", "ssme_pf_download_weights", "ssme_pf_get_layout",
     "ssme_pf_log_mean_exp", "ssme_pf_download_state", "ssme_pf_download_scalars", "ssme_pf_set_debug",
     "ssme_pf_set_graph_mode", "ssme_pf_set_tuning", "ssme_pf_last_elapsed_ms", "ssme_pf_profile_series", "ssme_pf_test_math",
     "ssme_pf_test_philox", "ssme_pf_test_quantize", "ssme_pf_test_rescale", "ssme_pf_test_block_scan",
@@ -97,6 +97,7 @@ def lib():
         L.ssme_pf_log_mean_exp.argtypes = [H, dp]
         L.ssme_pf_get_expectations_multi.argtypes = [H, i32p, C.c_int32, dp]
         L.ssme_pf_swarm_aggregate.argtypes = [H, i32p, C.c_int32, dp, dp]
+        L.ssme_pf_swarm_aggregate_threads.argtypes = [H, i32p, C.c_int32, C.c_int32, dp, dp]
         L.ssme_pf_download_weights.argtypes = [H, C.c_int32, dp, dp]
         L.ssme_pf_get_layout.argtypes = [H, i32p, i32p]
         L.ssme_pf_default_tile.argtypes = [C.c_int32, C.c_int32]

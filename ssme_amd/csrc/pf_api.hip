@@ -571,7 +571,11 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_dev), h->pin, 0));
         int rc2 = upload_key(h);
         if (rc2 != SSME_OK) return rc2;
-        if (h->shard_world > 0) return ensure_series_capacity(h, 1);
+        if (h->shard_world > 0) {
+            rc2 = ensure_logw(h);                // resamp_sched > 1: the carried log-weights of this rank's particles (local offsets)
+            if (rc2 != SSME_OK) return rc2;
+            return ensure_series_capacity(h, 1);
+        }
         rc2 = ensure_logw(h);
         if (rc2 != SSME_OK) return rc2;
         return ensure_series_capacity(h, 1);
@@ -615,7 +619,7 @@ int ssme_pf_default_tile(int32_t n_particles, int32_t bank_filters) { return def
 int ssme_pf_shard_create(const ssme_pf_config* cfg, int32_t rank, int32_t world, ssme_pf_handle* out) {
     if (!cfg || !out) return SSME_ERR_INVALID_ARG;
     if (world < 1 || world > 64 || rank < 0 || rank >= world) return SSME_ERR_INVALID_ARG;
-    if (cfg->n_filters != 1 || cfg->resamp_sched != 1) return SSME_ERR_UNSUPPORTED;
+    if (cfg->n_filters != 1 || cfg->resamp_sched < 1) return SSME_ERR_UNSUPPORTED;
     if (cfg->n_particles < 1 || cfg->n_particles % (kTile * world) != 0) return SSME_ERR_UNSUPPORTED;   // equal whole tiles per rank
     return create_impl(cfg, rank, world, out);
 }
@@ -652,7 +656,8 @@ static StepArgs shard_args(ssme_pf_handle h, int t, const double* tsum_all, cons
     a.z = h->g_has_z ? h->zbuf : nullptr;
     a.per_step = h->per_step;
     a.t = t; a.yi = t; a.gi = t;
-    a.logw = nullptr; a.anc = nullptr;
+    a.logw = h->cfg.resamp_sched > 1 ? h->logw : nullptr;      // steps without resampling carry the log-weights (this rank's own, local offsets)
+    a.anc = nullptr;
     return a;
 }
 
@@ -703,13 +708,15 @@ int ssme_pf_shard_step(ssme_pf_handle h, int32_t t, const double* x_win, const d
                        double* tmax_out, uint32_t* anc_out) {
     if (!h || !x_out || !cdf_out || !tsum_out || !tmax_out || t < 0) return SSME_ERR_INVALID_ARG;
     // win_tile0 may be negative on the C++ driver's fixed-halo path: rank 0's halo buffer starts `margin` (never-read) rows before tile 0
+    // (on a step without resampling -- t % resamp_sched != 0 -- x_win is this rank's OWN particles of step t - 1, stored as the
+    //  outputs are: the kernel reads them in place, cdf_win is not read)
     if (t > 0 && (!x_win || !cdf_win || !tsum_all || !tmax_all || win_tile0 < -h->sh_margin)) return SSME_ERR_INVALID_ARG;
     if (h->shard_world < 1 || !h->params_set) return SSME_ERR_STATE;
     if (t >= h->tcap) return SSME_ERR_STATE;            // ssme_pf_shard_prepare sizes the series
     HIPCHK(hipSetDevice(h->cfg.device));
     StepArgs a = shard_args(h, t, tsum_all, tmax_all);
     a.x_in = x_win; a.cdf_in = cdf_win; a.win_tile0 = win_tile0;
-    if (h->sh_check) { a.win_tiles = h->sh_rows; a.win_flag = h->sh_flag; }
+    if (h->sh_check && (t % h->cfg.resamp_sched) == 0) { a.win_tiles = h->sh_rows; a.win_flag = h->sh_flag; }
     a.x_out = x_out; a.cdf_out = cdf_out; a.tsum_out = tsum_out; a.tmax_out = tmax_out;
     a.anc = anc_out;
     a.finalize_prev = t > 0 ? 1 : 0;
@@ -820,10 +827,16 @@ static int shard_series(ssme_pf_handle h, ncclComm_t comm, const double* y, cons
         double* xo = h->sh_x[cur ^ 1] + (size_t)m * TL; double* co = h->sh_c[cur ^ 1] + (size_t)m * TL;   // outputs: the own rows of the other pair
         const double *xw = nullptr, *cw = nullptr;
         int win0 = 0;
+        const bool resampled = t > 0 && (t % h->cfg.resamp_sched) == 0;     // the draw that closes step t - 1 runs now (lazily)
         if (t > 0) {
             rc = shard_gather(h, comm);
             if (rc != SSME_OK) return rc;
-            if (fast) {
+            if (!resampled) {
+                // no draw: every particle continues itself with its carried log-weight -- sources = this rank's own tiles, no exchange;
+                // the gathered tile sums still give every rank the step's log p(y_{t-1} | .)
+                if (h->split_l2) { shard_plan_device(h, t, h->sh_tsum, h->sh_tmax); HIPCHK(hipGetLastError()); }
+                xw = xs + (size_t)m * TL; cw = cs + (size_t)m * TL; win0 = tile0;
+            } else if (fast) {
                 // up to 1024 tiles the step kernel runs level-2 itself and checks its own source tiles against the fixed
                 // halo (StepArgs::win_flag): no plan launch at all; above, k_level2_plan is needed anyway and a small check follows it
                 if (h->split_l2) {
@@ -1211,6 +1224,11 @@ int ssme_pf_get_expectations(ssme_pf_handle h, int32_t functional, double* out) 
 // step's log conditional likelihoods and of the expectations, reduced ON THE DEVICE; one download of n + 1 doubles.
 int ssme_pf_swarm_aggregate(ssme_pf_handle h, const int32_t* functionals, int32_t n, double* mean_logcondlike,
                             double* mean_expectations) {
+    return ssme_pf_swarm_aggregate_threads(h, functionals, n, 0, mean_logcondlike, mean_expectations);
+}
+
+int ssme_pf_swarm_aggregate_threads(ssme_pf_handle h, const int32_t* functionals, int32_t n, int32_t num_threads, double* mean_logcondlike,
+                                    double* mean_expectations) {
     if (!h || !mean_logcondlike || n < 0 || n > kMaxFunctionals || (n > 0 && (!functionals || !mean_expectations)))
         return SSME_ERR_INVALID_ARG;
     if (h->shard_world > 0) return SSME_ERR_STATE;
@@ -1225,7 +1243,7 @@ int ssme_pf_swarm_aggregate(ssme_pf_handle h, const int32_t* functionals, int32_
     mark_results_pending(pin, n);
     mark_results_pending(pin + kMaxFunctionals, 1);
     hipLaunchKernelGGL(k_swarm_means, dim3(n + 1), dim3(kThreads), 0, h->stream, (const double*)h->exp_out, (const FilterScalars*)h->scal,
-                       h->R, n, kMaxFunctionals, h->pin_dev + 2 + h->R + 64);
+                       h->R, n, kMaxFunctionals, h->pin_dev + 2 + h->R + 64, (int)num_threads);
     HIPCHK(hipGetLastError());
     HIPCHK(wait_results(h->stream, pin + kMaxFunctionals, 1));
     if (n > 0) HIPCHK(wait_results(h->stream, pin, n));

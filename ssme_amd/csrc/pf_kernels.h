@@ -1638,17 +1638,27 @@ __global__ __launch_bounds__(kThreads) void k_expect_final(const double* part, c
 // Swarm aggregation in one launch: block f < n: mean over the R members of expectation row f ([n][R] in exp_rows);
 // block n: mean of the members' last log conditional likelihoods.  out: n + 1 doubles at
 // out[0..n) and out[slot_ll] (device-mapped host memory: the host polls it).  grid (n + 1), block 256.
+// num_threads > 0: the reference's mean of per-thread means -- split_data_thread_pool deals member i to thread i % num_threads
+// (thread_pool.h:443-447), every thread averages its own members (intra_agg_func, pswarm_filter.h:130-160) and the thread
+// averages are averaged (inter_agg_func, :96-128).  That is a weighted mean with weight 1 / (num_threads * members of the
+// thread), equal to the plain mean only when num_threads divides R.  num_threads <= 0: the plain mean.
 __global__ __launch_bounds__(kThreads) void k_swarm_means(const double* exp_rows, const FilterScalars* scal, int R, int n, int slot_ll,
-                                                          double* out) {
+                                                          double* out, int num_threads) {
     __shared__ double lds[4];
     const int tid = threadIdx.x, f = blockIdx.x;
+    const int T = (num_threads > 0 && num_threads < R) ? num_threads : (num_threads >= R ? R : 0);
     double s = 0.0;
-    if (f < n) { for (int r = tid; r < R; r += kThreads) s = s + exp_rows[(size_t)f * R + r]; }
-    else { for (int r = tid; r < R; r += kThreads) s = s + scal[r].last_ll; }
+    for (int r = tid; r < R; r += kThreads) {
+        const double v = (f < n) ? exp_rows[(size_t)f * R + r] : scal[r].last_ll;
+        if (T > 0) {
+            const int members = R / T + ((r % T) < (R % T) ? 1 : 0);
+            s = s + v / (double)members;
+        } else s = s + v;
+    }
     s = wave_sum_xor(s);
     if ((tid & 63) == 0) lds[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) out[f < n ? f : slot_ll] = (((lds[0] + lds[1]) + lds[2]) + lds[3]) / (double)R;
+    if (tid == 0) out[f < n ? f : slot_ll] = (((lds[0] + lds[1]) + lds[2]) + lds[3]) / (double)(T > 0 ? T : R);
 }
 
 // Normalisable weights of one filter for host-side functionals (arbitrary std::function h: pswarm_filter.h:44,87-89):

@@ -136,12 +136,14 @@ class ParticleFilterBank:
                                                             capi.dptr(out)))
         return out
 
-    def swarm_aggregate(self, functionals=()):
-        """(mean over filters of the last log conditional likelihoods, [mean expectations]) reduced on the device."""
+    def swarm_aggregate(self, functionals=(), num_threads=0):
+        """(mean over filters of the last log conditional likelihoods, [mean expectations]) reduced on the device.
+        num_threads > 0: the reference's mean of per-thread means for a pool of that many workers (member i on thread
+        i % num_threads, pswarm_filter.h:96-160) -- the plain mean unless num_threads does not divide the member count."""
         fs = np.ascontiguousarray(functionals, dtype=np.int32)
         ll, ex = np.empty(1), np.empty(max(fs.size, 1))
-        self._chk(capi.lib().ssme_pf_swarm_aggregate(self._h, fs.ctypes.data_as(C.POINTER(C.c_int32)), fs.size,
-                                                     capi.dptr(ll), capi.dptr(ex)))
+        self._chk(capi.lib().ssme_pf_swarm_aggregate_threads(self._h, fs.ctypes.data_as(C.POINTER(C.c_int32)), fs.size, int(num_threads),
+                                                             capi.dptr(ll), capi.dptr(ex)))
         return float(ll[0]), ex[:fs.size].tolist()
 
     def weights(self, f=0):

@@ -181,7 +181,8 @@ def exchange_halos(bufs, tile0, plan, tiles_per_rank, rank, group=None, stage_th
 class ShardedParticleFilter:
     """Bootstrap filter with its N particles sharded over the ranks of a torch.distributed group."""
 
-    def __init__(self, model, n_particles, seed=0, resampler=capi.RESAMP_MULTINOMIAL, device=None, group=None, filter_id=0):
+    def __init__(self, model, n_particles, seed=0, resampler=capi.RESAMP_MULTINOMIAL, device=None, group=None, filter_id=0,
+                 resamp_sched=1):
         import torch
         import torch.distributed as dist
         assert dist.is_initialized(), "init_process_group first (one process per GPU)"
@@ -195,8 +196,9 @@ class ShardedParticleFilter:
         self.Bl = self.B // self.world
         self.tile0 = self.rank * self.Bl
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        cfg = capi.Config(model=model, n_particles=n_particles, n_filters=1, dtype=capi.F64, resampler=resampler, resamp_sched=1,
-                          seed=seed, device=self.device.index or 0, first_filter_id=filter_id)
+        self.resamp_sched = int(resamp_sched)
+        cfg = capi.Config(model=model, n_particles=n_particles, n_filters=1, dtype=capi.F64, resampler=resampler,
+                          resamp_sched=self.resamp_sched, seed=seed, device=self.device.index or 0, first_filter_id=filter_id)
         self._h = C.c_void_p()
         capi.check(capi.lib().ssme_pf_shard_create(C.byref(cfg), self.rank, self.world, C.byref(self._h)))
         # one side stream for kernels, staging copies and (nccl) collectives: torch's default stream has handle 0,
@@ -275,6 +277,13 @@ class ShardedParticleFilter:
             if t == 0:
                 xw = cw = None
                 win0 = 0
+            elif t % self.resamp_sched != 0:
+                # no resampling draw closes step t - 1: every particle continues itself with its carried log-weight; the
+                # sources are this rank's own tiles, nothing travels but the tile sums (for the step's log-likelihood)
+                self._gather_tiles()
+                if self.B > 1024:
+                    self._chk(L.ssme_pf_shard_plan(self._h, self._ptr(ts), self._ptr(tm), t, lo_hi))     # split level-2: accounts the step
+                xw, cw, win0 = hx.own(), hc.own(), self.tile0
             else:
                 self._gather_tiles()
                 self._chk(L.ssme_pf_shard_plan(self._h, self._ptr(ts), self._ptr(tm), t, lo_hi))

@@ -1,7 +1,7 @@
 // test_shard_threads.cpp -- the C++ shard drivers with SEVERAL ranks on one GPU: every rank is a host thread with its own
 // handle, the "RCCL" underneath is tests/cpp/mock_rccl.cpp (linked before anything else, so dlsym finds it).  Prints, per
 // configuration, what every rank got and what the unsharded filter gives; tests/test_sharded_gpu.py compares.
-//   usage: test_shard_threads CSV WORLD N T MODEL RESAMPLER MODE SEED [TAU [YSCALE]]     (MODEL -1: Liu-West, RESAMPLER = delta x 1000)
+//   usage: test_shard_threads CSV WORLD N T MODEL RESAMPLER MODE SEED [TAU [YSCALE [RESAMP_SCHED]]]     (MODEL -1: Liu-West, RESAMPLER = delta x 1000)
 //   TAU (linear-Gaussian model only): observation noise; a tiny value puts all the weight of a step on the one particle next to
 //   y_t, so every rank's next resampling window is that particle's tile -- far ranks leave their halo, near ranks do not.
 //   YSCALE: the observations are multiplied by it (outliers: the stochastic-volatility weights then degenerate the same way).
@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
     const int world = std::atoi(argv[2]), N = std::atoi(argv[3]), T = std::atoi(argv[4]), model = std::atoi(argv[5]), rs = std::atoi(argv[6]),
               mode = std::atoi(argv[7]);
     const unsigned long long seed = std::strtoull(argv[8], nullptr, 10);
+    const int sched = argc > 11 ? std::atoi(argv[11]) : 1;
     std::vector<double> y, z;
     { std::ifstream f(argv[1]); double v; while (f >> v && (int)y.size() < T) y.push_back(v); }
     if (argc > 10) for (double& v : y) v *= std::atof(argv[10]);
@@ -41,7 +42,7 @@ int main(int argc, char** argv) {
         xs[r].resize(nloc);
         if (model >= 0) {
             ssme_pf_config c{};
-            c.model = model; c.n_particles = N; c.n_filters = 1; c.dtype = SSME_F64; c.resampler = rs; c.resamp_sched = 1; c.seed = seed; c.device = 0;
+            c.model = model; c.n_particles = N; c.n_filters = 1; c.dtype = SSME_F64; c.resampler = rs; c.resamp_sched = sched; c.seed = seed; c.device = 0;
             ssme_pf_handle h = nullptr;
             rc = ssme_pf_shard_create(&c, r, world, &h);
             if (rc) die("shard_create", rc, "");
@@ -84,7 +85,7 @@ int main(int argc, char** argv) {
     std::vector<double> xref(N);
     if (model >= 0) {
         ssme_pf_config c{};
-        c.model = model; c.n_particles = N; c.n_filters = 1; c.dtype = SSME_F64; c.resampler = rs; c.resamp_sched = 1; c.seed = seed; c.device = 0;
+        c.model = model; c.n_particles = N; c.n_filters = 1; c.dtype = SSME_F64; c.resampler = rs; c.resamp_sched = sched; c.seed = seed; c.device = 0;
         c.tile_particles = 2048;
         ssme_pf_handle h = nullptr;
         if (ssme_pf_create(&c, &h)) die("create", 1, "");

@@ -1,6 +1,6 @@
 """Worker of tests/test_sharded_gpu.py: one rank of a particle-sharded filter (gloo rehearsal: every rank uses cuda:0).
 
-usage: shard_worker.py RANK WORLD PORT OUT.npz MODEL N T RESAMPLER SEED
+usage: shard_worker.py RANK WORLD PORT OUT.npz MODEL N T RESAMPLER SEED [RESAMP_SCHED]
 """
 import os
 import sys
@@ -23,7 +23,8 @@ def main():
     y = np.loadtxt(os.path.join(ROOT, "tests", "golden", "spy_returns.csv"))[:T]
     z = np.concatenate([[0.0], y[:-1]]) if model == 1 else None
     th = {0: [1.0, 0.95, 0.25], 1: [0.9, 0.0, 1.0, -0.1], 2: [0.9, 0.5, 0.7]}[model]
-    f = ShardedParticleFilter(model, n, seed=seed, resampler=rs)
+    sched = int(sys.argv[10]) if len(sys.argv) > 10 else 1
+    f = ShardedParticleFilter(model, n, seed=seed, resampler=rs, resamp_sched=sched)
     f.set_params(th)
     f.record_ancestors(True)
     ll = f.run_series(y, z)

@@ -418,6 +418,30 @@ def test_expectations(sa, oracle, spy):
     bank.close()
 
 
+def test_swarm_aggregate_as_the_reference_pool_computes_it(sa, spy):
+    """pswarm_filter.h:96-160 + thread_pool.h:443-447: member i runs on thread i % num_threads, every thread averages its members,
+    the thread averages are averaged -- the plain mean only when num_threads divides the member count (VERDICT r2 missing 6)."""
+    R, T = 7, 3
+    rng = np.random.default_rng(1)
+    th = np.stack([rng.uniform(.8, .99, R), rng.uniform(-.1, .1, R), rng.uniform(.01, .1, R), rng.uniform(-.5, -.01, R)], axis=1)
+    bank = sa.ParticleFilterBank(sa.MODEL_SVOL_LEVERAGE, 700, R, 3)
+    bank.set_params(th)
+    for t in range(4):
+        lcl = bank.step(spy[t], 0.0 if t == 0 else spy[t - 1])
+    ex = bank.expectations_multi([0, 1])
+    plain_ll, plain_ex = bank.swarm_aggregate([0, 1])
+    assert abs(plain_ll - lcl.mean()) <= 1e-14 * abs(lcl.mean()) and np.allclose(plain_ex, ex.mean(axis=1), rtol=1e-13)
+    ll3, ex3 = bank.swarm_aggregate([0, 1], num_threads=T)
+    groups = [np.arange(R)[np.arange(R) % T == j] for j in range(T)]
+    want_ll = np.mean([lcl[g].mean() for g in groups])
+    want_ex = [np.mean([ex[f][g].mean() for g in groups]) for f in range(2)]
+    assert abs(ll3 - want_ll) <= 1e-13 * abs(want_ll) and np.allclose(ex3, want_ex, rtol=1e-13)
+    assert abs(ll3 - plain_ll) > 1e-9 * abs(plain_ll)                       # 7 members on 3 threads: not the plain mean
+    ll7, _ = bank.swarm_aggregate([0], num_threads=7)
+    assert abs(ll7 - plain_ll) <= 1e-14 * abs(plain_ll)
+    bank.close()
+
+
 def test_expectations_multi_weights_and_host_functionals(sa, oracle, spy):
     """All functionals of filter(y, z, fs) in one device pass; the (x, weights) download for arbitrary host-side h
     (pswarm_filter.h:44,87-89: h is a std::function) gives the same expectations without debug mode; several tiles."""

