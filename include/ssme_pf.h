@@ -223,8 +223,9 @@ int ssme_pf_test_gamma(int32_t device, uint64_t seed, uint32_t rep, int32_t t, d
 /* ============================================================================================
  * Particle-sharded filter: ONE filter of cfg->n_particles particles over `world` GPUs,
  * one process per GPU.  Rank g owns tiles [g B/world, (g+1) B/world) (a tile = 2048 particles; n_particles must be a
- * multiple of 2048 world, at most 2^25; n_filters = 1, resamp_sched = 1).  Per time step the host side (ssme_amd/sharded.py over
- * torch.distributed) does:   all_gather of the tile sums / maxima  ->  ssme_pf_shard_plan (which source tiles each
+ * multiple of 2048 world, at most 2^25; n_filters = 1; any resamp_sched: a step without a resampling draw exchanges nothing
+ * but the tile sums and carries this rank's log-weights).  Per time step the host side (the C++ driver below, or
+ * ssme_amd/sharded.py over torch.distributed) does:   all_gather of the tile sums / maxima  ->  ssme_pf_shard_plan (which source tiles each
  * rank's resampling touches)  ->  exchange of those tiles (cdf + particles)  ->  ssme_pf_shard_step.
  * The level-2 arithmetic, the RNG counters (global particle index) and the Gamma tables (global tile id) are those of
  * the unsharded filter, so a sharded run is bit-identical to ssme_pf_run_series with the same N and seed.
@@ -325,7 +326,9 @@ int ssme_lw_last_elapsed_ms(ssme_lw_handle h, float* ms);
 const char* ssme_lw_last_error(ssme_lw_handle h);
 
 /* ---- particle-sharded Liu-West filter: ONE filter of cfg->n_particles particles over `world` GPUs (BASELINE.json configs[4]).
- * Rank g owns B/world consecutive tiles (n_particles a multiple of 2048 world, at most 2^25; n_filters = 1).  Per step the
+ * Rank g owns B/world consecutive tiles (n_particles a multiple of 2048 world, at most 2^25; n_filters = 1; resampling every
+ * step; both forms -- the SISR form, form = 1, has no k draw, so its stage 2 reads this rank's own stage-1 outputs and a step
+ * has ONE window exchange instead of two).  Per step the
  * host side (ssme_amd/sharded.py, ShardedLiuWest) gathers the tile sums / maxima of the second-stage weights, plans and
  * exchanges windows of (cdfB, x, theta) for the resampling draw (stage 1), gathers the first-stage tile sums / maxima and
  * the 14 moment partials per tile, runs ssme_lw_shard_mid on every rank (theta-bar, Cholesky factor: the moment sums are

@@ -1777,7 +1777,7 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
     if (cfg->n_particles < 1 || cfg->n_filters < 1 || cfg->n_filters > 65535) return SSME_ERR_INVALID_ARG;
     if (!(cfg->delta > 0.0 && cfg->delta <= 1.0)) return SSME_ERR_INVALID_ARG;
     if (cfg->form < 0 || cfg->form > 1 || cfg->resamp_sched < 0) return SSME_ERR_INVALID_ARG;
-    if (shard_world > 0 && (cfg->form != 0 || cfg->resamp_sched > 1)) return SSME_ERR_UNSUPPORTED;   // sharded: auxiliary form, every step
+    if (shard_world > 0 && cfg->resamp_sched > 1) return SSME_ERR_UNSUPPORTED;   // sharded: both forms, resampling every step
     for (int d = 0; d < kDP; ++d) {
         if (cfg->transforms[d] < 0 || cfg->transforms[d] > 3) return SSME_ERR_INVALID_ARG;     // parameters.h:283 invalid_argument
         if (!(cfg->prior_lo[d] <= cfg->prior_hi[d])) return SSME_ERR_INVALID_ARG;
@@ -2139,11 +2139,15 @@ int ssme_lw_shard_run_series(ssme_lw_handle h, void* nccl_comm, const double* y,
         LWNCCL(rccl().AllGather(momL, h->sh_mom_all, (size_t)Bl * 16, ncclDouble, comm, h->stream));
         LWNCCL(rccl().GroupEnd());
         // the plan of the k draw first: above 1024 tiles it provides the (m, S) that mid turns into the first-stage log-sum-exp
-        if (h->split_l2) { lw_launch_plan(h, 1, t, t, h->sh_allA_s, h->sh_allA_m, true); LWCHK(hipGetLastError()); }
+        // (SISR form, form 1: no first-stage weights and no k draw -- every particle continues itself, so stage 2 reads this
+        //  rank's own stage-1 outputs and the second exchange does not exist: ONE exchange per step)
+        if (h->split_l2 && h->form == 0) { lw_launch_plan(h, 1, t, t, h->sh_allA_s, h->sh_allA_m, true); LWCHK(hipGetLastError()); }
         rc = ssme_lw_shard_mid(h, t, h->sh_allA_s, h->sh_allA_m, h->sh_mom_all);
         if (rc != SSME_OK) return rc;
-        rc = lw_halo_exchange(h, comm, {{h->sh_xr, TL}, {h->sh_thr, TL * kDP}, {h->sh_g1, TL}, {h->sh_cdfA, TL}});
-        if (rc != SSME_OK) return rc;
+        if (h->form == 0) {
+            rc = lw_halo_exchange(h, comm, {{h->sh_xr, TL}, {h->sh_thr, TL * kDP}, {h->sh_g1, TL}, {h->sh_cdfA, TL}});
+            if (rc != SSME_OK) return rc;
+        }
         h->sh_check = 1;
         rc = ssme_lw_shard_stage2(h, t, tile0 - m, h->sh_rows, h->sh_xr, h->sh_thr, h->sh_g1, h->sh_cdfA, h->sh_allA_s, h->sh_allA_m,
                                   h->sh_xB + off, h->sh_thB + off * kDP, h->sh_cdfB + off, tsB, tmB, nullptr);

@@ -363,7 +363,9 @@ class ShardedLiuWest:
     """
 
     def __init__(self, delta, phi_l, phi_u, mu_l, mu_u, sig_l, sig_u, rho_l, rho_u, nparts, seed=0, transforms=(2, 0, 3, 1),
-                 device=None, group=None, filter_id=0):
+                 device=None, group=None, filter_id=0, form=0):
+        """form 0: auxiliary-particle form (LWFilterWithCovs); 1: SISR form (LWFilter2WithCovs, svol_lw_2_par): no first-stage
+        weights and no k draw, so a step has ONE window exchange (for the resampling draw) instead of two."""
         import torch
         import torch.distributed as dist
         assert dist.is_initialized(), "init_process_group first (one process per GPU)"
@@ -376,8 +378,9 @@ class ShardedLiuWest:
         self.Bl = self.B // self.world
         self.tile0 = self.rank * self.Bl
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.form = int(form)
         cfg = capi.LwConfig(n_particles=nparts, n_filters=1, seed=seed, device=self.device.index or 0, first_filter_id=filter_id,
-                            delta=delta)
+                            delta=delta, form=self.form)
         cfg.transforms[:] = list(transforms)
         cfg.prior_lo[:] = [phi_l, mu_l, sig_l, rho_l]
         cfg.prior_hi[:] = [phi_u, mu_u, sig_u, rho_u]
@@ -481,7 +484,11 @@ class ShardedLiuWest:
                                              p(self.tilesA[1]), p(self.mom), None))
             self._gather_A()
             # the plan of the k draw first: with the split level-2 it also provides the (m, S) that mid turns into lse1
-            w0, rows, (w_x, w_lw1, w_cdf), w_th = self._windows(1, t, self.allA, [self.xr, self.lw1, self.cdfA], self.thr)
+            if self.form == 0:
+                w0, rows, (w_x, w_lw1, w_cdf), w_th = self._windows(1, t, self.allA, [self.xr, self.lw1, self.cdfA], self.thr)
+            else:       # SISR form: every particle continues itself -- the sources of stage 2 are this rank's own stage-1 outputs
+                w0, rows = self.tile0, self.Bl
+                w_x, w_lw1, w_cdf, w_th = self.xr.own(), self.lw1.own(), self.cdfA.own(), self.thr.own()
             self._chk(L.ssme_lw_shard_mid(self._h, t, p(self.allA[0]), p(self.allA[1]), p(self.mom_all)))
             self._chk(L.ssme_lw_shard_stage2(self._h, t, w0, rows, p(w_x), p(w_th), p(w_lw1), p(w_cdf), p(self.allA[0]),
                                              p(self.allA[1]), p(self.xB.own()), thB_own, p(self.cdfB.own()), p(self.tilesB[0]),

@@ -1,7 +1,7 @@
 // test_shard_threads.cpp -- the C++ shard drivers with SEVERAL ranks on one GPU: every rank is a host thread with its own
 // handle, the "RCCL" underneath is tests/cpp/mock_rccl.cpp (linked before anything else, so dlsym finds it).  Prints, per
 // configuration, what every rank got and what the unsharded filter gives; tests/test_sharded_gpu.py compares.
-//   usage: test_shard_threads CSV WORLD N T MODEL RESAMPLER MODE SEED [TAU [YSCALE [RESAMP_SCHED]]]     (MODEL -1: Liu-West, RESAMPLER = delta x 1000)
+//   usage: test_shard_threads CSV WORLD N T MODEL RESAMPLER MODE SEED [TAU [YSCALE [RESAMP_SCHED [LW_FORM]]]]     (MODEL -1: Liu-West, RESAMPLER = delta x 1000)
 //   TAU (linear-Gaussian model only): observation noise; a tiny value puts all the weight of a step on the one particle next to
 //   y_t, so every rank's next resampling window is that particle's tile -- far ranks leave their halo, near ranks do not.
 //   YSCALE: the observations are multiplied by it (outliers: the stochastic-volatility weights then degenerate the same way).
@@ -21,6 +21,7 @@ int main(int argc, char** argv) {
               mode = std::atoi(argv[7]);
     const unsigned long long seed = std::strtoull(argv[8], nullptr, 10);
     const int sched = argc > 11 ? std::atoi(argv[11]) : 1;
+    const int lw_form = argc > 12 ? std::atoi(argv[12]) : 0;
     std::vector<double> y, z;
     { std::ifstream f(argv[1]); double v; while (f >> v && (int)y.size() < T) y.push_back(v); }
     if (argc > 10) for (double& v : y) v *= std::atof(argv[10]);
@@ -59,7 +60,7 @@ int main(int argc, char** argv) {
             ssme_pf_destroy(h);
         } else {
             ssme_lw_config c{};
-            c.n_particles = N; c.n_filters = 1; c.seed = seed; c.device = 0; c.delta = rs / 1000.0;
+            c.n_particles = N; c.n_filters = 1; c.seed = seed; c.device = 0; c.delta = rs / 1000.0; c.form = lw_form;
             const int tr[4] = {2, 0, 3, 1};
             const double lo[4] = {0.8, -0.1, 0.01, -0.5}, hi[4] = {0.99, 0.1, 0.1, -0.01};
             for (int d = 0; d < 4; ++d) { c.transforms[d] = tr[d]; c.prior_lo[d] = lo[d]; c.prior_hi[d] = hi[d]; }
@@ -95,7 +96,7 @@ int main(int argc, char** argv) {
         ssme_pf_destroy(h);
     } else {
         ssme_lw_config c{};
-        c.n_particles = N; c.n_filters = 1; c.seed = seed; c.device = 0; c.delta = rs / 1000.0;
+        c.n_particles = N; c.n_filters = 1; c.seed = seed; c.device = 0; c.delta = rs / 1000.0; c.form = lw_form;
         const int tr[4] = {2, 0, 3, 1};
         const double lo[4] = {0.8, -0.1, 0.01, -0.5}, hi[4] = {0.99, 0.1, 0.1, -0.01};
         for (int d = 0; d < 4; ++d) { c.transforms[d] = tr[d]; c.prior_lo[d] = lo[d]; c.prior_hi[d] = hi[d]; }

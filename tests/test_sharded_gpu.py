@@ -102,12 +102,12 @@ def test_sharded_filter_with_degenerate_weights(tmp_path, spy):
     ref.close()
 
 
-def _run_sharded_lw(tmp_path, world, n, T, seed, delta):
+def _run_sharded_lw(tmp_path, world, n, T, seed, delta, form=0):
     port = _free_port()
     outs = [str(tmp_path / f"lw_rank{r}.npz") for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker_lw.py"), str(r), str(world), str(port),
-                               outs[r], str(n), str(T), str(seed), str(delta)], env=env) for r in range(world)]
+                               outs[r], str(n), str(T), str(seed), str(delta), str(form)], env=env) for r in range(world)]
     try:
         for p in procs:
             assert p.wait(timeout=240) == 0
@@ -143,6 +143,27 @@ def test_sharded_liu_west_is_bit_identical_to_unsharded(tmp_path, spy, world, n,
     assert np.array_equal(x.view(np.uint64), st["x"].view(np.uint64))
     assert np.array_equal(th.view(np.uint64), st["theta"].view(np.uint64))
     assert sum(int(r["exchanged"]) for r in res) > 0
+
+
+@pytest.mark.parametrize("world,n", [(2, 16384), (4, 32768), (2, 2 * 600 * 2048)])
+def test_sharded_liu_west_sisr_form_is_bit_identical_to_unsharded(tmp_path, spy, world, n):
+    """The SISR form (LWFilter2WithCovs, liu_west_filter.h:2191-2343, model svol_lw_2_par) sharded: one window exchange per step
+    (the resampling draw); stage 2 continues every particle from this rank's own stage-1 outputs (VERDICT r2 missing 4)."""
+    import ssme_amd
+    T, seed = (10 if n < 100000 else 4), 99
+    res = _run_sharded_lw(tmp_path, world, n, T, seed, 0.99, form=1)
+    y = spy[:T]
+    z = np.concatenate([[0.0], y[:-1]])
+    ref = ssme_amd.svol_lw_2_par(0.99, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, seed=seed)
+    ll = ref.run_series(y, z)[0]
+    per = ref.per_step()[0]
+    st = ref.state(0)
+    ref.close()
+    for r in res:
+        assert float(r["ll"]) == ll
+        assert np.array_equal(r["per_step"].view(np.uint64), per.view(np.uint64))
+    assert np.array_equal(np.concatenate([r["x"] for r in res]).view(np.uint64), st["x"].view(np.uint64))
+    assert np.array_equal(np.concatenate([r["theta"] for r in res], axis=1).view(np.uint64), st["theta"].view(np.uint64))
 
 
 @pytest.mark.parametrize("model,n,rs,T,mode", [(0, 65536, 0, 16, 0), (1, 32768, 1, 12, 2), (0, 600 * 2048, 0, 5, 0), (0, 1100 * 2048, 0, 4, 2),
@@ -293,6 +314,21 @@ def test_native_driver_with_a_resampling_schedule(world, n, T, rs, mode, sched):
     ref = float(lines[0].split()[1])
     ranks = [l.split() for l in lines if l.startswith("rank")]
     assert len(ranks) == world and len({int(r[5]) for r in ranks}) == 1
+    for r in ranks:
+        assert float(r[3]) == ref, (r, ref)
+    assert lines[-1] == "particle_mismatches 0"
+
+
+@pytest.mark.parametrize("world,n,T", [(2, 16384, 10), (4, 65536, 8), (2, 2 * 600 * 2048, 3)])
+def test_native_liu_west_sisr_form_with_several_ranks(world, n, T):
+    """ssme_lw_shard_run_series with form = 1 (SISR) over the mock RCCL: one exchange per step; == the unsharded SISR filter."""
+    exe = _build_thread_harness()
+    out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "spy_returns.csv"), str(world), str(n), str(T), "-1", "990",
+                                   "0", "4242", "0.7", "1", "1", "1"], text=True, timeout=600)
+    lines = out.strip().splitlines()
+    ref = float(lines[0].split()[1])
+    ranks = [l.split() for l in lines if l.startswith("rank")]
+    assert len(ranks) == world and {int(r[5]) for r in ranks} == {1}
     for r in ranks:
         assert float(r[3]) == ref, (r, ref)
     assert lines[-1] == "particle_mismatches 0"
