@@ -475,7 +475,7 @@ static int do_reset(ssme_pf_handle h) {
 
 extern "C" {
 
-int ssme_pf_version(void) { return 310; }
+int ssme_pf_version(void) { return 330; }
 
 const char* ssme_pf_strerror(int s) {
     switch (s) {
