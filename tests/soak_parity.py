@@ -34,6 +34,7 @@ for case in range(NB):
     if not ok:
         bad += 1; print("MISMATCH", case, model, n, r, rs, sched, T, seed, split, small, tile, per[rep], po, flush=True)
     b.close()
+    if (case + 1) % 1000 == 0: print("bootstrap case", case + 1, "mismatches so far", bad, flush=True)     # progress (the GPU box kills silent runs)
 print("bootstrap soak done, mismatches:", bad, flush=True)
 bad = 0
 for case in range(NL):
@@ -58,4 +59,5 @@ for case in range(NL):
     if not np.array_equal(bits(per[rep]), bits(po)):
         bad += 1; print("LW MISMATCH", case, n, r, delta, T, seed, split, form, lrs, per[rep], po, flush=True)
     g.close()
+    if (case + 1) % 500 == 0: print("liu-west case", case + 1, "mismatches so far", bad, flush=True)
 print("liu-west soak done, mismatches:", bad, flush=True)
