@@ -16,8 +16,15 @@ t0 = time.time(); ll_dev = bank.run_series(y)[0]; t_dev = time.time() - t0
 per_dev = bank.per_step()[0]
 bank.close()
 print(f"device: log-likelihood {ll_dev!r}  ({t_dev:.3f} s incl. graph capture)", flush=True)
+import threading
+stop = threading.Event()
+def heartbeat():                              # the GPU box kills runs that stay silent for minutes
+    while not stop.wait(60.0):
+        print(f"  ... oracle running, {time.time() - t0:.0f} s", flush=True)
 t0 = time.time()
+threading.Thread(target=heartbeat, daemon=True).start()
 ll_o, per_o = oracle.Filter(oracle.MODEL_SVOL, n, th, seed).run_series(y)
+stop.set()
 print(f"oracle: log-likelihood {ll_o!r}  ({time.time() - t0:.0f} s on one core)", flush=True)
 bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 print("series log-likelihood equal to the bit:", ll_dev == ll_o, "| per-step values differing:", int((bits(per_dev) != bits(per_o)).sum()), "of", y.size, flush=True)
