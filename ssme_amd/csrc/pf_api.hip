@@ -35,6 +35,8 @@ struct ssme_pf_s {
     double *l2_T, *l2_R;     // [R][Bs] split level-2 outputs
     double* l2_work;         // [R][Bs] + [R][32]: scratch of the multi-workgroup level-2
     int32_t *l2_lo, *l2_hi;
+    int32_t* l2_ticket;      // [R] arrival counters of the one-launch level-2 (StepArgs::l2_inkernel)
+    int l2_tables;           // set_debug bit 4: the split level-2 writes its tables and ranges (k_level2_plan / k_l2_ranges), as sharded filters do
     size_t lds_bytes_big, lds_bytes_plan;
     double* small_ms;        // [R][tcap][2] scratch of the one-tile whole-series kernel
     double* yz_step;         // device [2]: y and z of the step API, uploaded by ONE copy
@@ -189,6 +191,13 @@ static StepArgs step_args(ssme_pf_handle h) {
     a.keyp = h->keybuf; a.first_filter = h->cfg.first_filter_id;
     a.logN = dlog((double)h->N);
     a.l2_T = h->l2_T; a.l2_R = h->l2_R; a.l2_lo = h->l2_lo; a.l2_hi = h->l2_hi; a.l2_work = h->l2_work;
+    a.l2_inkernel = (h->split_l2 && h->shard_world == 0 && !h->l2_tables) ? 1 : 0; a.l2_ticket = h->l2_ticket;
+    {
+        double* tail = h->l2_work + (size_t)h->R * h->Bs;                     // [R][kL2Scratch] and 32 zeros after them
+        a.l2_tsrc = a.l2_inkernel ? h->l2_work : h->l2_T;
+        a.l2_offs = a.l2_inkernel ? tail + kL2Offsets : tail + (size_t)h->R * kL2Scratch;
+        a.l2_offs_stride = a.l2_inkernel ? kL2Scratch : 0;
+    }
     {
         // two 512-thread workgroups fit a CU (LDS): is the whole grid resident at once?
         const long blocks = (long)(h->shard_world > 0 ? h->B / h->shard_world : h->B) * h->R;
@@ -333,7 +342,10 @@ static void launch_gamma(ssme_pf_handle h, int t0, int nT) {
 }
 // the split level-2 of one draw: one workgroup per filter up to 1024 tiles, several above (k_l2_scan_blocks + k_l2_ranges)
 static void launch_level2(hipStream_t st, const StepArgs& a, int n_filters, size_t lds, int ranges) {
-    if (a.l2_work && a.B > 1024) {
+    if (a.l2_inkernel) {
+        // unsharded bootstrap filter: one launch; k_filter_step<.., true> finds the source-tile ranges itself
+        hipLaunchKernelGGL(k_l2_scan_blocks, dim3((a.B + 1023) / 1024, n_filters), dim3(1024), 0, st, a);
+    } else if (a.l2_work && a.B > 1024) {
         const dim3 grid((a.B + 1023) / 1024, n_filters);
         hipLaunchKernelGGL(k_l2_scan_blocks, grid, dim3(1024), 0, st, a);
         hipLaunchKernelGGL(k_l2_ranges, grid, dim3(1024), lds, st, a, ranges);
@@ -551,7 +563,8 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
                                    (int)h->lds_bytes_plan));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_l2_ranges), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lds_bytes_plan));
-        HIPCHK(hipMalloc(&h->l2_work, sizeof(double) * ((size_t)h->R * h->Bs + (size_t)h->R * 32)));
+        HIPCHK(hipMalloc(&h->l2_work, sizeof(double) * ((size_t)h->R * h->Bs + (size_t)h->R * kL2Scratch + 32)));
+        HIPCHK(hipMemset(h->l2_work, 0, sizeof(double) * ((size_t)h->R * h->Bs + (size_t)h->R * kL2Scratch + 32)));
         HIPCHK(hipMalloc(&h->l2_T, sizeof(double) * (size_t)h->R * h->Bs));
         HIPCHK(hipMalloc(&h->l2_R, sizeof(double) * (size_t)h->R * h->Bs));
         HIPCHK(hipMalloc(&h->l2_lo, sizeof(int32_t) * (size_t)h->R * h->Bs));
@@ -566,6 +579,8 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
         HIPCHK(hipMalloc(&h->keybuf, sizeof(uint32_t) * 2));
         HIPCHK(hipMalloc(&h->yz_step, sizeof(double) * 2));
         HIPCHK(hipMalloc(&h->ticket, sizeof(int32_t) * h->R));
+        HIPCHK(hipMalloc(&h->l2_ticket, sizeof(int32_t) * h->R));
+        HIPCHK(hipMemsetAsync(h->l2_ticket, 0, sizeof(int32_t) * h->R, h->stream));
         HIPCHK(hipMemsetAsync(h->ticket, 0, sizeof(int32_t) * h->R, h->stream));
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pin), sizeof(double) * (2 + (size_t)h->R + 64 + 8), hipHostMallocMapped));   // + 128 ints for the shard plan + 8 swarm aggregates
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pin_dev), h->pin, 0));
@@ -592,7 +607,7 @@ int ssme_pf_destroy(ssme_pf_handle h) {
     h->stream = h->own_stream;
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     void* bufs[] = {h->x[0], h->x[1], h->cdf[0], h->cdf[1], h->tsum[0], h->tsum[1], h->tmax[0], h->tmax[1], h->logw,
-                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_work, h->l2_lo, h->l2_hi, h->yz_step, h->ticket, h->small_ms, h->exp_part, h->exp_out, h->wscratch,
+                    h->ybuf, h->zbuf, h->per_step, h->scratchR, h->anc, h->scal, h->mc, h->gam, h->pgam, h->gtot, h->keybuf, h->plan_dev, h->l2_T, h->l2_R, h->l2_work, h->l2_lo, h->l2_hi, h->yz_step, h->ticket, h->l2_ticket, h->small_ms, h->exp_part, h->exp_out, h->wscratch,
                     h->sh_x[0], h->sh_x[1], h->sh_c[0], h->sh_c[1], h->sh_loc, h->sh_raw, h->sh_tsum, h->sh_tmax, h->sh_winx, h->sh_winc, h->sh_flag};
     for (void* p : bufs) if (p) hipFree(p);
     if (h->pin) hipHostFree(h->pin);
@@ -1003,7 +1018,7 @@ int ssme_pf_reset(ssme_pf_handle h) {
     return do_reset(h);
 }
 
-// flags: bit 0 = record ancestor indices, bit 1 = keep the log-weights in memory
+// flags: bit 0 = record ancestor indices, bit 1 = keep the log-weights in memory, bits 2-4 = level-2 policy (below)
 int ssme_pf_set_debug(ssme_pf_handle h, int32_t flags) {
     if (!h) return SSME_ERR_INVALID_ARG;
     if (h->shard_world > 0) return SSME_ERR_STATE;
@@ -1015,10 +1030,13 @@ int ssme_pf_set_debug(ssme_pf_handle h, int32_t flags) {
     h->debug_anc = (flags & 1) ? 1 : 0;
     h->keep_logw = (flags & 2) ? 1 : 0;
     {
-        // bit 2 forces the split level-2, bit 3 the in-kernel one (where it exists: <= 2048 tiles); default by size
+        // bit 2 forces the split level-2, bit 3 the in-kernel one (where it exists: <= 2048 tiles); default by size.
+        // bit 4: the split level-2 by the table kernels (two launches above 1024 tiles) instead of one launch + ranges in the step kernel
         const int want = (h->B > kMaxTilesPerFilter || (flags & 4)) ? 1 : ((flags & 8) ? 0 : (h->B > kSplitLevel2Above ? 1 : 0));
-        if (want != h->split_l2 && h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+        const int tables = (flags & 16) ? 1 : 0;
+        if ((want != h->split_l2 || tables != h->l2_tables) && h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
         h->split_l2 = want;
+        h->l2_tables = tables;
     }
     return ensure_logw(h);
 }
@@ -1800,7 +1818,7 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
     int rc = [&]() -> int {
         LWCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->own_stream = h->stream;
-        LWCHK(hipMalloc(&h->l2_work, sizeof(double) * ((size_t)h->R * h->Bs + (size_t)h->R * 32)));
+        LWCHK(hipMalloc(&h->l2_work, sizeof(double) * ((size_t)h->R * h->Bs + (size_t)h->R * kL2Scratch)));
         for (int d = 0; d < 2; ++d) {
             LWCHK(hipMalloc(&h->l2T[d], sizeof(double) * (size_t)h->R * h->Bs));
             LWCHK(hipMalloc(&h->l2R[d], sizeof(double) * (size_t)h->R * h->Bs));

@@ -35,6 +35,8 @@ constexpr int kTileSmall = 512;
 constexpr int kTileMid = 1024;            // small tile: 2048 < N <= 2^18, so that a mid-size filter spreads over the chip (N = 2^16: 128 workgroups)
 constexpr int kMaxTilesPerFilter = 2048;   // in-kernel level-2 (one entry per thread at NT = 512 .. four at 512 threads)
 constexpr int kSplitLevel2Above = 1024;    // measured (profiles/r02_level2_split.txt): in-kernel 24.7 vs split 25.4 us at 768 tiles, equal at 1024, 67.9 vs 43.3 at 1536
+constexpr int kL2Scratch = 64;             // doubles of l2_work per filter after the block-local scans: [0, 16) block totals, [16] m,
+constexpr int kL2Offsets = 32;             //   [kL2Offsets, + 17) exclusive offsets of the blocks and S' (l2_inkernel)
 constexpr int kMaxTilesSplit = 16384;      // split level-2 (k_level2_plan + k_filter_step<.., true>): N <= 2^25
 constexpr int kStageTiles = 3;             // cdf tiles staged in LDS per output tile
 constexpr int kEShift = 35;                // exponential spacings: qE = rne(E * 2^35)
@@ -102,8 +104,17 @@ struct StepArgs {
     double* l2_R;              // [R][Bs] A_b / A'_b
     int32_t* l2_lo;            // [R][Bs] first / last source tile of every output tile's targets
     int32_t* l2_hi;
-    double* l2_work;           // [R][Bs] block-local scans + [R][32] block totals and m: scratch of the multi-workgroup level-2
-                               // (k_l2_scan_blocks / k_l2_ranges, filters of more than 1024 tiles), or null
+    double* l2_work;           // [R][Bs] block-local scans + [R][64] per filter: [0,16) block totals, [16] m, [17] S', [32,49) exclusive
+                               // offsets of the blocks: scratch of the multi-workgroup level-2 (k_l2_scan_blocks / k_l2_ranges,
+                               // filters of more than 1024 tiles), or null
+    int32_t l2_inkernel;       // 1 (round 3, unsharded bootstrap filters of more than 1024 tiles): the level-2 is ONE launch --
+                               // k_l2_scan_blocks, whose last-arriving workgroup takes the block offsets, S' and the accounting --
+                               // and k_filter_step<.., true> finds its own source-tile range in T'_j = offset[j / 1024] + local
+                               // scan[j] (a 64-entry window around its own tile id, binary search beyond it): no k_l2_ranges launch
+    int32_t* l2_ticket;        // [R] arrival counters of that launch (zero between launches)
+    const double* l2_tsrc;     // k_filter_step<.., true> reads T'_j = l2_offs[r * l2_offs_stride + j / 1024] + l2_tsrc[r * Bs + j]:
+    const double* l2_offs;     //   l2_T and zeros (stride 0) after the table kernels, l2_work's scans and offsets (stride 64) with l2_inkernel
+    int32_t l2_offs_stride;
     int32_t prio_mode;         // wave-priority schedule of k_filter_step (prio_at): 0 none, 1 single residency wave, 2 several
     int32_t stream_stores;     // 1: particles and cdf are stored non-temporally (grids that are resident all at once)
     const uint32_t* keyp;      // [2] Philox key (the seed), device resident so that a captured graph survives ssme_pf_set_seed
@@ -673,6 +684,17 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     } else if (need_l2 && !BIG) level2_load<NT>(a.tsum_in + (size_t)r * a.Bs, a.tmax_in + (size_t)r * a.Bs, a.B, A2, M2);
     const double* l2T = a.l2_T + (size_t)r * a.Bs;
     const double* l2R = a.l2_R + (size_t)r * a.Bs;
+    // T'_j of the split level-2 = l2_offs[j / 1024] + l2_tsrc[j]: a table plus zeros (k_level2_plan / k_l2_ranges), or block
+    // offset + block-local scan (l2_inkernel) -- one expression, no branch at the reads
+    const bool l2ink = BIG && a.l2_inkernel;
+    const double* l2ts = a.l2_tsrc + (size_t)r * a.Bs;
+    const double* l2of = a.l2_offs + (size_t)r * a.l2_offs_stride;
+    auto l2Tg = [&](int j) -> double { return l2of[j >> 10] + l2ts[j]; };
+    // l2_inkernel: wave 0 looks for this tile's source range itself; the 64 entries around its own tile id, requested now
+    // (two loads; their sum is taken where it is needed, after the other loads of the head have been issued)
+    const int l2w0 = (b - 32 < 0 || a.B <= 64) ? 0 : (b - 32 > a.B - 64 ? a.B - 64 : b - 32);
+    double l2win_o = 0.0, l2win_t = dinf();
+    if (l2ink && need_l2 && sorted && tid < 64 && l2w0 + tid < a.B) { l2win_o = l2of[(l2w0 + tid) >> 10]; l2win_t = l2ts[l2w0 + tid]; }
     if (tid == 0) { lds_cnt[0] = 0; lds_cnt[1] = 0; }
     double gam = 0.0, pgam = 0.0, pgam_next = 0.0, G = 1.0;
     const bool multinomial = resampled && rsm == RESAMP_MULTINOMIAL;
@@ -696,6 +718,28 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             u0 = u01_co(ox.v0, ox.v1);
         }
         tile_target_bounds(rsm, S, a.N, i_first, nvalid, pgam, pgam_next, G, u0, t_scale, t_lo, t_hi);
+        if (l2ink && sorted && tid < 64) {
+            // lo = #{T'_j < t_lo}, hi = #{T'_j < t_hi}.  T' is nondecreasing, so the window [w0, w0 + 64) gives a count
+            // exactly when it brackets the target: something below it inside (or w0 = 0) and something not below it inside (or
+            // the window reaches B).  Weights that are not wildly uneven put the targets of tile b a few tiles from b; beyond
+            // that a 64-ary descent (strides 256, 4, 1: three rounds for 16384 tiles) finds the same counts.
+            const bool at_end = l2w0 + 64 >= a.B;
+            const double l2win = l2win_o + l2win_t;
+            int lo = __popcll(__ballot(l2win < t_lo)), hi = __popcll(__ballot(l2win < t_hi));
+            const bool ok = (lo > 0 || l2w0 == 0) && (lo < 64 || at_end) && (hi > 0 || l2w0 == 0) && (hi < 64 || at_end);
+            lo += l2w0; hi += l2w0;
+            if (!ok) {
+                lo = 0; hi = 0;
+                auto round = [&](int stride) {
+                    const int jl = lo + (tid + 1) * stride - 1, jh = hi + (tid + 1) * stride - 1;
+                    const double vl = jl < a.B ? l2Tg(jl) : dinf(), vh = jh < a.B ? l2Tg(jh) : dinf();
+                    lo += __popcll(__ballot(vl < t_lo)) * stride;
+                    hi += __popcll(__ballot(vh < t_hi)) * stride;
+                };
+                round(256); round(4); round(1);
+            }
+            if (tid == 0) { lds_cnt[0] = lo; lds_cnt[1] = hi; }
+        }
     }
     if (need_l2 && !BIG) {
         double Tinc[NE];
@@ -783,7 +827,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         __syncthreads();          // lds_T, lds_cnt visible
         if (sorted) {
             int lo, hi;
-            if (BIG) { lo = a.l2_lo[(size_t)r * a.Bs + b]; hi = a.l2_hi[(size_t)r * a.Bs + b]; }
+            if (BIG && !l2ink) { lo = a.l2_lo[(size_t)r * a.Bs + b]; hi = a.l2_hi[(size_t)r * a.Bs + b]; }
             else { lo = lds_cnt[0]; hi = lds_cnt[1]; }
             lo = lo < a.B - 1 ? lo : a.B - 1;
             hi = hi < a.B - 1 ? hi : a.B - 1;
@@ -936,9 +980,9 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                 }
             }
             const int b1 = bb_min + 1 < a.B ? bb_min + 1 : a.B - 1, b2 = bb_min + 2 < a.B ? bb_min + 2 : a.B - 1;
-            const double T0 = BIG ? l2T[bb_min] : lds_T[bb_min];
-            const double T1 = (bb_min + 1 < a.B) ? (BIG ? l2T[bb_min + 1] : lds_T[bb_min + 1]) : dinf();
-            const double Pm = bb_min ? (BIG ? l2T[bb_min - 1] : lds_T[bb_min - 1]) : 0.0;
+            const double T0 = BIG ? l2Tg(bb_min) : lds_T[bb_min];
+            const double T1 = (bb_min + 1 < a.B) ? (BIG ? l2Tg(bb_min + 1) : lds_T[bb_min + 1]) : dinf();
+            const double Pm = bb_min ? (BIG ? l2Tg(bb_min - 1) : lds_T[bb_min - 1]) : 0.0;
             __syncthreads();
             const double R0 = BIG ? l2R[bb_min] : lds_R3[0], R1 = BIG ? l2R[b1] : lds_R3[1], R2 = BIG ? l2R[b2] : lds_R3[2];
             STAMP(a, 5);
@@ -970,9 +1014,9 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const double target = tau[k][c];
-                    int bb = count_less_pow2(a.Bpow2, target, [&](int j) { return BIG ? (j < a.B ? l2T[j] : dinf()) : lds_T[j]; });
+                    int bb = count_less_pow2(a.Bpow2, target, [&](int j) { return BIG ? (j < a.B ? l2Tg(j) : dinf()) : lds_T[j]; });
                     bb = bb < a.B - 1 ? bb : a.B - 1;
-                    const double Pb = bb ? (BIG ? l2T[bb - 1] : lds_T[bb - 1]) : 0.0;
+                    const double Pb = bb ? (BIG ? l2Tg(bb - 1) : lds_T[bb - 1]) : 0.0;
                     const double tloc = __builtin_ceil((target - Pb) * (BIG ? l2R[bb] : lds_R[bb]));
                     const double* tile = cdf_r + (size_t)(bb - a.win_tile0) * TILE;
                     const int j = count_less_pow2(TILE, tloc, [&](int q) { return tile[q]; });
@@ -1348,14 +1392,57 @@ __global__ __launch_bounds__(1024) void k_l2_scan_blocks(const StepArgs a) {
     sv = sv + dpp_f64_zero<0x118, 0xF>(sv);
     const double pre = wave ? readlane_f64(sv, wave - 1) : 0.0;
     double* Tloc = a.l2_work + (size_t)r * a.Bs;
-    double* blkv = a.l2_work + (size_t)a.R * a.Bs + (size_t)r * 32;
+    double* blkv = a.l2_work + (size_t)a.R * a.Bs + (size_t)r * kL2Scratch;
     if (jo < a.B) {
         Tloc[jo] = pre + inc;
         a.l2_R[(size_t)r * a.Bs + jo] = A / Ap;
     }
-    if (tid == 0) {
+    if (tid == 0 && !a.l2_inkernel) {
         blkv[blk] = readlane_f64(sv, 15);
         if (blk == 0) blkv[KMAX] = m;
+    }
+    if (wave == 0 && a.l2_inkernel) {
+        // One launch: the workgroup that arrives last adds up the block totals.  The total goes out as an agent-scope store and
+        // has left the CU (s_waitcnt) before the arrival is counted; the last arriver reads the totals with agent-scope loads
+        // issued after its own count came back -- the hand-over of the step API's ticket (k_filter_step), at 16 workgroups.
+        // Lane k of its first wave takes block k: one load, a 16-lane scan (integer sums: exact in any order).
+        const int nblk = (int)gridDim.x;
+        const double tot = readlane_f64(sv, 15);
+        int arrived = 0;
+        if (lane == 0) {
+            __hip_atomic_store(&blkv[blk], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            arrived = __hip_atomic_fetch_add(a.l2_ticket + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if (arrived == nblk - 1) {
+            const double v = (lane < nblk) ? __hip_atomic_load(&blkv[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            double tinc = v;
+            tinc = tinc + dpp_f64_zero<0x111, 0xF>(tinc);
+            tinc = tinc + dpp_f64_zero<0x112, 0xF>(tinc);
+            tinc = tinc + dpp_f64_zero<0x114, 0xF>(tinc);
+            tinc = tinc + dpp_f64_zero<0x118, 0xF>(tinc);
+            const double S = readlane_f64(tinc, 15);
+            double* off = blkv + kL2Offsets;
+            if (lane <= KMAX) off[lane] = (lane < KMAX) ? tinc - v : S;       // exclusive offset of block k (k >= nblk: S')
+            if (lane == 0) {
+                __hip_atomic_store(a.l2_ticket + r, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool resampled = (a.t % a.resamp_sched == 0);
+                FilterScalars* sc = a.scal + r;
+                sc->m = m;
+                sc->S = S;
+                if (a.finalize_prev) {
+                    const double Sdd = (S > 0.0) ? dldexp(S, -a.rshift) : dnan();
+                    const double lse = m + dlog(Sdd);
+                    const double ll = lse - sc->prev;
+                    sc->last_ll = ll;
+                    sc->loglik = sc->loglik + ll;
+                    sc->prev = resampled ? a.logN : lse;
+                    if (a.per_step) a.per_step[(size_t)r * a.Tcap + (a.t - 1)] = ll;
+                    if (a.ll_host) a.ll_host[r] = ll;
+                }
+            }
+        }
     }
 }
 
@@ -1365,7 +1452,7 @@ __global__ __launch_bounds__(1024) void k_l2_ranges(const StepArgs a, int plan_r
     double* lds_T = reinterpret_cast<double*>(smem_l2r);         // [Bpow2]
     const int tid = threadIdx.x, blk = blockIdx.x, r = blockIdx.y;
     const double* Tloc = a.l2_work + (size_t)r * a.Bs;
-    const double* blkv = a.l2_work + (size_t)a.R * a.Bs + (size_t)r * 32;
+    const double* blkv = a.l2_work + (size_t)a.R * a.Bs + (size_t)r * kL2Scratch;
     double* Tp = a.l2_T + (size_t)r * a.Bs;
     const uint32_t rep = a.first_filter + (uint32_t)r;
     const bool resampled = (a.t % a.resamp_sched == 0);

@@ -80,8 +80,10 @@ class ParticleFilterBank:
 
     def set_debug(self, record_ancestors=True, keep_logw=True, split_level2=None):
         """Parity/debug: record ancestor indices and/or keep the log-weights in device memory; split_level2 forces the
-        one-launch-per-filter level-2 (True) or the in-kernel one (False, up to 2048 tiles); None chooses by size."""
-        pol = 0 if split_level2 is None else (4 if split_level2 else 8)      # None: by size (split above 1024 tiles)
+        one-launch-per-filter level-2 (True) or the in-kernel one (False, up to 2048 tiles); None chooses by size.
+        "tables": the split level-2 with its tables and source ranges written by the level-2 kernels (what sharded and
+        Liu-West filters run; two launches above 1024 tiles) instead of one launch + ranges found by the step kernel."""
+        pol = 0 if split_level2 is None else (20 if split_level2 == "tables" else (4 if split_level2 else 8))   # None: by size
         self._chk(capi.lib().ssme_pf_set_debug(self._h, (1 if record_ancestors else 0) | (2 if keep_logw else 0) | pol))
 
     def set_graph_mode(self, on=True):

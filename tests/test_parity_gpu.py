@@ -977,6 +977,30 @@ def test_filter_of_more_than_2048_tiles(sa, oracle, spy):
     b.close()
 
 
+@pytest.mark.parametrize("rs", [0, 1])
+def test_source_ranges_found_by_the_step_kernel(sa, oracle, spy, rs):
+    """4100 tiles (five level-2 workgroups, one launch): the step kernel's own range search -- the 64-tile window around its
+    tile id, and with an outlier's degenerate weights the 64-ary descent -- against the table kernels and the oracle; particles
+    and cdf of the last step as well."""
+    n, T = 4100 * 2048 - 11, 4
+    y = spy[:T].copy()
+    y[1] *= 40.0
+    outs = []
+    for pol in (None, "tables"):
+        b = sa.ParticleFilterBank(sa.MODEL_SVOL, n, 1, 5, rs)
+        b.set_debug(False, True, split_level2=pol)
+        b.set_params([1.0, 0.95, 0.25])
+        ll = b.run_series(y)
+        st = b.state(0)
+        outs.append((ll, b.per_step(), st["x"], st["cdf"]))
+        b.close()
+    for k in range(3):
+        assert_bits_equal(outs[0][k], outs[1][k], f"ranges in the step kernel vs tables [{k}]")
+    np.testing.assert_array_equal(outs[0][3], outs[1][3])
+    po = oracle.Filter(oracle.MODEL_SVOL, n, [1.0, 0.95, 0.25], 5, resampler=rs).run_series(y)[1]
+    assert_bits_equal(outs[0][1][0], po, "ranges in the step kernel vs oracle")
+
+
 def test_level2_policy_by_size_is_result_invariant(sa, spy):
     """1200 tiles: split level-2 (the default above 1024 tiles) == in-kernel level-2 (four tile sums per thread)."""
     n, y = 1200 * 2048 - 5, spy[:5]
@@ -1002,7 +1026,7 @@ def test_multi_workgroup_level2_matches_in_kernel_level2_and_oracle(sa, oracle, 
     y[2] *= 30.0                                           # an outlier: unbalanced weights, wide source ranges
     z = np.concatenate([[0.0], y[:-1]]) if model == 1 else None
     outs = []
-    for split in (True, False):
+    for split in (True, False, "tables"):
         b = sa.ParticleFilterBank(model, n, 2, 17, rs)
         b.set_debug(False, False, split_level2=split)
         b.set_params(th)
@@ -1011,9 +1035,10 @@ def test_multi_workgroup_level2_matches_in_kernel_level2_and_oracle(sa, oracle, 
         nxt = b.step(spy[T], None if z is None else y[T - 1])
         outs.append((ll, per, nxt))
         b.close()
-    assert_bits_equal(outs[0][0], outs[1][0], "multi-workgroup level-2: log-lik")
-    assert_bits_equal(outs[0][1], outs[1][1], "multi-workgroup level-2: per-step")
-    assert_bits_equal(outs[0][2], outs[1][2], "multi-workgroup level-2: step API")
+    for k in (1, 2):
+        assert_bits_equal(outs[0][0], outs[k][0], "multi-workgroup level-2: log-lik")
+        assert_bits_equal(outs[0][1], outs[k][1], "multi-workgroup level-2: per-step")
+        assert_bits_equal(outs[0][2], outs[k][2], "multi-workgroup level-2: step API")
     o = oracle.Filter(model, n, th, 17, rep=1, resampler=rs)
     assert_bits_equal(outs[0][1][1], o.run_series(y, z)[1], "multi-workgroup level-2 vs oracle")
 

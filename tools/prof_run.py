@@ -21,7 +21,7 @@ ap.add_argument("--eager", action="store_true")
 ap.add_argument("--nt", type=int, default=0)
 ap.add_argument("--tile", type=int, default=0, help="particles per tile: 0 = by N, 512, 1024 or 2048")
 ap.add_argument("--sweep", action="store_true")
-ap.add_argument("--split", type=int, default=-1, help="1: force the split level-2 (k_level2_plan), 0: force the in-kernel one")
+ap.add_argument("--split", type=int, default=-1, help="1: force the split level-2 (k_level2_plan), 0: force the in-kernel one, 2: split with the table kernels")
 ap.add_argument("--lw", action="store_true", help="Liu-West filter instead of the bootstrap filter")
 a = ap.parse_args()
 y = np.loadtxt(os.path.join(ROOT, "tests", "golden", "spy_returns.csv"))[:a.T]
@@ -43,7 +43,7 @@ bank = ssme_amd.ParticleFilterBank(a.model, a.n, a.filters, 20260101, a.resample
 if a.eager:
     bank.set_graph_mode(False)
 if a.split >= 0:
-    bank.set_debug(False, False, split_level2=bool(a.split))
+    bank.set_debug(False, False, split_level2=("tables" if a.split == 2 else bool(a.split)))
 bank.set_params(th)
 combos = [256, 512, 1024] if a.sweep else [a.nt]
 for nt in combos:
