@@ -222,9 +222,12 @@ int ssme_pf_test_gamma(int32_t device, uint64_t seed, uint32_t rep, int32_t t, d
 
 /* ============================================================================================
  * Particle-sharded filter: ONE filter of cfg->n_particles particles over `world` GPUs,
- * one process per GPU.  Rank g owns tiles [g B/world, (g+1) B/world) (a tile = 2048 particles; n_particles must be a
- * multiple of 2048 world, at most 2^25; n_filters = 1; any resamp_sched: a step without a resampling draw exchanges nothing
- * but the tile sums and carries this rank's log-weights).  Per time step the host side (the C++ driver below, or
+ * one process per GPU.  A tile = 2048 particles, B = ceil(n_particles / 2048) tiles, Bl = ceil(B / world): rank g owns tiles
+ * [g Bl, min((g+1) Bl, B)) -- any n_particles up to 2^25 for which every rank owns at least one tile, (world-1) Bl < B (always
+ * true from world (world-1) tiles on; SSME_ERR_UNSUPPORTED otherwise): the last rank may own fewer tiles and a ragged last
+ * tile, and every per-rank layout (the gathered tile arrays: world x Bl entries of which the first B are tiles; buffers; halos)
+ * has Bl rows per rank -- ssme_pf_shard_layout.  n_filters = 1; any resamp_sched: a step without a resampling draw exchanges
+ * nothing but the tile sums and carries this rank's log-weights.  Per time step the host side (the C++ driver below, or
  * ssme_amd/sharded.py over torch.distributed) does:   all_gather of the tile sums / maxima  ->  ssme_pf_shard_plan (which source tiles each
  * rank's resampling touches)  ->  exchange of those tiles (cdf + particles)  ->  ssme_pf_shard_step.
  * The level-2 arithmetic, the RNG counters (global particle index) and the Gamma tables (global tile id) are those of
@@ -234,11 +237,13 @@ int ssme_pf_test_gamma(int32_t device, uint64_t seed, uint32_t rep, int32_t t, d
  * driven by the log_like_eval loop (example/estimate_univ_svol.h:121-127), the decomposition is SURVEY.md section 8e's.
  * ============================================================================================ */
 int ssme_pf_shard_create(const ssme_pf_config* cfg, int32_t rank, int32_t world, ssme_pf_handle* out);
+/* out4 = { B (tiles of the filter), Bl (rows per rank in every layout), tiles this rank owns, particles this rank owns } */
+int ssme_pf_shard_layout(ssme_pf_handle h, int32_t* out4);
 /* Launch on the caller's HIP stream (hipStream_t as void*; NULL = the handle's own stream). */
 int ssme_pf_set_stream(ssme_pf_handle h, void* hip_stream);
 /* Uploads the series, draws the Gamma tables of all T steps (every rank holds all tiles' draws), resets the scalars. */
 int ssme_pf_shard_prepare(ssme_pf_handle h, const double* y, const double* z, int32_t T);
-/* Step t >= 1: from the gathered tile sums / maxima of step t-1 (device, B doubles each) the inclusive source-tile range
+/* Step t >= 1: from the gathered tile sums / maxima of step t-1 (device, world x Bl doubles each) the inclusive source-tile range
  * [lo, hi] of every rank: lo_hi_host[2*g], lo_hi_host[2*g+1].  Synchronises the stream. */
 int ssme_pf_shard_plan(ssme_pf_handle h, const double* tsum_all, const double* tmax_all, int32_t t, int32_t* lo_hi_host);
 /* One filter step on this rank's tiles.  x_win / cdf_win hold source tiles win_tile0 .. (at least) this rank's hi,
@@ -268,7 +273,7 @@ int ssme_shard_comm_init(const void* id128, int32_t rank, int32_t world, int32_t
 int ssme_shard_comm_destroy(void* comm);
 int ssme_pf_shard_run_series(ssme_pf_handle h, void* nccl_comm, const double* y, const double* z, int32_t T, int32_t mode,
                              double* loglik_out);
-/* after ssme_pf_shard_run_series: this rank's N / world particles and integer cdf (nullable), the path the last series
+/* after ssme_pf_shard_run_series: this rank's particles (ssme_pf_shard_layout's out4[3]) and integer cdf (nullable), the path the last series
  * took (1 fixed halo, 2 exact) and the number of tiles this rank received from other ranks */
 int ssme_pf_shard_download(ssme_pf_handle h, double* x_local, uint64_t* cdf_local, int32_t* path, int64_t* exchanged_tiles);
 /* after ssme_pf_shard_run_series, of its last FIXED-HALO pass: out4[0] = 1 if a resampling window left the halo on ANY rank (the
@@ -326,7 +331,8 @@ int ssme_lw_last_elapsed_ms(ssme_lw_handle h, float* ms);
 const char* ssme_lw_last_error(ssme_lw_handle h);
 
 /* ---- particle-sharded Liu-West filter: ONE filter of cfg->n_particles particles over `world` GPUs (BASELINE.json configs[4]).
- * Rank g owns B/world consecutive tiles (n_particles a multiple of 2048 world, at most 2^25; n_filters = 1; resampling every
+ * Rank g owns tiles [g Bl, min((g+1) Bl, B)), Bl = ceil(B / world), as ssme_pf_shard_create lays a filter out (any n_particles
+ * up to 2^25 with (world-1) Bl < B; ssme_lw_shard_layout); n_filters = 1; resampling every
  * step; both forms -- the SISR form, form = 1, has no k draw, so its stage 2 reads this rank's own stage-1 outputs and a step
  * has ONE window exchange instead of two).  Per step the
  * host side (ssme_amd/sharded.py, ShardedLiuWest) gathers the tile sums / maxima of the second-stage weights, plans and
@@ -336,8 +342,9 @@ const char* ssme_lw_last_error(ssme_lw_handle h);
  * for the k draw (stage 2) -- call ssme_lw_shard_plan(which = 1) BEFORE ssme_lw_shard_mid: above 1024 tiles the plan also
  * provides the first-stage (m, S) that mid turns into the log-sum-exp.  theta buffers are 4 planes: [4][tiles * 2048].  Bit-identical to ssme_lw_run_series. */
 int ssme_lw_shard_create(const ssme_lw_config* cfg, int32_t rank, int32_t world, ssme_lw_handle* out);
+int ssme_lw_shard_layout(ssme_lw_handle h, int32_t* out4);      /* as ssme_pf_shard_layout */
 int ssme_lw_set_stream(ssme_lw_handle h, void* hip_stream);
-/* theta OUTPUT buffers are 4 planes of `tiles` rows each (default B / world; larger when the caller keeps halo rows around
+/* theta OUTPUT buffers are 4 planes of `tiles` rows each (default Bl; larger when the caller keeps halo rows around
  * its own tiles).  In the stage calls `win_tiles` is the same thing for the theta SOURCE window: rows per plane. */
 int ssme_lw_shard_set_plane_tiles(ssme_lw_handle h, int32_t tiles);
 int ssme_lw_shard_prepare(ssme_lw_handle h, const double* y, const double* z, int32_t T);
@@ -361,7 +368,7 @@ int ssme_lw_shard_finalize(ssme_lw_handle h, int32_t t, const double* tsumB_all,
  * stage kernels verify their own source tiles against the exchanged window; if one ever left it ON ANY RANK (flags reduced by
  * ncclAllReduce after the loop) the call returns SSME_ERR_STATE ON EVERY RANK and the caller runs the exact host-planned loop over the step-wise entry points above.  loglik_out: 1. */
 int ssme_lw_shard_run_series(ssme_lw_handle h, void* nccl_comm, const double* y, const double* z, int32_t T, double* loglik_out);
-/* after ssme_lw_shard_run_series: this rank's N / world particles, transformed parameters theta[d * n + i], tiles received */
+/* after ssme_lw_shard_run_series: this rank's n particles (ssme_lw_shard_layout), transformed parameters theta[d * n + i], tiles received */
 int ssme_lw_shard_download(ssme_lw_handle h, double* x_local, double* theta_local, int64_t* exchanged_tiles);
 /* as ssme_pf_shard_stats: out4[0] the reduced flag (SSME_ERR_STATE was returned on EVERY rank if it is set), out4[1] this rank's own */
 int ssme_lw_shard_stats(ssme_lw_handle h, int32_t* out4);

@@ -21,7 +21,7 @@ H_X, H_X2, H_VOL, H_CONST42 = 0, 1, 2, 3
 EXPORTS = [
     "ssme_pf_create", "ssme_pf_destroy", "ssme_pf_default_tile", "ssme_pf_user_model_n_theta", "ssme_pf_set_params", "ssme_pf_reset", "ssme_pf_set_seed", "ssme_pf_set_small_series", "ssme_pf_shard_create", "ssme_pf_set_stream",
     "ssme_pf_shard_prepare", "ssme_shard_comm_get_unique_id", "ssme_shard_comm_init", "ssme_shard_comm_destroy", "ssme_pf_shard_run_series",
-    "ssme_pf_shard_download", "ssme_pf_shard_stats", "ssme_pf_shard_plan", "ssme_pf_shard_step", "ssme_pf_shard_finalize", "ssme_pf_step",
+    "ssme_pf_shard_download", "ssme_pf_shard_stats", "ssme_pf_shard_layout", "ssme_pf_shard_plan", "ssme_pf_shard_step", "ssme_pf_shard_finalize", "ssme_pf_step",
     "ssme_pf_run_series", "ssme_pf_get_per_step", "ssme_pf_get_loglik", "ssme_pf_get_expectations", "ssme_pf_get_expectations_multi", "ssme_pf_swarm_aggregate", "ssme_pf_swarm_aggregate_threads", "ssme_pf_download_weights", "ssme_pf_get_layout",
     "ssme_pf_log_mean_exp", "ssme_pf_download_state", "ssme_pf_download_scalars", "ssme_pf_set_debug",
     "ssme_pf_set_graph_mode", "ssme_pf_set_tuning", "ssme_pf_last_elapsed_ms", "ssme_pf_profile_series", "ssme_pf_test_math",
@@ -33,7 +33,7 @@ EXPORTS = [
     "ssme_lw_get_param_means", "ssme_lw_get_expectations", "ssme_lw_download_weights", "ssme_lw_download_state", "ssme_lw_set_debug", "ssme_lw_last_elapsed_ms",
     "ssme_lw_last_error",
     "ssme_lw_shard_create", "ssme_lw_set_stream", "ssme_lw_shard_set_plane_tiles", "ssme_lw_shard_prepare", "ssme_lw_shard_init", "ssme_lw_shard_plan",
-    "ssme_lw_shard_stage1", "ssme_lw_shard_mid", "ssme_lw_shard_stage2", "ssme_lw_shard_finalize", "ssme_lw_get_loglik", "ssme_lw_shard_run_series", "ssme_lw_shard_download", "ssme_lw_shard_stats",
+    "ssme_lw_shard_stage1", "ssme_lw_shard_mid", "ssme_lw_shard_stage2", "ssme_lw_shard_finalize", "ssme_lw_get_loglik", "ssme_lw_shard_run_series", "ssme_lw_shard_download", "ssme_lw_shard_stats", "ssme_lw_shard_layout",
 ]
 
 
@@ -129,6 +129,7 @@ def lib():
         L.ssme_pf_shard_run_series.argtypes = [H, C.c_void_p, dp, dp, C.c_int32, C.c_int32, dp]
         L.ssme_pf_shard_download.argtypes = [H, dp, u64p, i32p, C.POINTER(C.c_int64)]
         L.ssme_pf_shard_stats.argtypes = [H, i32p]
+        L.ssme_pf_shard_layout.argtypes = [H, i32p]
         L.ssme_pf_set_seed.argtypes = [H, C.c_uint64]
         L.ssme_pf_set_small_series.argtypes = [H, C.c_int32]
         L.ssme_lw_create.argtypes = [C.POINTER(LwConfig), C.POINTER(H)]
@@ -158,6 +159,7 @@ def lib():
         L.ssme_lw_shard_run_series.argtypes = [H, vp, dp, dp, C.c_int32, dp]
         L.ssme_lw_shard_download.argtypes = [H, dp, dp, C.POINTER(C.c_int64)]
         L.ssme_lw_shard_stats.argtypes = [H, i32p]
+        L.ssme_lw_shard_layout.argtypes = [H, i32p]
         L.ssme_lw_last_error.restype = C.c_char_p
         L.ssme_lw_last_error.argtypes = [H]
         L.ssme_pf_strerror.restype = C.c_char_p

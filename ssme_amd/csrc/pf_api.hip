@@ -28,7 +28,8 @@ struct ssme_pf_s {
     bool params_set;
     int debug_anc, keep_logw;
     int graph_mode;
-    int shard_rank, shard_world;   // particle-sharded filter: this handle computes tiles [rank*B/world, (rank+1)*B/world); world = 0: unsharded
+    int shard_rank, shard_world;   // particle-sharded filter: this handle computes tiles [rank*Bl, rank*Bl + sh_Bown); world = 0: unsharded
+    int sh_Bl, sh_Bown;            // Bl = ceil(B / world) tiles per rank in every layout (gathers, halos); the last rank owns B - (world-1) Bl >= 1 of them
     hipStream_t own_stream;  // the stream created with the handle (stream may be replaced by ssme_pf_set_stream)
     int32_t* plan_dev;       // [world][2] source-tile ranges (k_shard_plan)
     int split_l2;            // 1: level-2 by k_level2_plan (filters of more than 2048 tiles, or forced by set_debug bit 2)
@@ -200,7 +201,7 @@ static StepArgs step_args(ssme_pf_handle h) {
     }
     {
         // two 512-thread workgroups fit a CU (LDS): is the whole grid resident at once?
-        const long blocks = (long)(h->shard_world > 0 ? h->B / h->shard_world : h->B) * h->R;
+        const long blocks = (long)(h->shard_world > 0 ? h->sh_Bown : h->B) * h->R;
         a.prio_mode = (blocks <= 2L * h->num_cus) ? 1 : 2;
         static const char* force = getenv("SSME_PRIO_MODE");         // measurement aid: 0 none, 1 / 2 the two schedules, 3.. experimental
         if (force) a.prio_mode = atoi(force);
@@ -522,6 +523,10 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     if (!h) return SSME_ERR_INVALID_ARG;
     h->cfg = *cfg;
     h->shard_rank = shard_rank; h->shard_world = shard_world;
+    if (shard_world > 0) {
+        h->sh_Bl = (B + shard_world - 1) / shard_world;
+        h->sh_Bown = B - shard_rank * h->sh_Bl < h->sh_Bl ? B - shard_rank * h->sh_Bl : h->sh_Bl;
+    }
     h->tile = tile;
     h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * tile;
     h->Bs = (B + 1) & ~1; h->Bpow2 = next_pow2(B);
@@ -635,8 +640,21 @@ int ssme_pf_shard_create(const ssme_pf_config* cfg, int32_t rank, int32_t world,
     if (!cfg || !out) return SSME_ERR_INVALID_ARG;
     if (world < 1 || world > 64 || rank < 0 || rank >= world) return SSME_ERR_INVALID_ARG;
     if (cfg->n_filters != 1 || cfg->resamp_sched < 1) return SSME_ERR_UNSUPPORTED;
-    if (cfg->n_particles < 1 || cfg->n_particles % (kTile * world) != 0) return SSME_ERR_UNSUPPORTED;   // equal whole tiles per rank
+    if (cfg->n_particles < 1) return SSME_ERR_UNSUPPORTED;
+    {
+        // ceil(B / world) tiles per rank; the last rank takes what is left (fewer tiles, a ragged last tile) and must own at least one
+        const int B = (cfg->n_particles + kTile - 1) / kTile, Bl = (B + world - 1) / world;
+        if ((world - 1) * Bl >= B) return SSME_ERR_UNSUPPORTED;
+    }
     return create_impl(cfg, rank, world, out);
+}
+
+int ssme_pf_shard_layout(ssme_pf_handle h, int32_t* out4) {
+    if (!h || !out4) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1) return SSME_ERR_STATE;
+    const long first = (long)h->shard_rank * h->sh_Bl * kTile, own = (long)h->sh_Bown * kTile;
+    out4[0] = h->B; out4[1] = h->sh_Bl; out4[2] = h->sh_Bown; out4[3] = (int32_t)(h->N - first < own ? h->N - first : own);
+    return SSME_OK;
 }
 
 int ssme_pf_set_stream(ssme_pf_handle h, void* hip_stream) {
@@ -685,10 +703,10 @@ static void shard_plan_device(ssme_pf_handle h, int t, const double* tsum_all, c
         a.finalize_prev = 1;
         launch_level2(h->stream, a, 1, h->lds_bytes_plan, 1);
         if (flag) hipLaunchKernelGGL(k_shard_window_check, dim3(1), dim3(64), 0, h->stream, (const int32_t*)nullptr, (const int32_t*)h->l2_lo,
-                                     (const int32_t*)h->l2_hi, h->shard_world, h->B / h->shard_world, margin, flag, flag + 1);
+                                     (const int32_t*)h->l2_hi, h->shard_world, h->sh_Bl, h->B, margin, flag, flag + 1);
     } else {
         hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(512), sizeof(double) * (h->Bpow2 < 2 ? 2 : h->Bpow2), h->stream, a,
-                           h->shard_world, h->plan_dev, margin, flag);
+                           h->shard_world, h->sh_Bl, h->plan_dev, margin, flag);
     }
 }
 
@@ -701,13 +719,14 @@ int ssme_pf_shard_plan(ssme_pf_handle h, const double* tsum_all, const double* t
     int32_t* stage = reinterpret_cast<int32_t*>(h->pin + 2 + h->R);            // pinned
     if (h->split_l2) {
         // more than 1024 tiles in total: the split level-2 plans every tile; a rank's window is [lo of its first tile, hi of its last]
-        const int Bl = h->B / h->shard_world;
+        const int Bl = h->sh_Bl;
         const bool sorted = h->cfg.resampler != SSME_RESAMP_MULTINOMIAL_IID;
         for (int d = 0; d < h->shard_world; ++d) {
             stage[2 * d] = 0; stage[2 * d + 1] = h->B - 1;
             if (sorted) {
                 HIPCHK(hipMemcpyAsync(stage + 2 * d, h->l2_lo + (size_t)d * Bl, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(hipMemcpyAsync(stage + 2 * d + 1, h->l2_hi + (size_t)(d + 1) * Bl - 1, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+                const size_t last = (size_t)(d + 1) * Bl - 1 < (size_t)h->B - 1 ? (size_t)(d + 1) * Bl - 1 : (size_t)h->B - 1;     // the last rank may own fewer tiles
+                HIPCHK(hipMemcpyAsync(stage + 2 * d + 1, h->l2_hi + last, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
             }
         }
     } else {
@@ -735,9 +754,8 @@ int ssme_pf_shard_step(ssme_pf_handle h, int32_t t, const double* x_win, const d
     a.x_out = x_out; a.cdf_out = cdf_out; a.tsum_out = tsum_out; a.tmax_out = tmax_out;
     a.anc = anc_out;
     a.finalize_prev = t > 0 ? 1 : 0;
-    const int Bl = h->B / h->shard_world;
-    a.tile0 = h->shard_rank * Bl;
-    launch_step_on(h, a, dim3(Bl, 1));
+    a.tile0 = h->shard_rank * h->sh_Bl;
+    launch_step_on(h, a, dim3(h->sh_Bown, 1));
     HIPCHK(hipGetLastError());
     h->t = t + 1;
     return SSME_OK;
@@ -791,7 +809,7 @@ int ssme_shard_comm_destroy(void* comm) {
 }
 
 static int shard_alloc(ssme_pf_handle h, bool exact) {
-    const int world = h->shard_world, Bl = h->B / world;
+    const int world = h->shard_world, Bl = h->sh_Bl;
     if (!h->sh_x[0]) {
         // halo margin: a rank's resampling window normally reaches a tile or two into its neighbours (the cumulative tile
         // weights wander like sqrt(tiles) around the uniform split); 4 tiles or 1/64 of the share, never more than the share
@@ -805,9 +823,11 @@ static int shard_alloc(ssme_pf_handle h, bool exact) {
             HIPCHK(hipMalloc(&h->sh_c[i], nb)); HIPCHK(hipMemset(h->sh_c[i], 0, nb));
         }
         HIPCHK(hipMalloc(&h->sh_loc, sizeof(double) * 2 * Bl));
-        HIPCHK(hipMalloc(&h->sh_raw, sizeof(double) * 2 * (size_t)h->B));
-        HIPCHK(hipMalloc(&h->sh_tsum, sizeof(double) * h->Bs));
-        HIPCHK(hipMalloc(&h->sh_tmax, sizeof(double) * h->Bs));
+        const size_t nall = (size_t)world * Bl > (size_t)h->Bs ? (size_t)world * Bl : (size_t)h->Bs;   // gathered: world x Bl entries, the first B are tiles
+        HIPCHK(hipMalloc(&h->sh_raw, sizeof(double) * 2 * nall));
+        HIPCHK(hipMalloc(&h->sh_tsum, sizeof(double) * nall));
+        HIPCHK(hipMalloc(&h->sh_tmax, sizeof(double) * nall));
+        HIPCHK(hipMemset(h->sh_loc, 0, sizeof(double) * 2 * Bl));
         HIPCHK(hipMalloc(&h->sh_flag, sizeof(int32_t) * 4));
     }
     if (exact && !h->sh_winx) {
@@ -819,7 +839,8 @@ static int shard_alloc(ssme_pf_handle h, bool exact) {
 
 // tile sums and tile maxima of all ranks, each straight into its final [B] array: two all-gathers in one group (one launch)
 static int shard_gather(ssme_pf_handle h, ncclComm_t comm) {
-    const int world = h->shard_world, Bl = h->B / world;
+    const int world = h->shard_world, Bl = h->sh_Bl;
+    (void)world;
     NCCLCHK(rccl().GroupStart());
     NCCLCHK(rccl().AllGather(h->sh_loc, h->sh_tsum, (size_t)Bl, ncclDouble, comm, h->stream));
     NCCLCHK(rccl().AllGather(h->sh_loc + Bl, h->sh_tmax, (size_t)Bl, ncclDouble, comm, h->stream));
@@ -829,7 +850,7 @@ static int shard_gather(ssme_pf_handle h, ncclComm_t comm) {
 
 // One series on one path.  fast: fixed halo exchange, no host synchronisation inside the loop; exact: planned exchange.
 static int shard_series(ssme_pf_handle h, ncclComm_t comm, const double* y, const double* z, int T, bool fast, bool* overflow) {
-    const int world = h->shard_world, rank = h->shard_rank, Bl = h->B / world, m = h->sh_margin, tile0 = rank * Bl;
+    const int world = h->shard_world, rank = h->shard_rank, Bl = h->sh_Bl, m = h->sh_margin, tile0 = rank * Bl;
     const size_t TL = kTile;
     int rc = ssme_pf_shard_prepare(h, y, z, T);
     if (rc != SSME_OK) return rc;
@@ -961,7 +982,9 @@ int ssme_pf_shard_download(ssme_pf_handle h, double* x_local, uint64_t* cdf_loca
     if (!h) return SSME_ERR_INVALID_ARG;
     if (h->shard_world < 1 || !h->sh_x[0]) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
-    const size_t n = (size_t)(h->B / h->shard_world) * kTile, off = (size_t)h->sh_margin * kTile;
+    // this rank's particles: Bl tiles, fewer on the last rank (and its last tile may be ragged)
+    const size_t first = (size_t)h->shard_rank * h->sh_Bl * kTile, off = (size_t)h->sh_margin * kTile;
+    const size_t n = (size_t)h->N - first < (size_t)h->sh_Bown * kTile ? (size_t)h->N - first : (size_t)h->sh_Bown * kTile;
     if (x_local) HIPCHK(hipMemcpy(x_local, h->sh_x[h->cur] + off, sizeof(double) * n, hipMemcpyDeviceToHost));
     if (cdf_local) {
         HIPCHK(hipMemcpy(cdf_local, h->sh_c[h->cur] + off, sizeof(double) * n, hipMemcpyDeviceToHost));
@@ -1595,7 +1618,8 @@ struct ssme_lw_s {
     uint32_t *anc, *kidx, *keybuf;
     uint32_t* ancbuf;        // unsharded handles: this step's resampling ancestors, stage 1 -> stage 2 (compose mode, lw_kernels.h)
     int shard_rank, shard_world;     // particle-sharded filter (world = 0: unsharded)
-    int th_plane_tiles;              // sharded: rows (tiles) per theta plane of the caller's OUTPUT buffers (default B / world)
+    int th_plane_tiles;              // sharded: rows (tiles) per theta plane of the caller's OUTPUT buffers (default Bl)
+    int sh_Bl, sh_Bown;              // Bl = ceil(B / world) tiles per rank in every layout; the last rank owns B - (world-1) Bl >= 1 of them
     hipStream_t own_stream;
     int32_t* plan_dev;
     int32_t* plan_pin;               // pinned staging of the plan download
@@ -1807,6 +1831,10 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
     h->cfg = *cfg;
     h->form = cfg->form; h->rs = cfg->resamp_sched < 1 ? 1 : cfg->resamp_sched;
     h->shard_rank = shard_rank; h->shard_world = shard_world;
+    if (shard_world > 0) {
+        h->sh_Bl = (B + shard_world - 1) / shard_world;
+        h->sh_Bown = B - shard_rank * h->sh_Bl < h->sh_Bl ? B - shard_rank * h->sh_Bl : h->sh_Bl;
+    }
     h->N = cfg->n_particles; h->R = cfg->n_filters; h->B = B; h->Npad = B * kTile;
     h->Bs = (B + 1) & ~1; h->Bpow2 = next_pow2(B);
     h->rshift = 52 - ceil_log2(h->Npad);
@@ -1849,7 +1877,7 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
         } else {
             LWCHK(hipMalloc(&h->plan_dev, sizeof(int32_t) * 2 * h->shard_world));
             LWCHK(hipHostMalloc(reinterpret_cast<void**>(&h->plan_pin), sizeof(int32_t) * 2 * h->shard_world, hipHostMallocDefault));
-            h->th_plane_tiles = h->B / h->shard_world;
+            h->th_plane_tiles = h->sh_Bl;
         }
         LWCHK(hipMalloc(&h->mom, sizeof(double) * (size_t)h->R * h->B * 16));
         LWCHK(hipMalloc(&h->prop, sizeof(double) * (size_t)h->R * 16));
@@ -1887,8 +1915,21 @@ int ssme_lw_shard_create(const ssme_lw_config* cfg, int32_t rank, int32_t world,
     if (!cfg || !out) return SSME_ERR_INVALID_ARG;
     if (world < 1 || world > 64 || rank < 0 || rank >= world) return SSME_ERR_INVALID_ARG;
     if (cfg->n_filters != 1) return SSME_ERR_UNSUPPORTED;
-    if (cfg->n_particles < 1 || cfg->n_particles % (kTile * world) != 0) return SSME_ERR_UNSUPPORTED;
+    if (cfg->n_particles < 1) return SSME_ERR_UNSUPPORTED;
+    {
+        // ceil(B / world) tiles per rank; the last rank takes what is left and must own at least one tile (ssme_pf_shard_create)
+        const int B = (cfg->n_particles + kTile - 1) / kTile, Bl = (B + world - 1) / world;
+        if ((world - 1) * Bl >= B) return SSME_ERR_UNSUPPORTED;
+    }
     return lw_create_impl(cfg, rank, world, out);
+}
+
+int ssme_lw_shard_layout(ssme_lw_handle h, int32_t* out4) {
+    if (!h || !out4) return SSME_ERR_INVALID_ARG;
+    if (h->shard_world < 1) return SSME_ERR_STATE;
+    const long first = (long)h->shard_rank * h->sh_Bl * kTile, own = (long)h->sh_Bown * kTile;
+    out4[0] = h->B; out4[1] = h->sh_Bl; out4[2] = h->sh_Bown; out4[3] = (int32_t)(h->N - first < own ? h->N - first : own);
+    return SSME_OK;
 }
 
 int ssme_lw_set_stream(ssme_lw_handle h, void* hip_stream) {
@@ -1902,7 +1943,7 @@ int ssme_lw_set_stream(ssme_lw_handle h, void* hip_stream) {
 int ssme_lw_shard_set_plane_tiles(ssme_lw_handle h, int32_t tiles) {
     if (!h || tiles < 1) return SSME_ERR_INVALID_ARG;
     if (h->shard_world < 1) return SSME_ERR_STATE;
-    if (tiles < h->B / h->shard_world) return SSME_ERR_INVALID_ARG;
+    if (tiles < h->sh_Bl) return SSME_ERR_INVALID_ARG;
     h->th_plane_tiles = tiles;
     return SSME_OK;
 }
@@ -1926,7 +1967,7 @@ int ssme_lw_shard_prepare(ssme_lw_handle h, const double* y, const double* z, in
 
 static LwArgs lw_shard_args(ssme_lw_handle h, int t) {
     LwArgs a = lw_args(h);
-    const int Bl = h->B / h->shard_world;
+    const int Bl = h->sh_Bl;
     a.t = t; a.yi = t; a.gi = t; a.finalize_prev = t > 1 || t == 1 ? 1 : 0;
     a.per_step = h->per_step;
     a.tile0 = h->shard_rank * Bl;
@@ -1941,7 +1982,7 @@ int ssme_lw_shard_init(ssme_lw_handle h, double* xB, double* thB, double* cdfB, 
     LWCHK(hipSetDevice(h->cfg.device));
     LwArgs a = lw_shard_args(h, 0);
     a.xB = xB; a.thB = thB; a.cdfB = cdfB; a.tsumB = tsumB; a.tmaxB = tmaxB;
-    hipLaunchKernelGGL(k_lw_init, dim3(h->B / h->shard_world, 1), dim3(kLwNT), 0, h->stream, a);
+    hipLaunchKernelGGL(k_lw_init, dim3(h->sh_Bown, 1), dim3(kLwNT), 0, h->stream, a);
     LWCHK(hipGetLastError());
     h->t = 1;
     return SSME_OK;
@@ -1955,10 +1996,11 @@ int ssme_lw_shard_plan(ssme_lw_handle h, int32_t which, int32_t t, const double*
     if (h->split_l2) {
         lw_launch_plan(h, which, t, t, tsum_all, tmax_all, true);
         LWCHK(hipGetLastError());
-        const int Bl = h->B / h->shard_world;
+        const int Bl = h->sh_Bl;
         for (int d = 0; d < h->shard_world; ++d) {
+            const size_t last = (size_t)(d + 1) * Bl - 1 < (size_t)h->B - 1 ? (size_t)(d + 1) * Bl - 1 : (size_t)h->B - 1;
             LWCHK(hipMemcpyAsync(h->plan_pin + 2 * d, h->l2lo[which] + (size_t)d * Bl, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-            LWCHK(hipMemcpyAsync(h->plan_pin + 2 * d + 1, h->l2hi[which] + (size_t)(d + 1) * Bl - 1, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            LWCHK(hipMemcpyAsync(h->plan_pin + 2 * d + 1, h->l2hi[which] + last, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         }
         LWCHK(wait_stream_low_latency(h->stream));
         for (int d = 0; d < 2 * h->shard_world; ++d) lo_hi[d] = h->plan_pin[d];
@@ -1972,7 +2014,7 @@ int ssme_lw_shard_plan(ssme_lw_handle h, int32_t which, int32_t t, const double*
     a.pgam = which ? h->pgamA : h->pgamB; a.gtot = which ? h->gtotA : h->gtotB;
     a.keyp = h->keybuf; a.first_filter = h->cfg.first_filter_id;
     hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(512), sizeof(double) * (h->Bpow2 < 2 ? 2 : h->Bpow2), h->stream, a,
-                       h->shard_world, h->plan_dev);
+                       h->shard_world, h->sh_Bl, h->plan_dev);
     LWCHK(hipGetLastError());
     LWCHK(hipMemcpyAsync(h->plan_pin, h->plan_dev, sizeof(int32_t) * 2 * h->shard_world, hipMemcpyDeviceToHost, h->stream));
     LWCHK(wait_stream_low_latency(h->stream));
@@ -1995,8 +2037,8 @@ int ssme_lw_shard_stage1(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t
     a.win_tile0 = win_tile0; (void)win_tiles;
     a.xr = xr; a.thr = thr; a.lw1 = lw1; a.cdfA = cdfA; a.tsumA = tsumA; a.tmaxA = tmaxA; a.mom = mom;
     a.anc = anc;
-    if (h->split_l2) hipLaunchKernelGGL(k_lw_stage1<true>, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes_big, h->stream, a);
-    else hipLaunchKernelGGL(k_lw_stage1<false>, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes, h->stream, a);
+    if (h->split_l2) hipLaunchKernelGGL(k_lw_stage1<true>, dim3(h->sh_Bown, 1), dim3(kLwNT), h->lds_bytes_big, h->stream, a);
+    else hipLaunchKernelGGL(k_lw_stage1<false>, dim3(h->sh_Bown, 1), dim3(kLwNT), h->lds_bytes, h->stream, a);
     LWCHK(hipGetLastError());
     return SSME_OK;
 }
@@ -2036,8 +2078,8 @@ int ssme_lw_shard_stage2(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t
     a.win_tile0 = win_tile0; (void)win_tiles;
     a.xB = xB; a.thB = thB; a.cdfB = cdfB; a.tsumB = tsumB; a.tmaxB = tmaxB;
     a.kidx = kidx;
-    if (h->split_l2) hipLaunchKernelGGL(k_lw_stage2<true>, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes_big, h->stream, a);
-    else hipLaunchKernelGGL(k_lw_stage2<false>, dim3(h->B / h->shard_world, 1), dim3(kLwNT), h->lds_bytes, h->stream, a);
+    if (h->split_l2) hipLaunchKernelGGL(k_lw_stage2<true>, dim3(h->sh_Bown, 1), dim3(kLwNT), h->lds_bytes_big, h->stream, a);
+    else hipLaunchKernelGGL(k_lw_stage2<false>, dim3(h->sh_Bown, 1), dim3(kLwNT), h->lds_bytes, h->stream, a);
     LWCHK(hipGetLastError());
     h->t = t + 1;
     return SSME_OK;
@@ -2070,7 +2112,7 @@ int ssme_lw_shard_finalize(ssme_lw_handle h, int32_t t, const double* tsumB_all,
 
 static int lw_shard_alloc(ssme_lw_handle h) {
     if (h->sh_xB) return SSME_OK;
-    const int world = h->shard_world, Bl = h->B / world;
+    const int world = h->shard_world, Bl = h->sh_Bl;
     int m = Bl / 64 > 4 ? Bl / 64 : 4;
     if (m > Bl) m = Bl;
     if (world == 1) m = 0;
@@ -2084,15 +2126,17 @@ static int lw_shard_alloc(ssme_lw_handle h) {
     LWCHK(hipMalloc(&h->sh_locA, sizeof(double) * 18 * Bl));                 // tile sums | tile maxima | 16 moment slots per tile
     LWCHK(hipMemset(h->sh_locA, 0, sizeof(double) * 18 * Bl));
     double** all[] = {&h->sh_allB_s, &h->sh_allB_m, &h->sh_allA_s, &h->sh_allA_m};
-    for (auto p : all) LWCHK(hipMalloc(p, sizeof(double) * h->Bs));
-    LWCHK(hipMalloc(&h->sh_mom_all, sizeof(double) * (size_t)h->B * 16));
+    const size_t nall = (size_t)world * Bl > (size_t)h->Bs ? (size_t)world * Bl : (size_t)h->Bs;        // gathered: world x Bl entries, the first B are tiles
+    for (auto p : all) LWCHK(hipMalloc(p, sizeof(double) * nall));
+    LWCHK(hipMalloc(&h->sh_mom_all, sizeof(double) * nall * 16));
+    LWCHK(hipMemset(h->sh_locB, 0, sizeof(double) * 2 * Bl));
     LWCHK(hipMalloc(&h->sh_flag, sizeof(int32_t) * 4));
     return SSME_OK;
 }
 
 // halo exchange with the two neighbouring ranks for a list of buffers (rows of `width` doubles per tile)
 static int lw_halo_exchange(ssme_lw_handle h, ncclComm_t comm, std::initializer_list<std::pair<double*, size_t>> bufs) {
-    const int world = h->shard_world, rank = h->shard_rank, Bl = h->B / world, m = h->sh_margin;
+    const int world = h->shard_world, rank = h->shard_rank, Bl = h->sh_Bl, m = h->sh_margin;
     if (world == 1 || m == 0) return SSME_OK;
     LWNCCL(rccl().GroupStart());
     for (auto& bw : bufs) {
@@ -2121,7 +2165,8 @@ int ssme_lw_shard_run_series(ssme_lw_handle h, void* nccl_comm, const double* y,
     ncclComm_t comm = reinterpret_cast<ncclComm_t>(nccl_comm);
     int rc = lw_shard_alloc(h);
     if (rc != SSME_OK) return rc;
-    const int world = h->shard_world, Bl = h->B / world, m = h->sh_margin, tile0 = h->shard_rank * Bl;
+    const int world = h->shard_world, Bl = h->sh_Bl, m = h->sh_margin, tile0 = h->shard_rank * Bl;
+    (void)world;
     const size_t TL = kTile, off = (size_t)m * TL;
     rc = ssme_lw_shard_set_plane_tiles(h, h->sh_rows);
     if (rc != SSME_OK) return rc;
@@ -2190,7 +2235,8 @@ int ssme_lw_shard_download(ssme_lw_handle h, double* x_local, double* theta_loca
     if (!h) return SSME_ERR_INVALID_ARG;
     if (h->shard_world < 1 || !h->sh_xB) return SSME_ERR_STATE;
     LWCHK(hipSetDevice(h->cfg.device));
-    const size_t n = (size_t)(h->B / h->shard_world) * kTile, off = (size_t)h->sh_margin * kTile;
+    const size_t first = (size_t)h->shard_rank * h->sh_Bl * kTile, off = (size_t)h->sh_margin * kTile;
+    const size_t n = (size_t)h->N - first < (size_t)h->sh_Bown * kTile ? (size_t)h->N - first : (size_t)h->sh_Bown * kTile;      // fewer on the last rank
     if (x_local) LWCHK(hipMemcpy(x_local, h->sh_xB + off, sizeof(double) * n, hipMemcpyDeviceToHost));
     if (theta_local) {
         std::vector<double> rec(n * kDP);

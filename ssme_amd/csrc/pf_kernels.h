@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(1024) void k_l2_ranges(const StepArgs a, int plan_r
 // Runs the same level-2 and the same target bounds as k_filter_step, so the ranges are exact.
 // grid = 1, block = 512, dynamic LDS = max(Bpow2, 2) doubles.  lo_hi: [world][2] ints.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_shard_plan(const StepArgs a, int world, int32_t* lo_hi, int margin = 0, int32_t* flag = nullptr) {
+__global__ __launch_bounds__(512) void k_shard_plan(const StepArgs a, int world, int Bl, int32_t* lo_hi, int margin = 0, int32_t* flag = nullptr) {
     constexpr int NT = 512, NE = 2048 / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_plan[];
     double* lds_T = reinterpret_cast<double*>(smem_plan);
@@ -1544,7 +1544,7 @@ __global__ __launch_bounds__(512) void k_shard_plan(const StepArgs a, int world,
     }
     __syncthreads();
     if (tid < world) {
-        const int Bl = a.B / world, bF = tid * Bl, bL = bF + Bl - 1;
+        const int bF = tid * Bl, bL = bF + Bl - 1 < a.B - 1 ? bF + Bl - 1 : a.B - 1;      // Bl = ceil(B / world): the last rank may own fewer
         int lo = 0, hi = a.B - 1;
         if (a.resampler != RESAMP_MULTINOMIAL_IID) {
             const uint32_t key0 = a.keyp[0], key1 = a.keyp[1];

@@ -68,13 +68,14 @@ static const RcclApi& rccl() {
 
 // Does every rank's window [lo, hi] stay inside [first own tile - margin, last own tile + margin]?  lo_hi: [world][2]
 // (k_shard_plan), or null: the per-tile ranges of k_level2_plan (window = [lo of the rank's first tile, hi of its last]).
-__global__ void k_shard_window_check(const int32_t* lo_hi, const int32_t* l2_lo, const int32_t* l2_hi, int world, int Bl, int margin,
+__global__ void k_shard_window_check(const int32_t* lo_hi, const int32_t* l2_lo, const int32_t* l2_hi, int world, int Bl, int B, int margin,
                                      int32_t* flag, int32_t* stats /*[2]: max tiles needed left / right of the own range*/) {
     const int g = threadIdx.x;
     if (g >= world) return;
+    const int last = (g + 1) * Bl - 1 < B - 1 ? (g + 1) * Bl - 1 : B - 1;       // the last rank may own fewer than Bl tiles
     const int lo = lo_hi ? lo_hi[2 * g] : l2_lo[(size_t)g * Bl];
-    const int hi = lo_hi ? lo_hi[2 * g + 1] : l2_hi[(size_t)(g + 1) * Bl - 1];
-    const int left = g * Bl - lo, right = hi - ((g + 1) * Bl - 1);
+    const int hi = lo_hi ? lo_hi[2 * g + 1] : l2_hi[last];
+    const int left = g * Bl - lo, right = hi - last;
     if (left > margin || right > margin) atomicOr(flag, 1);
     if (left > 0) atomicMax(&stats[0], left);
     if (right > 0) atomicMax(&stats[1], right);

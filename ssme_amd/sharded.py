@@ -1,6 +1,7 @@
 """One particle filter sharded over the GPUs of a node.
 
-One process per GPU; rank g owns N/G consecutive particles = B/G tiles of 2048.  A time step is
+One process per GPU; rank g owns Bl = ceil(B / G) consecutive tiles of 2048 particles (the last rank what is left of the
+B = ceil(N / 2048): `shard_layout`).  A time step is
 
     1. all_gather of the per-tile weight sums and maxima of step t-1 (B x 16 bytes in total).  Every rank then runs
        the SAME exact level-2 (global max, rescaled integer tile sums, exact scan): the global log-sum-exp, hence
@@ -29,7 +30,21 @@ from ._capi import SsmeError
 
 TILE = 2048
 
-__all__ = ["ShardedParticleFilter", "ShardedLiuWest", "exchange_plan", "TILE"]
+__all__ = ["ShardedParticleFilter", "ShardedLiuWest", "exchange_plan", "shard_layout", "TILE"]
+
+
+def shard_layout(n_particles, rank, world):
+    """(N, B, Bl, tiles this rank owns, particles this rank owns): B = ceil(N / 2048) tiles, Bl = ceil(B / world) rows per rank
+    in every layout; rank g owns tiles [g Bl, min((g + 1) Bl, B)) -- the last rank may own fewer tiles and a ragged last one,
+    and must own at least one (include/ssme_pf.h: ssme_pf_shard_create)."""
+    n = int(n_particles)
+    B = (n + TILE - 1) // TILE
+    Bl = (B + world - 1) // world
+    if n < 1 or (world - 1) * Bl >= B:
+        raise SsmeError(capi.ERR_UNSUPPORTED, f"{n} particles = {B} tiles of {TILE} do not give each of {world} ranks a tile "
+                                              f"({Bl} per rank)")
+    own = min(Bl, B - rank * Bl)
+    return n, B, Bl, own, min(own * TILE, n - rank * Bl * TILE)
 
 
 def exchange_plan(lo_hi, tiles_per_rank, rank):
@@ -190,10 +205,7 @@ class ShardedParticleFilter:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.stage = self.backend != "nccl"                     # gloo rehearsal: collectives on host copies
-        if n_particles % (TILE * self.world) != 0:
-            raise SsmeError(capi.ERR_UNSUPPORTED, f"n_particles must be a multiple of {TILE} x world ({self.world})")
-        self.n, self.B = int(n_particles), n_particles // TILE
-        self.Bl = self.B // self.world
+        self.n, self.B, self.Bl, self.Bown, self.n_local = shard_layout(n_particles, self.rank, self.world)
         self.tile0 = self.rank * self.Bl
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.resamp_sched = int(resamp_sched)
@@ -212,7 +224,7 @@ class ShardedParticleFilter:
         self._hc = [HaloBuffer(self.Bl, TILE, margin, self.device, torch.float64) for _ in range(2)]
         self._cur = 0
         self.tiles_loc = torch.zeros((2, self.Bl), **f64)       # row 0: tile sums, row 1: tile maxima
-        self.tiles_all = torch.zeros((2, self.B), **f64)
+        self.tiles_all = torch.zeros((2, self.world * self.Bl), **f64)      # gathered: world x Bl entries, the first B are tiles
         self.anc = None
         self.exchanged_tiles = 0                                # tiles received from other ranks (statistics)
         self._T = 0
@@ -317,10 +329,10 @@ class ShardedParticleFilter:
         return out[0]
 
     def local_particles(self):
-        return self._hx[self._cur].own().reshape(-1).cpu().numpy()
+        return self._hx[self._cur].own().reshape(-1)[:self.n_local].cpu().numpy()
 
     def local_cdf(self):
-        return self._hc[self._cur].own().reshape(-1).cpu().numpy()
+        return self._hc[self._cur].own().reshape(-1)[:self.n_local].cpu().numpy()
 
     # ---- the same loop in C++ over RCCL (ssme_pf_shard_run_series): no Python, no host synchronisation per step ----
     def _native_comm(self):
@@ -344,7 +356,7 @@ class ShardedParticleFilter:
 
     def native_state(self):
         """(particles, integer cdf, path, tiles received) of this rank after run_series_native."""
-        n = self.Bl * TILE
+        n = self.n_local
         x, cdf = np.empty(n), np.empty(n, dtype=np.uint64)
         path, ex = C.c_int32(), C.c_int64()
         self._chk(capi.lib().ssme_pf_shard_download(self._h, capi.dptr(x), capi.u64ptr(cdf), C.byref(path), C.byref(ex)))
@@ -372,10 +384,7 @@ class ShardedLiuWest:
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.stage = dist.get_backend(group) != "nccl"
-        if nparts % (TILE * self.world) != 0:
-            raise SsmeError(capi.ERR_UNSUPPORTED, f"nparts must be a multiple of {TILE} x world ({self.world})")
-        self.n, self.B = int(nparts), nparts // TILE
-        self.Bl = self.B // self.world
+        self.n, self.B, self.Bl, self.Bown, self.n_local = shard_layout(nparts, self.rank, self.world)
         self.tile0 = self.rank * self.Bl
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.form = int(form)
@@ -402,9 +411,9 @@ class ShardedLiuWest:
         self._locA = torch.zeros(18 * Bl, **f64)             # stage-1 outputs in one buffer: tile sums | tile maxima | 16 moments per tile
         self.tilesA = self._locA[:2 * Bl].view(2, Bl)
         self.mom = self._locA[2 * Bl:].view(Bl, 16)
-        self.allB = torch.zeros((2, self.B), **f64)
-        self.allA = torch.zeros((2, self.B), **f64)
-        self.mom_all = torch.zeros((self.B, 16), **f64)
+        self.allB = torch.zeros((2, self.world * Bl), **f64)   # gathered: world x Bl entries, the first B are tiles
+        self.allA = torch.zeros((2, self.world * Bl), **f64)
+        self.mom_all = torch.zeros((self.world * Bl, 16), **f64)
         self.exchanged_tiles = 0
         self._T = 0
         torch.cuda.synchronize(self.device)
@@ -506,11 +515,11 @@ class ShardedLiuWest:
         return out[0]
 
     def local_particles(self):
-        return self.xB.own().reshape(-1).cpu().numpy()
+        return self.xB.own().reshape(-1)[:self.n_local].cpu().numpy()
 
     def local_theta(self):
-        """[4, N / world]: transformed parameters of this rank's particles (the device keeps [particle][4] records)."""
-        return self.thB.own().reshape(-1, 4).t().contiguous().cpu().numpy()
+        """[4, n_local]: transformed parameters of this rank's particles (the device keeps [particle][4] records)."""
+        return self.thB.own().reshape(-1, 4)[:self.n_local].t().contiguous().cpu().numpy()
 
     # ---- the same loop in C++ over RCCL (ssme_lw_shard_run_series) ----
     def run_series_native(self, y, z=None):
@@ -535,7 +544,7 @@ class ShardedLiuWest:
         return float(out[0])
 
     def native_state(self):
-        n = self.Bl * TILE
+        n = self.n_local
         x, th = np.empty(n), np.empty((4, n))
         ex = C.c_int64()
         self._chk(capi.lib().ssme_lw_shard_download(self._h, capi.dptr(x), capi.dptr(th), C.byref(ex)))

@@ -34,19 +34,21 @@ int main(int argc, char** argv) {
     std::vector<int> path(world, 0), own_flag(world, 0), any_flag(world, 0);
     std::vector<long long> exch(world, 0);
     std::vector<std::vector<double>> xs(world);
+    std::vector<size_t> first(world, 0);
     std::vector<std::thread> ranks;
     for (int r = 0; r < world; ++r) ranks.emplace_back([&, r] {
         void* comm = nullptr;
         int rc = ssme_shard_comm_init(id, r, world, 0, &comm);
         if (rc) die("comm_init", rc, "");
-        const size_t nloc = (size_t)N / world;
-        xs[r].resize(nloc);
+        int32_t lay[4] = {0, 0, 0, 0};                 // {B, Bl, tiles this rank owns, particles this rank owns}
         if (model >= 0) {
             ssme_pf_config c{};
             c.model = model; c.n_particles = N; c.n_filters = 1; c.dtype = SSME_F64; c.resampler = rs; c.resamp_sched = sched; c.seed = seed; c.device = 0;
             ssme_pf_handle h = nullptr;
             rc = ssme_pf_shard_create(&c, r, world, &h);
             if (rc) die("shard_create", rc, "");
+            if (ssme_pf_shard_layout(h, lay)) die("shard_layout", 1, "");
+            xs[r].resize((size_t)lay[3]); first[r] = (size_t)r * lay[1] * 2048;
             rc = ssme_pf_set_params(h, model == 0 ? th_svol : (model == 1 ? th_lev : th_lg), model == 1 ? 4 : 3, 1);
             if (rc) die("set_params", rc, ssme_pf_last_error(h));
             rc = ssme_pf_shard_run_series(h, comm, y.data(), model == 1 ? z.data() : nullptr, T, mode, &ll[r]);
@@ -67,6 +69,8 @@ int main(int argc, char** argv) {
             ssme_lw_handle h = nullptr;
             rc = ssme_lw_shard_create(&c, r, world, &h);
             if (rc) die("lw_shard_create", rc, "");
+            if (ssme_lw_shard_layout(h, lay)) die("lw_shard_layout", 1, "");
+            xs[r].resize((size_t)lay[3]); first[r] = (size_t)r * lay[1] * 2048;
             rc = ssme_lw_shard_run_series(h, comm, y.data(), z.data(), T, &ll[r]);
             path[r] = rc == SSME_ERR_STATE ? 2 : 1;                        // 2: a window left the halo (caller falls back)
             if (rc && rc != SSME_ERR_STATE) die("lw_shard_run_series", rc, ssme_lw_last_error(h));
@@ -106,10 +110,13 @@ int main(int argc, char** argv) {
         ssme_lw_download_state(h, 0, xref.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
         ssme_lw_destroy(h);
     }
-    size_t mism = 0;
-    for (int r = 0; r < world; ++r)
+    size_t mism = 0, held = 0;
+    for (int r = 0; r < world; ++r) {
+        held += xs[r].size();
         if (path[r] == 1 || model >= 0)
-            for (size_t i = 0; i < xs[r].size(); ++i) mism += xs[r][i] != xref[(size_t)r * (N / world) + i];
+            for (size_t i = 0; i < xs[r].size(); ++i) mism += xs[r][i] != xref[first[r] + i];
+    }
+    if (held != (size_t)N) mism += 1;                  // the ranks' shares add up to the filter
     std::printf("ref %.17g\n", ll_ref);
     // any_left_halo: the reduced flag of the last fixed-halo pass (identical on every rank); own_left_halo: what this rank's own workgroups saw
     for (int r = 0; r < world; ++r) std::printf("rank %d ll %.17g path %d exchanged %lld any_left_halo %d own_left_halo %d\n", r, ll[r], path[r], exch[r], any_flag[r], own_flag[r]);

@@ -29,7 +29,7 @@ def main():
     f.record_ancestors(True)
     ll = f.run_series(y, z)
     np.savez(out, ll=ll, per_step=f.per_step(), x=f.local_particles(), cdf=f.local_cdf(),
-             anc=f.anc.reshape(-1).cpu().numpy(), exchanged=f.exchanged_tiles)
+             anc=f.anc.reshape(-1)[:f.n_local].cpu().numpy(), exchanged=f.exchanged_tiles)
     f.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -105,8 +105,21 @@ def test_shard_and_liu_west_entry_points_validate_arguments():
     assert L.ssme_pf_shard_create(C.byref(cfg), 0, 3, C.byref(h)) == _capi.ERR_UNSUPPORTED        # 4 tiles over 3 ranks
     cfg.n_filters = 2
     assert L.ssme_pf_shard_create(C.byref(cfg), 0, 2, C.byref(h)) == _capi.ERR_UNSUPPORTED        # one filter only
-    cfg.n_filters, cfg.resamp_sched = 1, 2
-    assert L.ssme_pf_shard_create(C.byref(cfg), 0, 2, C.byref(h)) == _capi.ERR_UNSUPPORTED
+    cfg.n_filters, cfg.resamp_sched = 1, 0
+    assert L.ssme_pf_shard_create(C.byref(cfg), 0, 2, C.byref(h)) == _capi.ERR_UNSUPPORTED        # resamp_sched < 1
+    # accepted shapes get past the argument checks (and fail at the first HIP call where there is no device):
+    # a resampling schedule; N that is not whole tiles per rank (5 tiles + 1 particle over 2 ranks: 3 + 3, the last one ragged)
+    for n, sched in ((4 * 2048, 2), (5 * 2048 + 1, 1)):
+        cfg.n_particles, cfg.resamp_sched = n, sched
+        rc = L.ssme_pf_shard_create(C.byref(cfg), 1, 2, C.byref(h))
+        assert rc in (_capi.OK, _capi.ERR_HIP)
+        if rc == _capi.OK:
+            lay = (C.c_int32 * 4)()
+            assert L.ssme_pf_shard_layout(h, lay) == _capi.OK
+            assert list(lay) == ([4, 2, 2, 4096] if n == 4 * 2048 else [6, 3, 3, 2 * 2048 + 1])
+            L.ssme_pf_destroy(h)
+            h = C.c_void_p()
+    cfg.n_particles = 4 * 2048
     cfg.resamp_sched, cfg.dtype = 1, _capi.F32
     assert L.ssme_pf_shard_create(C.byref(cfg), 0, 2, C.byref(h)) == _capi.ERR_UNSUPPORTED        # float-at-the-boundary handles do not shard
     assert not h.value

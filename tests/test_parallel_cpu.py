@@ -93,6 +93,32 @@ def test_exchange_plan_covers_exactly_the_planned_windows():
                     assert cnt == 0 or (s * Bl <= first and first + cnt <= (s + 1) * Bl)
 
 
+def test_shard_layout_of_sizes_that_are_not_whole_tiles_per_rank():
+    """ceil(B / world) tiles per rank; the last rank owns what is left (fewer tiles, a ragged last tile) and at least one; plans
+    over such a layout (windows end at tile B - 1) still give contiguous windows."""
+    from ssme_amd.sharded import exchange_plan, shard_layout, TILE
+    from ssme_amd import SsmeError
+    for n, world in ((16384 + 2048 + 77, 2), (10 * 2048 + 5, 3), (1 << 24, 8), (2049, 2), (8 * 8 * 2048 - 9000, 8), (100000, 7)):
+        lay = [shard_layout(n, r, world) for r in range(world)]
+        B, Bl = lay[0][1], lay[0][2]
+        assert B == -(-n // TILE) and Bl == -(-B // world)
+        assert sum(l[3] for l in lay) == B and sum(l[4] for l in lay) == n
+        assert all(l[3] == Bl for l in lay[:-1]) and 1 <= lay[-1][3] <= Bl
+        assert all(l[4] == Bl * TILE for l in lay[:-1])
+        rng = np.random.default_rng(n)
+        for _ in range(20):
+            lo = np.sort(rng.integers(0, B, world))
+            hi = np.maximum(lo, np.sort(rng.integers(0, B, world)))
+            plan = list(zip(lo.tolist(), hi.tolist()))
+            for r in range(world):
+                sends, recvs = exchange_plan(plan, Bl, r)
+                tiles = [t for first, cnt in recvs for t in range(first, first + cnt)]
+                assert tiles == list(range(plan[r][0], plan[r][1] + 1))
+    for n, world in ((4 * 2048, 3), (100, 2), (2048, 2), (6 * 2048, 5), (8 * 4 * 2048 - 9000, 8)):          # the last rank would own nothing
+        with pytest.raises(SsmeError):
+            shard_layout(n, 0, world)
+
+
 def _exchange_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
