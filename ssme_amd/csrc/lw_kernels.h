@@ -735,6 +735,25 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
         for (int q = 0; q < 14; ++q) prop[q] = readfirstlane_f64(lds_prop[q]);
     }
     double lg[NK][2];
+    // The sources of the thread's 2 NK particles are two dependent gathers each (k -> the ancestor it composes with -> state,
+    // parameters).  All ancestor indices are requested at once; the records are then software-pipelined: particle p + 1's three
+    // loads are in flight while particle p's ~800 instructions run (all of them up front would need 12 more registers per
+    // particle and the kernel would lose a workgroup per CU).
+    const double* xsrc = a.compose ? a.xB : a.xr;
+    const double* thsrc = a.compose ? a.thB : a.thr;
+    int jsrc[NK][2];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) jsrc[k][c] = a.compose ? (int)a.ancbuf[rowoff + kk[k][c]] : kk[k][c];
+    }
+    double nx_x, nx_lw1, nx_th[kDP];
+    auto request = [&](int k, int c) {
+        nx_x = xsrc[rowoff + (jsrc[k][c] - win0)];
+        nx_lw1 = a.lw1[rowoff + (kk[k][c] - win0)];
+        th_load(thsrc, rowoff + (size_t)(jsrc[k][c] - win0), nx_th);
+    };
+    request(0, 0);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int i0 = i_first + (k * NT + tid) * 2;
@@ -745,12 +764,12 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
         for (int c = 0; c < 2; ++c) {
             const int i = i0 + c;
             const int j = kk[k][c];
-            // compose: the particle that continues is ancestor ancbuf[j] of the population the step started from
-            const int js = a.compose ? (int)a.ancbuf[rowoff + j] : j;
-            const double* xsrc = a.compose ? a.xB : a.xr;
-            const double* thsrc = a.compose ? a.thB : a.thr;
-            const double xk = xsrc[rowoff + (js - win0)];
-            const double lw1k = a.lw1[rowoff + (j - win0)];
+            const double xk = nx_x, lw1k = nx_lw1;
+            double thrk[kDP];
+#pragma unroll
+            for (int d = 0; d < kDP; ++d) thrk[d] = nx_th[d];
+            if (c == 0) request(k, 1);
+            else if (k + 1 < NK) request(k + 1, 0);
             double e[kDP];
             {
                 // the four jitter normals of a particle from ONE call: two Box-Muller pairs, (words 0-1) and (words 2-3)
@@ -758,8 +777,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
                 pair_normals(o1.v0, o1.v1, &lds_dtab, &e[0], &e[1]);
                 pair_normals(o1.v2, o1.v3, &lds_dtab, &e[2], &e[3]);
             }
-            double tu[kDP], thrk[kDP];
-            th_load(thsrc, rowoff + (size_t)(js - win0), thrk);
+            double tu[kDP];
             int q = kDP;
 #pragma unroll
             for (int d = 0; d < kDP; ++d) {
