@@ -457,21 +457,31 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
     double lg[NK][2];
     const double* xB = a.xB + rowoff;
     double fold[kNMom][2];
+    // the records of all 2 NK ancestors are requested before the first one is used (20 doubles in flight per thread: the
+    // kernel has the registers, and a pair's gather latency is no longer paid once per pair)
+    double xall[NK][2], ttall[NK][kDP][2];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int j = anc[k][c];
+            xall[k][c] = xB[j - win0];
+            double trec[kDP];
+            th_load(a.thB, rowoff + (size_t)(j - win0), trec);
+#pragma unroll
+            for (int d = 0; d < kDP; ++d) ttall[k][d][c] = trec[d];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int i0 = i_first + (k * NT + tid) * 2;
         double xo[2], tt[kDP][2], g1[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int j = anc[k][c];
-            xo[c] = xB[j - win0];
-            {
-                double trec[kDP];
-                th_load(a.thB, rowoff + (size_t)(j - win0), trec);
+            xo[c] = xall[k][c];
 #pragma unroll
-                for (int d = 0; d < kDP; ++d) tt[d][c] = trec[d];
-            }
-            if (a.anc && i0 + c < a.N) a.anc[rowoff + (i0 - out0) + c] = (uint32_t)j;
+            for (int d = 0; d < kDP; ++d) tt[d][c] = ttall[k][d][c];
+            if (a.anc && i0 + c < a.N) a.anc[rowoff + (i0 - out0) + c] = (uint32_t)anc[k][c];
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
