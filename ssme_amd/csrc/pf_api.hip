@@ -480,6 +480,9 @@ static int do_reset(ssme_pf_handle h) {
     const double logN = dlog((double)h->N);
     for (auto& s : sc) { std::memset(&s, 0, sizeof(s)); s.prev = logN; }
     HIPCHK(hipMemcpyAsync(h->scal, sc.data(), sizeof(FilterScalars) * h->R, hipMemcpyHostToDevice, h->stream));
+    // arrival counters of the in-step accounting and of the one-launch level-2: every launch leaves them at zero; a reset does too
+    if (h->ticket) HIPCHK(hipMemsetAsync(h->ticket, 0, sizeof(int32_t) * h->R, h->stream));
+    if (h->l2_ticket) HIPCHK(hipMemsetAsync(h->l2_ticket, 0, sizeof(int32_t) * h->R, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));   // sc is a temporary
     h->t = 0; h->cur = 0;
     h->gamma_rows = 0;                          // tables are redrawn for the new stream / the new series
@@ -488,7 +491,7 @@ static int do_reset(ssme_pf_handle h) {
 
 extern "C" {
 
-int ssme_pf_version(void) { return 330; }
+int ssme_pf_version(void) { return 331; }
 
 const char* ssme_pf_strerror(int s) {
     switch (s) {
