@@ -29,6 +29,14 @@ constexpr int kDP = 4;             // phi, mu, sigma, rho
 constexpr int kLwNT = 512;         // threads per 2048-particle tile (2 pairs per thread)
 constexpr int kNMom = 14;          // 4 means + 10 second moments
 enum { TR_NULL = 0, TR_TWICE_FISHER = 1, TR_LOGIT = 2, TR_LOG = 3 };      // enum order of parameters.h:27
+// The transform set of the reference's Liu-West test models (test_liu_west.cpp:70: logit, null, log, twice_fisher) also exists as a
+// compile-time constant (template parameter FT of the stage kernels): without the four scalar branches per transform the
+// compiler interleaves the four exp chains of a particle -- N = 2^20: 67.9 -> 63.1 us per step.  Any other set: FT = false.
+template <bool FT>
+__device__ __forceinline__ int lw_trans_kind(const int32_t* trans, int d) {
+    if (FT) return d == 0 ? TR_LOGIT : (d == 1 ? TR_NULL : (d == 2 ? TR_LOG : TR_TWICE_FISHER));
+    return trans[d];
+}
 enum { STREAM_LW_PRIOR = 3 /* and 4 */, STREAM_LW_JIT = 5 /* and 6 */, STREAM_LW_K = 7, STREAM_LW_K_EXTRA = 8,
        STREAM_GAMMA_K = 80 };
 
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_init(const LwArgs a) {
 // ---------------------------------------------------------------------------------------
 // Stage 1 (t >= 1).  grid = (B, R), block = 512, dynamic LDS as k_filter_step
 // ---------------------------------------------------------------------------------------
-template <bool BIG>
+template <bool BIG, bool FT = false>
 __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
     constexpr int NT = kLwNT, NK = 2;
     LW_LDS_SETUP(a)
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
         for (int c = 0; c < 2; ++c) {
             double tu[kDP];
 #pragma unroll
-            for (int d = 0; d < kDP; ++d) tu[d] = tr_inv(a.trans[d], tt[d][c], lds_etab);
+            for (int d = 0; d < kDP; ++d) tu[d] = tr_inv(lw_trans_kind<FT>(a.trans, d), tt[d][c], lds_etab);
             // the log-weight this particle starts the step with: 0 after a resampling, else the carried second-stage weight
             const bool valid = (i0 + c) < a.N;
             const double lw_old = (resampled || !valid) ? 0.0 : a.lwB[rowoff + (i0 - out0) + c];
@@ -638,7 +646,7 @@ __global__ __launch_bounds__(kThreads) void k_lw_mid(const LwArgs a) {
 // ---------------------------------------------------------------------------------------
 // Stage 2 (t >= 1).  grid = (B, R), block = 512
 // ---------------------------------------------------------------------------------------
-template <bool BIG>
+template <bool BIG, bool FT = false>
 __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
     constexpr int NT = kLwNT, NK = 2;
     LW_LDS_SETUP(a)
@@ -797,7 +805,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage2(const LwArgs a) {
 #pragma unroll
                 for (int w = 0; w <= d; ++w) { acc = acc + prop[q] * e[w]; ++q; }
                 tho[d][c] = mm + acc;                                                    // MVN draw, :1026-1027
-                tu[d] = tr_inv(a.trans[d], tho[d][c], lds_etab);
+                tu[d] = tr_inv(lw_trans_kind<FT>(a.trans, d), tho[d][c], lds_etab);
             }
             const double mean = (tu[1] + tu[0] * (xk - tu[1])) + ((z * tu[3]) * tu[2]) * dexp_scaled_t(-0.5 * xk, 0, lds_etab);       // fSamp :114-121
             xo[c] = mean + zs[c] * (tu[2] * dsqrt(1.0 - tu[3] * tu[3]));

@@ -1621,6 +1621,7 @@ struct ssme_lw_s {
     uint32_t *anc, *kidx, *keybuf;
     uint32_t* ancbuf;        // unsharded handles: this step's resampling ancestors, stage 1 -> stage 2 (compose mode, lw_kernels.h)
     int shard_rank, shard_world;     // particle-sharded filter (world = 0: unsharded)
+    int fixed_trans;                 // the transform set is (logit, null, log, twice_fisher): stage kernels with it compiled in (lw_trans_kind)
     int th_plane_tiles;              // sharded: rows (tiles) per theta plane of the caller's OUTPUT buffers (default Bl)
     int sh_Bl, sh_Bown;              // Bl = ceil(B / world) tiles per rank in every layout; the last rank owns B - (world-1) Bl >= 1 of them
     hipStream_t own_stream;
@@ -1725,6 +1726,18 @@ static void lw_launch_gamma(ssme_lw_handle h, int t0, int nT) {
     prefix(h->gamA, h->pgamA, h->gtotA, (uint32_t)STREAM_LW_K_EXTRA);
 }
 
+// the stage kernels, with the reference test models' transform set compiled in when the handle has it
+template <bool BIG>
+static void lw_launch_stage1(ssme_lw_handle h, dim3 grid, size_t lds, const LwArgs& a) {
+    if (h->fixed_trans) hipLaunchKernelGGL((k_lw_stage1<BIG, true>), grid, dim3(kLwNT), lds, h->stream, a);
+    else hipLaunchKernelGGL((k_lw_stage1<BIG, false>), grid, dim3(kLwNT), lds, h->stream, a);
+}
+template <bool BIG>
+static void lw_launch_stage2(ssme_lw_handle h, dim3 grid, size_t lds, const LwArgs& a) {
+    if (h->fixed_trans) hipLaunchKernelGGL((k_lw_stage2<BIG, true>), grid, dim3(kLwNT), lds, h->stream, a);
+    else hipLaunchKernelGGL((k_lw_stage2<BIG, false>), grid, dim3(kLwNT), lds, h->stream, a);
+}
+
 static void lw_launch_plan(ssme_lw_handle h, int draw, int t, int gi, const double* tsum, const double* tmax, bool ranges) {
     StepArgs a{};
     a.tsum_in = tsum; a.tmax_in = tmax;
@@ -1750,24 +1763,24 @@ static void lw_enqueue_step(ssme_lw_handle h, int t, int yi, int gi, bool record
         hipLaunchKernelGGL(k_lw_init, grid, dim3(kLwNT), 0, h->stream, a);
     } else if (h->split_l2) {
         lw_launch_plan(h, 0, t, gi, h->tsumB, h->tmaxB, resampled);
-        hipLaunchKernelGGL(k_lw_stage1<true>, grid, dim3(kLwNT), h->lds_bytes_big, h->stream, a);
+        lw_launch_stage1<true>(h, grid, h->lds_bytes_big, a);
         if (h->form == 0) lw_launch_plan(h, 1, t, gi, h->tsumA, h->tmaxA, true);
         a.momtot = h->momtot;
         hipLaunchKernelGGL(k_lw_mom_totals, dim3(kNMom, h->R), dim3(64), 0, h->stream, a);
         hipLaunchKernelGGL(k_lw_mid<true>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
-        hipLaunchKernelGGL(k_lw_stage2<true>, grid, dim3(kLwNT), h->lds_bytes_big, h->stream, a);
+        lw_launch_stage2<true>(h, grid, h->lds_bytes_big, a);
         if (a.compose) { std::swap(h->xB, h->xr); std::swap(h->thB, h->thr); }      // the new population is where stage 2 wrote it
     } else {
         // two launches when the tile partials ([B][14] doubles) fit the window area of stage 2's LDS: every workgroup of stage 2
         // then takes theta-bar and the Cholesky factor from them itself
         a.fuse_mid = ((size_t)h->B * kNMom * sizeof(double) <= h->lds_bytes) ? 1 : 0;
-        hipLaunchKernelGGL(k_lw_stage1<false>, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
+        lw_launch_stage1<false>(h, grid, h->lds_bytes, a);
         if (!a.fuse_mid) {
             a.momtot = h->momtot;                // 586 .. 1024 tiles: the totals by one wave per moment, then the one-workgroup rest
             hipLaunchKernelGGL(k_lw_mom_totals, dim3(kNMom, h->R), dim3(64), 0, h->stream, a);
             hipLaunchKernelGGL(k_lw_mid<false>, dim3(h->R), dim3(kThreads), 0, h->stream, a);
         }
-        hipLaunchKernelGGL(k_lw_stage2<false>, grid, dim3(kLwNT), h->lds_bytes, h->stream, a);
+        lw_launch_stage2<false>(h, grid, h->lds_bytes, a);
         if (a.compose) { std::swap(h->xB, h->xr); std::swap(h->thB, h->thr); }
     }
 }
@@ -1834,6 +1847,7 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
     h->cfg = *cfg;
     h->form = cfg->form; h->rs = cfg->resamp_sched < 1 ? 1 : cfg->resamp_sched;
     h->shard_rank = shard_rank; h->shard_world = shard_world;
+    h->fixed_trans = (cfg->transforms[0] == TR_LOGIT && cfg->transforms[1] == TR_NULL && cfg->transforms[2] == TR_LOG && cfg->transforms[3] == TR_TWICE_FISHER) ? 1 : 0;
     if (shard_world > 0) {
         h->sh_Bl = (B + shard_world - 1) / shard_world;
         h->sh_Bown = B - shard_rank * h->sh_Bl < h->sh_Bl ? B - shard_rank * h->sh_Bl : h->sh_Bl;
@@ -1895,10 +1909,14 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
             const uint32_t k[2] = {(uint32_t)h->cfg.seed, (uint32_t)(h->cfg.seed >> 32)};
             LWCHK(hipMemcpy(h->keybuf, k, sizeof(k), hipMemcpyHostToDevice));
         }
-        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage1<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage1<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_big));
-        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_big));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage1<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage2<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage1<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_big));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage2<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_big));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage1<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage2<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage1<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_big));
+        LWCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lw_stage2<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes_big));
         int rc2 = lw_ensure_capacity(h, 1);
         if (rc2 != SSME_OK) return rc2;
         return lw_reset(h);
@@ -2040,8 +2058,8 @@ int ssme_lw_shard_stage1(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t
     a.win_tile0 = win_tile0; (void)win_tiles;
     a.xr = xr; a.thr = thr; a.lw1 = lw1; a.cdfA = cdfA; a.tsumA = tsumA; a.tmaxA = tmaxA; a.mom = mom;
     a.anc = anc;
-    if (h->split_l2) hipLaunchKernelGGL(k_lw_stage1<true>, dim3(h->sh_Bown, 1), dim3(kLwNT), h->lds_bytes_big, h->stream, a);
-    else hipLaunchKernelGGL(k_lw_stage1<false>, dim3(h->sh_Bown, 1), dim3(kLwNT), h->lds_bytes, h->stream, a);
+    if (h->split_l2) lw_launch_stage1<true>(h, dim3(h->sh_Bown, 1), h->lds_bytes_big, a);
+    else lw_launch_stage1<false>(h, dim3(h->sh_Bown, 1), h->lds_bytes, a);
     LWCHK(hipGetLastError());
     return SSME_OK;
 }
@@ -2081,8 +2099,8 @@ int ssme_lw_shard_stage2(ssme_lw_handle h, int32_t t, int32_t win_tile0, int32_t
     a.win_tile0 = win_tile0; (void)win_tiles;
     a.xB = xB; a.thB = thB; a.cdfB = cdfB; a.tsumB = tsumB; a.tmaxB = tmaxB;
     a.kidx = kidx;
-    if (h->split_l2) hipLaunchKernelGGL(k_lw_stage2<true>, dim3(h->sh_Bown, 1), dim3(kLwNT), h->lds_bytes_big, h->stream, a);
-    else hipLaunchKernelGGL(k_lw_stage2<false>, dim3(h->sh_Bown, 1), dim3(kLwNT), h->lds_bytes, h->stream, a);
+    if (h->split_l2) lw_launch_stage2<true>(h, dim3(h->sh_Bown, 1), h->lds_bytes_big, a);
+    else lw_launch_stage2<false>(h, dim3(h->sh_Bown, 1), h->lds_bytes, a);
     LWCHK(hipGetLastError());
     h->t = t + 1;
     return SSME_OK;

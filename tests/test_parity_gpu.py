@@ -658,6 +658,29 @@ def test_liu_west_bit_exact_vs_oracle(sa, oracle, n):
     g.close()
 
 
+@pytest.mark.parametrize("transforms", [(1, 0, 2, 1), (3, 0, 3, 0), (2, 0, 3, 1)])
+@pytest.mark.parametrize("form,n", [(0, 5000), (1, 700), (0, 600 * 2048 - 3)])
+def test_liu_west_transform_sets_bit_exact_vs_oracle(sa, oracle, transforms, form, n):
+    """param::pack's transform kinds per dimension (parameters.h:27: null 0, twice_fisher 1, logit 2, log 3).  The reference's test
+    models use (logit, null, log, twice_fisher), which the stage kernels also hold as a compile-time constant; any other set takes
+    the run-time switch.  Both against the oracle, both forms, in-kernel and split level-2 sizes."""
+    T = 5 if n < 100000 else 3
+    y, z = _lw_series(T, seed=3)
+    lo, hi = (0.8, -0.1, 0.01, 0.01), (0.99, 0.1, 0.1, 0.5)          # inside the support of every kind used above
+    cls = sa.svol_lw_2_par if form == 1 else sa.svol_lw_1_par
+    g = cls(0.97, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3], nparts=n, seed=12, transforms=transforms)
+    g.run_series(y, z)
+    per = g.per_step()[0]
+    st = g.state(0)
+    g.close()
+    o = oracle.LWFilter(n, 12, delta=0.97, transforms=transforms, lo=lo, hi=hi, form=form)
+    po = np.array([o.step(y[t], z[t]) for t in range(T)])
+    so = o.state()
+    assert_bits_equal(per, po, f"LW transforms {transforms}: per-step")
+    assert_bits_equal(st["x"], so["x"], f"LW transforms {transforms}: x")
+    assert_bits_equal(st["theta"], so["theta"], f"LW transforms {transforms}: theta")
+
+
 @pytest.mark.parametrize("form,rs", [(1, 1), (0, 3), (1, 3), (1, 2)])
 @pytest.mark.parametrize("n", [700, 5000])
 def test_liu_west_forms_and_schedules_bit_exact_vs_oracle(sa, oracle, form, rs, n):
