@@ -312,6 +312,25 @@ def test_window_overflow_on_some_ranks_only_is_decided_globally(model, seed):
         assert paths[0] == 2                                             # SSME_ERR_STATE on every rank (the harness prints 2)
 
 
+@pytest.mark.parametrize("seed", [4242, 7])
+def test_fallback_to_the_exact_path_with_uneven_shares(seed):
+    """The same degenerate weights over 7 tiles on 4 ranks (2 + 2 + 2 + 1, the last one ragged): windows leave the fixed halo, the
+    reduced flag sends every rank to the exact (host-planned) path, whose exchange must handle the short last share."""
+    exe = _build_thread_harness()
+    world, n, T = 4, 4 * 2 * 2048 - 2048 - 700, 3
+    out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "spy_returns.csv"), str(world), str(n), str(T), "2", "0", "0",
+                                   str(seed), "1e-7"], text=True, timeout=180)
+    lines = out.strip().splitlines()
+    ref = float(lines[0].split()[1])
+    ranks = [l.split() for l in lines if l.startswith("rank")]
+    assert len(ranks) == world
+    assert {int(r[5]) for r in ranks} == {2}                              # every rank reran on the exact path
+    assert len({int(r[9]) for r in ranks}) == 1
+    for r in ranks:
+        assert float(r[3]) == ref, (r, ref)
+    assert lines[-1] == "particle_mismatches 0"
+
+
 @pytest.mark.parametrize("world,n,T,rs,mode,sched", [(4, 65536, 13, 0, 0, 2), (3, 3 * 4 * 2048, 13, 1, 1, 3), (2, 2 * 600 * 2048, 5, 0, 0, 2), (4, 65536, 9, 0, 2, 2),
                                                       (3, 10 * 2048 + 5, 13, 0, 0, 2), (2, 2 * 600 * 2048 - 4097, 5, 1, 0, 3)])     # uneven shares
 def test_native_driver_with_a_resampling_schedule(world, n, T, rs, mode, sched):
