@@ -406,11 +406,37 @@ __global__ __launch_bounds__(kLwNT) void k_lw_init(const LwArgs a) {
 // ---------------------------------------------------------------------------------------
 // Stage 1 (t >= 1).  grid = (B, R), block = 512, dynamic LDS as k_filter_step
 // ---------------------------------------------------------------------------------------
+// Row totals of 16 per-lane values (the last two are zeros here) in the balanced pairwise order over the 16 lanes of a DPP row.
+// Level s exchanges with the lane DPP offers as a partner -- l^1, l^2, then the mirror images l^7 and l^15 -- and a lane keeps the
+// values whose index bit s equals c_s(l): c_0 = l0^l2, c_1 = l1^l2, c_2 = l2^l3, c_3 = l3 (chosen so that both partners of every
+// level agree on the bits already fixed and differ in the new one).  Lane l ends with value index c_0 + 2 c_1 + 4 c_2 + 8 c_3.
+__device__ __forceinline__ int lw_row_tree_index(int l) {
+    const int l0 = l & 1, l1 = (l >> 1) & 1, l2 = (l >> 2) & 1, l3 = (l >> 3) & 1;
+    return (l0 ^ l2) | ((l1 ^ l2) << 1) | ((l2 ^ l3) << 2) | (l3 << 3);
+}
+template <int CTRL>
+__device__ __forceinline__ double lw_tree_level(double lo, double hi, bool keep_hi) {
+    const double send = keep_hi ? lo : hi, keep = keep_hi ? hi : lo;
+    return keep + dpp_f64_perm<CTRL>(send);
+}
+__device__ __forceinline__ double lw_row_tree14(const double (&v)[16], int tid) {
+    const int l = tid & 15;
+    const bool c0 = ((l ^ (l >> 2)) & 1) != 0, c1 = (((l >> 1) ^ (l >> 2)) & 1) != 0, c2 = (((l >> 2) ^ (l >> 3)) & 1) != 0, c3 = ((l >> 3) & 1) != 0;
+    double y[8], z[4], w[2];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) y[m] = lw_tree_level<0xB1>(v[2 * m], v[2 * m + 1], c0);         // quad_perm [1,0,3,2]: pairs
+#pragma unroll
+    for (int n = 0; n < 4; ++n) z[n] = lw_tree_level<0x4E>(y[2 * n], y[2 * n + 1], c1);         // quad_perm [2,3,0,1]: quads
+#pragma unroll
+    for (int p = 0; p < 2; ++p) w[p] = lw_tree_level<0x141>(z[2 * p], z[2 * p + 1], c2);        // row_half_mirror: half rows
+    return lw_tree_level<0x140>(w[0], w[1], c3);                                                // row_mirror: the row
+}
+
 template <bool BIG, bool FT = false>
 __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
     constexpr int NT = kLwNT, NK = 2;
     LW_LDS_SETUP(a)
-    __shared__ double lds_mom[8][kNMom];
+    __shared__ double lds_mom[8][4][16];          // [wave][DPP row][moment]: row totals of the 14 moment sums
     const int tid = threadIdx.x;
     const int gtile = xcd_tile_of_block((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
     const int r = gtile / (int)gridDim.x, bloc = gtile - r * (int)gridDim.x;   // XCD-contiguous (filter, tile) map
@@ -522,11 +548,19 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
             th_store_pair(a.thr, rowoff + (size_t)(i0 - out0), tt);
         }
     }
-    // wave tree per 128-element segment of the folded half tile, then the 8 segments in order
+    // wave tree per 128-element segment of the folded half tile, then the 8 segments in order.  The tree is the balanced pairwise
+    // one that the last lane of wave_incl_scan_f64 holds -- ((l0 + l1) + (l2 + l3)) + ... per 16-lane row, then (r0 + r1) + (r2 + r3)
+    // -- but fourteen full wave scans were a tenth of the kernel's instructions.  lw_row_tree14 takes all fourteen sums through the
+    // SAME tree at once: at each of its four levels a lane keeps half of its values and hands the other half to its partner, so
+    // the work halves per level (about 100 instructions instead of 250) and lane j of a row ends with the row total of moment
+    // lw_row_tree_index(j).  The four row totals of a wave meet in the final sum below.  Same additions, same bits.
+    {
+        double v[16];
 #pragma unroll
-    for (int q = 0; q < kNMom; ++q) {
-        const double s = wave_incl_scan_f64(fold[q][0] + fold[q][1]);
-        if ((tid & 63) == 63) lds_mom[tid >> 6][q] = s;
+        for (int q = 0; q < kNMom; ++q) v[q] = fold[q][0] + fold[q][1];
+        v[14] = 0.0; v[15] = 0.0;
+        const double rowtot = lw_row_tree14(v, tid);
+        lds_mom[tid >> 6][(tid >> 4) & 3][lw_row_tree_index(tid & 15)] = rowtot;
     }
     if (a.form == 0) lw_store_cdf(lg, a.N, i_first, a.cdfA + rowoff, a.tsumA + (size_t)r * a.Bs, a.tmaxA + (size_t)r * a.Bs, b, lds_d2, lds_seg_c, lds_etab, a.tile0);
     else __syncthreads();
@@ -534,7 +568,7 @@ __global__ __launch_bounds__(kLwNT) void k_lw_stage1(const LwArgs a) {
     if (tid < kNMom) {
         double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) s = s + lds_mom[w][tid];
+        for (int w = 0; w < 8; ++w) s = s + ((lds_mom[w][3][tid] + lds_mom[w][2][tid]) + (lds_mom[w][1][tid] + lds_mom[w][0][tid]));
         a.mom[((size_t)r * gridDim.x + bloc) * 16 + tid] = s;       // gridDim.x = B unless the filter is sharded
     }
 }
