@@ -313,6 +313,27 @@ __device__ __forceinline__ void block_scan1_f64(double v, double& incl, double& 
     incl = pre + inc;
 }
 
+// two independent block scans behind ONE barrier (their DPP steps interleave): v -> (incl, total), u -> (incl_u, total_u)
+template <int NT>
+__device__ __forceinline__ void block_scan2_f64(double v, double& incl, double& total, double* lds_seg, double u, double& incl_u,
+                                                double& total_u, double* lds_seg_u) {
+    constexpr int NSEG = NT / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double inc = wave_incl_scan_f64(v), incu = wave_incl_scan_f64(u);
+    if constexpr (NSEG == 1) { incl = inc; total = readlane_f64(inc, 63); incl_u = incu; total_u = readlane_f64(incu, 63); return; }
+    if (lane == 63) { lds_seg[wave] = inc; lds_seg_u[wave] = incu; }
+    __syncthreads();
+    double sv = (lane & 15) < NSEG ? lds_seg[lane & 15] : 0.0, su = (lane & 15) < NSEG ? lds_seg_u[lane & 15] : 0.0;
+    sv = sv + dpp_f64_zero<0x111, 0xF>(sv); su = su + dpp_f64_zero<0x111, 0xF>(su);
+    sv = sv + dpp_f64_zero<0x112, 0xF>(sv); su = su + dpp_f64_zero<0x112, 0xF>(su);
+    sv = sv + dpp_f64_zero<0x114, 0xF>(sv); su = su + dpp_f64_zero<0x114, 0xF>(su);
+    sv = sv + dpp_f64_zero<0x118, 0xF>(sv); su = su + dpp_f64_zero<0x118, 0xF>(su);
+    total = readlane_f64(sv, 15); total_u = readlane_f64(su, 15);
+    incl = (wave ? readlane_f64(sv, wave - 1) : 0.0) + inc;
+    incl_u = (wave ? readlane_f64(su, wave - 1) : 0.0) + incu;
+}
+
 // min(#{ j < P : tile[j] < target }, P-1) by a radix-8 descent (see count_less_radix8_x2)
 template <int P>
 __device__ __forceinline__ int count_less_radix8(const double* tile, double t0) {
@@ -360,9 +381,27 @@ __global__ __launch_bounds__(NT) void k_filter_series_lane(const StepArgs a, con
     double y_n = a.y[0], z_n = a.z ? a.z[0] : 0.0;
     double gam_n = 0.0, pgam_n = 0.0, G_n = 1.0;
 
+    // The draws of a step do not depend on the filter's state, and at one or two waves per SIMD the step is a chain of dependent
+    // instructions: the Philox call, the Box-Muller pair and the spacing of step t + 1 are therefore computed DURING step t, in the
+    // block that waits for the search's LDS reads, and the spacings' block scan shares the barrier of the weights' scan
+    // (block_scan2_f64).  Carried to the next iteration: the normal, the spacing's inclusive sum and the total.  Same arithmetic.
+    double zn_n = 0.0, le_n = 0.0, se_n = 1.0, qe_n = 0.0;
+    auto draw_for = [&](int tn) {
+        // the pair's Philox call: words 0-1 -> Box-Muller (this lane keeps cos or sin), words 2 / 3 -> this lane's spacing
+        const u32x4 o = pair_words((uint32_t)(tid >> 1), (uint32_t)tn, rep, key0, key1);
+        double z0, z1;
+        pair_normals(o.v0, o.v1, &lds_dtab, &z0, &z1);
+        zn_n = c ? z1 : z0;
+        const bool mult = multinomial_kind && tn > 0 && (tn % a.resamp_sched == 0);
+        const double e = -dlog_u32(u01_mid32(c ? o.v3 : o.v2), lds_dtab.log);
+        qe_n = (valid && mult) ? __builtin_rint(e * 34359738368.0 /* 2^35 */) : 0.0;
+    };
+    draw_for(0);
+
     for (int t = 0; t < T; ++t) {
         const double y = y_n, zcov = z_n;
         const double gam = gam_n, pgam = pgam_n, G = G_n;
+        const double zn = zn_n, le = le_n, se = se_n;
         if (t + 1 < T) {
             y_n = a.y[t + 1];
             if (a.z) z_n = a.z[t + 1];
@@ -372,7 +411,6 @@ __global__ __launch_bounds__(NT) void k_filter_series_lane(const StepArgs a, con
             }
         }
         const bool resampled = (t > 0) && (t % a.resamp_sched == 0);
-        const bool multinomial = resampled && multinomial_kind;
 
         // --- level-2 with one tile; (m, S) of step t-1 go to the scratch, their logarithm is taken after the loop ---
         double S = 0.0, R0 = 0.0;
@@ -386,24 +424,12 @@ __global__ __launch_bounds__(NT) void k_filter_series_lane(const StepArgs a, con
             if (tid == 0) { ms[2 * (t - 1)] = m; ms[2 * (t - 1) + 1] = S; }
         }
 
-        // --- the pair's Philox call: words 0-1 -> Box-Muller (this lane keeps cos or sin), words 2 / 3 -> this lane's spacing ---
-        double zn, le = 0.0, se = 1.0;
-        {
-            const u32x4 o = pair_words((uint32_t)(tid >> 1), (uint32_t)t, rep, key0, key1);
-            double z0, z1;
-            pair_normals(o.v0, o.v1, &lds_dtab, &z0, &z1);
-            zn = c ? z1 : z0;
-            if (multinomial) {
-                const double e = -dlog_u32(u01_mid32(c ? o.v3 : o.v2), lds_dtab.log);
-                const double qe = valid ? __builtin_rint(e * 34359738368.0 /* 2^35 */) : 0.0;
-                block_scan1_f64<NT>(qe, le, se, lds_seg_a);
-            }
-        }
-
         double xin = 0.0, lw_old = 0.0;
         if (t == 0) {
+            draw_for(t + 1);
         } else if (!resampled) {
             xin = xcur; lw_old = lwcur;
+            draw_for(t + 1);
         } else {
             double tau;
             if (a.resampler == RESAMP_MULTINOMIAL) {
@@ -425,6 +451,7 @@ __global__ __launch_bounds__(NT) void k_filter_series_lane(const StepArgs a, con
             }
             const double tl = __builtin_ceil((tau - 0.0) * R0);
             const int jj = count_less_radix8<P>(lds_cdf, tl);
+            draw_for(t + 1);                                   // fills the waits of the descent's LDS reads and of the gather
             const int anc = jj < a.N - 1 ? jj : a.N - 1;
             if (a.anc && valid) a.anc[rowoff + tid] = (uint32_t)anc;
             xin = lds_x[anc];
@@ -440,10 +467,10 @@ __global__ __launch_bounds__(NT) void k_filter_series_lane(const StepArgs a, con
         const double mx = (valid && l > -dinf()) ? l : -dinf();
         const double mb = block_max_nanprop<NT>(mx, nan, lds_d2);    // barrier: every search / gather of this step is done
 
-        // --- tile-local fixed-point weights, exact scan -> the next step's cdf (LDS) ---
+        // --- tile-local fixed-point weights, exact scan -> the next step's cdf (LDS); the next step's spacings ride along ---
         const double q = valid ? __builtin_rint(dexp_scaled_t(lg - mb, kTileShift, lds_etab)) : 0.0;
         double inc, total;
-        block_scan1_f64<NT>(q, inc, total, lds_seg_c);
+        block_scan2_f64<NT>(q, inc, total, lds_seg_c, qe_n, le_n, se_n, lds_seg_a);
         lds_cdf[tid] = inc;
         lds_x[tid] = xcur;
         A_prev = total;
