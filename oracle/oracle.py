@@ -251,6 +251,63 @@ class UserModelFilter:
     step = None      # filled in below from Filter (same handle type)
 
 
+class UserVectorModelFilter:
+    """The same for a user model with a VECTOR state / observation (model_api.h: dim_x, dim_y <= 4).  Callbacks on numpy views:
+    init(zn[dx]) -> x0[dx];  prop(x[dx], zn[dx], zcov) -> x'[dx];  logg(y[dy], x[dx]) -> log g.  Component 0 of the normals is the
+    pair's draw of the scalar filter, component d >= 1 one more Philox call per pair on counter stream 96 + d."""
+
+    def __init__(self, n, seed, dx, dy, init, prop, logg, rep=0, resampler=RESAMP_MULTINOMIAL, resamp_sched=1, tile=None, bad=False):
+        self.n, self.dx, self.dy = int(n), int(dx), int(dy)
+        self.tile = default_tile(self.n) if tile is None else int(tile)
+        self.nt = (self.n + self.tile - 1) // self.tile
+        L = lib()
+        dp = C.POINTER(C.c_double)
+        arr = lambda p, k: np.ctypeslib.as_array(p, shape=(k,))
+
+        def _init(zn, x0):
+            arr(x0, self.dx)[:] = init(arr(zn, self.dx))
+
+        def _prop(x, zn, zcov, xn):
+            arr(xn, self.dx)[:] = prop(arr(x, self.dx), arr(zn, self.dx), zcov)
+
+        def _logg(y, x):
+            return float(logg(arr(y, self.dy), arr(x, self.dx)))
+
+        self._cb = (C.CFUNCTYPE(None, dp, dp)(_init), C.CFUNCTYPE(None, dp, dp, C.c_double, dp)(_prop), C.CFUNCTYPE(C.c_double, dp, dp)(_logg))
+        L.orc_pf_create_user_vec.restype = C.c_void_p
+        L.orc_pf_create_user_vec.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_pf_run_series_vec.restype = C.c_double
+        L.orc_pf_run_series_vec.argtypes = [C.c_void_p, dp, dp, C.c_int, dp]
+        L.orc_pf_state_dim.argtypes = [C.c_void_p, C.c_int, dp]
+        self._h = L.orc_pf_create_user_vec(self.n, resampler, resamp_sched, seed, rep, self.dx, self.dy, int(bool(bad)),
+                                           C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), C.cast(self._cb[2], C.c_void_p),
+                                           self.tile)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_pf_destroy(self._h)
+            self._h = None
+
+    def run_series(self, y, z=None):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        z = None if z is None else np.ascontiguousarray(z, dtype=np.float64)
+        T = y.size // self.dy
+        per = np.empty(T)
+        ll = lib().orc_pf_run_series_vec(self._h, _dp(y), _dp(z), T, _dp(per))
+        return ll, per
+
+    def state(self):
+        """x: [dx, n] (component 0 first), cdf, ancestors, ... as Filter.state()."""
+        st = Filter.state(self)
+        x = np.empty((self.dx, self.n))
+        x[0] = st["x"]
+        for d in range(1, self.dx):
+            lib().orc_pf_state_dim(self._h, d, _dp(x[d]))
+        st["x"] = x
+        return st
+
+
 class Filter:
     """Kernel-matched oracle filter (mode B), one replicate.  tile: particles per tile (None: the device's default by N)."""
 

@@ -296,6 +296,11 @@ enum { RESAMP_MULTINOMIAL = 0, RESAMP_SYSTEMATIC = 1, RESAMP_STRATIFIED = 2, RES
 // user model for the device restates it independently (in Python, through ctypes) and hands the restatement in here
 typedef double (*user_prop_fn)(double x, double zn, double zcov);
 typedef double (*user_logg_fn)(double y, double x);
+// ... with a vector state / observation (model_api.h: dim_x, dim_y <= 4): q1Samp, fSamp and logGEv on arrays
+typedef void (*user_initv_fn)(const double* zn, double* x0);
+typedef void (*user_propv_fn)(const double* x, const double* zn, double zcov, double* xn);
+typedef double (*user_loggv_fn)(const double* y, const double* x);
+enum { STREAM_XDIM = 96 };         // counter stream of state component d >= 1: STREAM_XDIM + d (component 0: the pair's draw)
 
 struct ModelConst {          // derived once per replicate on the host, in this op order
     int model;
@@ -303,6 +308,10 @@ struct ModelConst {          // derived once per replicate on the host, in this 
     int bad;                        // 1 -> logG == -inf (e.g. beta <= 0)
     user_prop_fn u_prop = nullptr;  // MODEL_USER0 only
     user_logg_fn u_logg = nullptr;
+    int dx = 1, dy = 1;             // MODEL_USER0 with a vector state / observation
+    user_initv_fn v_init = nullptr;
+    user_propv_fn v_prop = nullptr;
+    user_loggv_fn v_logg = nullptr;
 };
 
 ModelConst derive(int model, const double* th) {
@@ -419,6 +428,7 @@ struct Filter {
     int B, Npad, rshift;
     int t;
     std::vector<double> x, xprev, logw;
+    std::vector<double> xv[4], xvprev[4];     // vector states: components 1 .. dx-1 (component 0 is x)
     std::vector<uint64_t> loc, A, Ap, Tincl;  // tile-local sums, tile sums (tile scale), rescaled tile sums, their prefixes
     std::vector<double> mb;                   // per-tile max log-weight
     std::vector<uint32_t> anc;
@@ -605,6 +615,55 @@ struct Filter {
         }
         Sint = run;
         return Sint ? std::ldexp((double)Sint, -rshift) : std::numeric_limits<double>::quiet_NaN();
+    }
+
+    // standard normal of state component d >= 1 for particle i at time tt: words 0-1 of the pair's call on stream STREAM_XDIM + d
+    double normal_dim(int i, int tt, int d) const {
+        const uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)tt, rep, (uint32_t)(STREAM_XDIM + d)};
+        uint32_t o[4]; philox4x32_10(ctr, key, o);
+        const double rad = std::sqrt(-2.0 * o_log_u(u01_mid40(o[0], o[1])));
+        double sn, cs; o_sincos_k24(o[1], &sn, &cs);
+        return (i & 1) ? rad * sn : rad * cs;
+    }
+    // MODEL_USER0 with a vector state / observation (model_api.h): the scalar step with arrays in the model calls
+    double step_vec(const double* yv, double zcov) {
+        const int DX = mc.dx;
+        const bool resampled_prev = (t > 0) && (t % rs == 0);
+        std::vector<double> lw_old(N, 0.0);
+        for (int d = 1; d < DX; ++d) { if ((int)xv[d].size() != Npad) { xv[d].assign(Npad, 0.0); xvprev[d].assign(Npad, 0.0); } }
+        if (t > 0) {
+            xprev.swap(x);
+            for (int d = 1; d < DX; ++d) xvprev[d].swap(xv[d]);
+            if (resampled_prev) {
+                std::vector<uint64_t> tau; targets(t, tau);
+                for (int i = 0; i < N; ++i) anc[i] = (uint32_t)search(tau[i]);
+            } else {
+                for (int i = 0; i < N; ++i) lw_old[i] = logw[i];
+            }
+        }
+        for (int i = 0; i < N; ++i) {
+            double zin[4], xin[4] = {0, 0, 0, 0}, xo[4];
+            zin[0] = normal(i, t);
+            for (int d = 1; d < DX; ++d) zin[d] = normal_dim(i, t, d);
+            if (t == 0) mc.v_init(zin, xo);
+            else {
+                const int j = resampled_prev ? (int)anc[i] : i;
+                xin[0] = xprev[j];
+                for (int d = 1; d < DX; ++d) xin[d] = xvprev[d][j];
+                mc.v_prop(xin, zin, zcov, xo);
+            }
+            x[i] = xo[0];
+            for (int d = 1; d < DX; ++d) xv[d][i] = xo[d];
+            logw[i] = lw_old[i] + (mc.bad ? NEG_INF : mc.v_logg(yv, xo));
+        }
+        const double Sd = build_cdf();
+        const double lse = m + o_log(Sd);
+        last_ll = lse - prev;
+        loglik += last_ll;
+        const bool resample_now = ((t + 1) % rs == 0);
+        prev = resample_now ? o_log((double)N) : lse;
+        ++t;
+        return last_ll;
     }
 
     double step(double y, double zcov) {
@@ -1168,6 +1227,24 @@ void* orc_pf_create_user(int N, int resamp, int rs, uint64_t seed, uint32_t rep,
     f->mc.model = MODEL_USER0; f->mc.a2 = init_sd; f->mc.bad = bad; f->mc.u_prop = prop; f->mc.u_logg = logg;
     return f;
 }
+// ... with a vector state / observation: dx, dy <= 4; y of orc_pf_run_series_vec is T rows of dy values
+void* orc_pf_create_user_vec(int N, int resamp, int rs, uint64_t seed, uint32_t rep, int dx, int dy, int bad, user_initv_fn init, user_propv_fn prop,
+                             user_loggv_fn logg, int tile) {
+    Filter* f = new Filter(); f->bootstrap_draws = true; f->tile = tile;
+    const double th[3] = {1.0, 0.5, 0.1};
+    f->init(MODEL_SVOL, N, resamp, rs, seed, rep, th);
+    f->model = MODEL_USER0;
+    f->mc = ModelConst{};
+    f->mc.model = MODEL_USER0; f->mc.bad = bad; f->mc.dx = dx; f->mc.dy = dy; f->mc.v_init = init; f->mc.v_prop = prop; f->mc.v_logg = logg;
+    return f;
+}
+double orc_pf_run_series_vec(void* h, const double* y, const double* z, int T, double* per_step) {
+    Filter* f = (Filter*)h; f->reset();
+    for (int t = 0; t < T; ++t) { const double l = f->step_vec(y + (size_t)t * f->mc.dy, z ? z[t] : 0.0); if (per_step) per_step[t] = l; }
+    return f->loglik;
+}
+// component d (1 .. dx-1) of the particles after the last step (component 0: orc_pf_state)
+void orc_pf_state_dim(void* h, int d, double* x) { Filter* f = (Filter*)h; std::memcpy(x, f->xv[d].data(), sizeof(double) * f->N); }
 void orc_pf_destroy(void* h) { delete (Filter*)h; }
 void orc_pf_reset(void* h) { ((Filter*)h)->reset(); }
 double orc_pf_step(void* h, double y, double z) { return ((Filter*)h)->step(y, z); }

@@ -19,7 +19,7 @@ F64, F32 = 0, 1
 H_X, H_X2, H_VOL, H_CONST42 = 0, 1, 2, 3
 
 EXPORTS = [
-    "ssme_pf_create", "ssme_pf_destroy", "ssme_pf_default_tile", "ssme_pf_user_model_n_theta", "ssme_pf_set_params", "ssme_pf_reset", "ssme_pf_set_seed", "ssme_pf_set_small_series", "ssme_pf_shard_create", "ssme_pf_set_stream",
+    "ssme_pf_create", "ssme_pf_destroy", "ssme_pf_default_tile", "ssme_pf_user_model_n_theta", "ssme_pf_user_model_dims", "ssme_pf_set_params", "ssme_pf_reset", "ssme_pf_set_seed", "ssme_pf_set_small_series", "ssme_pf_shard_create", "ssme_pf_set_stream",
     "ssme_pf_shard_prepare", "ssme_shard_comm_get_unique_id", "ssme_shard_comm_init", "ssme_shard_comm_destroy", "ssme_pf_shard_run_series",
     "ssme_pf_shard_download", "ssme_pf_shard_stats", "ssme_pf_shard_layout", "ssme_pf_shard_plan", "ssme_pf_shard_step", "ssme_pf_shard_finalize", "ssme_pf_step",
     "ssme_pf_run_series", "ssme_pf_get_per_step", "ssme_pf_get_loglik", "ssme_pf_get_expectations", "ssme_pf_get_expectations_multi", "ssme_pf_swarm_aggregate", "ssme_pf_swarm_aggregate_threads", "ssme_pf_download_weights", "ssme_pf_get_layout",
@@ -102,6 +102,7 @@ def lib():
         L.ssme_pf_get_layout.argtypes = [H, i32p, i32p]
         L.ssme_pf_default_tile.argtypes = [C.c_int32, C.c_int32]
         L.ssme_pf_user_model_n_theta.argtypes = []
+        L.ssme_pf_user_model_dims.argtypes = [i32p, i32p]
         L.ssme_pf_download_state.argtypes = [H, C.c_int32, dp, dp, u64p, u32p]
         L.ssme_pf_download_scalars.argtypes = [H, C.c_int32, dp, u64p, u64p, dp, i32p]
         L.ssme_pf_set_debug.argtypes = [H, C.c_int32]

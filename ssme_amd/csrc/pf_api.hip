@@ -47,6 +47,8 @@ struct ssme_pf_s {
     int gamma_t0, gamma_rows;   // step API: the Gamma tables hold time indices gamma_t0 .. gamma_t0 + gamma_rows - 1
     int num_cus;             // compute units of the device (priority schedule of the step kernel)
     int small_series;        // 1: one-tile filters run the whole series in one launch (k_filter_series_small)
+    double y_step_v[3];      // step API: components 1 .. of this call's vector observation
+    int dx, dy;              // state / observation dimension: 1, or the user model's dim_x / dim_y (model_api.h)
     int nt;                  // threads per 2048-particle tile of k_filter_step (256, 512, 1024)
     // C++ shard driver (ssme_pf_shard_run_series): halo buffers [margin | own tiles | margin] x 2048 doubles, ping-pong;
     // this rank's tile sums / maxima, their gathered and repacked forms; exact-path window buffers; flag + statistics
@@ -165,6 +167,13 @@ static ModelConst derive(int model, const double* th) {
 }
 
 constexpr int kStepGammaChunk = 64;
+// state / observation dimension of a model: 1 for the built-in models, dim_x / dim_y of a compiled-in user model
+static void dims_of(int model, int* dx, int* dy) {
+    *dx = 1; *dy = 1;
+#if SSME_HAS_USER_MODEL
+    if (model == SSME_MODEL_USER0) { *dx = user_dims<ssme_user_model0>::dx; *dy = user_dims<ssme_user_model0>::dy; }
+#endif
+}
 static int n_theta_of(int model) {
 #if SSME_HAS_USER_MODEL
     if (model == SSME_MODEL_USER0) return ssme_user_model0::n_theta;
@@ -177,7 +186,7 @@ static bool logw_needed(ssme_pf_handle h) { return h->keep_logw || h->cfg.resamp
 static StepArgs step_args(ssme_pf_handle h) {
     StepArgs a{};
     const int i = h->cur, o = h->cur ^ 1;
-    a.x_in = h->x[i]; a.x_out = h->x[o];
+    a.x_in = h->x[i]; a.x_out = h->x[o]; a.xplane = (size_t)h->R * h->Npad;
     a.cdf_in = h->cdf[i]; a.cdf_out = h->cdf[o];
     a.tsum_in = h->tsum[i]; a.tsum_out = h->tsum[o];
     a.tmax_in = h->tmax[i]; a.tmax_out = h->tmax[o];
@@ -379,6 +388,7 @@ static void enqueue_step(ssme_pf_handle h, int t, int yi, int gi, bool has_z, bo
     a.z = has_z ? h->zbuf : nullptr;
     if (from_step_staging) {
         a.by_value = 1; a.y_now = h->pin[0]; a.z_now = has_z ? h->pin[1] : 0.0;
+        for (int d = 1; d < h->dy; ++d) a.y_now_v[d - 1] = h->y_step_v[d - 1];
         if (!h->split_l2) { a.ticket = h->ticket; a.ll_host = results_to_host ? h->pin_dev + 2 : nullptr; }     // accounting inside the step kernel (its last workgroup)
     }
     a.per_step = record_per_step ? h->per_step : nullptr;
@@ -440,7 +450,7 @@ static int ensure_series_capacity(ssme_pf_handle h, int T) {
         if (h->ybuf) hipFree(h->ybuf);
         if (h->zbuf) hipFree(h->zbuf);
         h->ybuf = h->zbuf = nullptr;
-        HIPCHK(hipMalloc(&h->ybuf, sizeof(double) * T));
+        HIPCHK(hipMalloc(&h->ybuf, sizeof(double) * T * h->dy));
         HIPCHK(hipMalloc(&h->zbuf, sizeof(double) * T));
         h->ycap = T;
         if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
@@ -516,6 +526,11 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     if (cfg->resamp_sched < 1) return SSME_ERR_INVALID_ARG;
     if (cfg->dtype != SSME_F64 && cfg->dtype != SSME_F32) return SSME_ERR_INVALID_ARG;
     if (cfg->dtype == SSME_F32 && shard_world > 0) return SSME_ERR_UNSUPPORTED;     // the sharded entry points exchange raw fp64 arrays
+    {
+        int dx = 1, dy = 1;
+        dims_of(cfg->model, &dx, &dy);
+        if ((dx > 1 || dy > 1) && (shard_world > 0 || cfg->dtype == SSME_F32)) return SSME_ERR_UNSUPPORTED;   // vector models: unsharded, fp64 boundary
+    }
     if (cfg->tile_particles != 0 && cfg->tile_particles != kTile && cfg->tile_particles != kTileSmall && cfg->tile_particles != kTileMid) return SSME_ERR_INVALID_ARG;
     if (cfg->n_filters_total < 0 || (cfg->n_filters_total > 0 && cfg->n_filters_total < cfg->n_filters)) return SSME_ERR_INVALID_ARG;
     const int tile = shard_world > 0 ? kTile : (cfg->tile_particles ? cfg->tile_particles
@@ -541,6 +556,8 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
     h->lds_bytes_plan = sizeof(double) * (size_t)(h->Bpow2 < 2 ? 2 : h->Bpow2);
     h->graph_mode = 1;
     h->small_series = 1;
+    dims_of(cfg->model, &h->dx, &h->dy);
+    if (h->dx > 1 || h->dy > 1) h->small_series = 0;             // vector models run the tiled step kernel at every N
     h->nt = tile == kTileSmall ? 256 : 512;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) { delete h; return SSME_ERR_HIP; }
@@ -556,11 +573,11 @@ static int create_impl(const ssme_pf_config* cfg, int shard_rank, int shard_worl
         const size_t np = (size_t)h->R * h->Npad, nb = (size_t)h->R * h->Bs;
         if (h->shard_world > 0) HIPCHK(hipMalloc(&h->plan_dev, sizeof(int32_t) * 2 * h->shard_world));
         for (int i = 0; i < 2 && h->shard_world == 0; ++i) {   // a sharded handle works on the caller's buffers
-            HIPCHK(hipMalloc(&h->x[i], sizeof(double) * np));
+            HIPCHK(hipMalloc(&h->x[i], sizeof(double) * np * h->dx));          // dim_x planes of [R][Npad]
             HIPCHK(hipMalloc(&h->cdf[i], sizeof(double) * np));
             HIPCHK(hipMalloc(&h->tsum[i], sizeof(double) * nb));
             HIPCHK(hipMalloc(&h->tmax[i], sizeof(double) * nb));
-            HIPCHK(hipMemset(h->x[i], 0, sizeof(double) * np));
+            HIPCHK(hipMemset(h->x[i], 0, sizeof(double) * np * h->dx));
             HIPCHK(hipMemset(h->cdf[i], 0, sizeof(double) * np));
             HIPCHK(hipMemset(h->tsum[i], 0, sizeof(double) * nb));
             HIPCHK(hipMemset(h->tmax[i], 0, sizeof(double) * nb));
@@ -634,6 +651,18 @@ int ssme_pf_user_model_n_theta(void) {
     return 0;
 #endif
 }
+int ssme_pf_user_model_dims(int32_t* dim_x, int32_t* dim_y) {
+    if (!dim_x || !dim_y) return SSME_ERR_INVALID_ARG;
+#if SSME_HAS_USER_MODEL
+    int dx = 1, dy = 1;
+    dims_of(SSME_MODEL_USER0, &dx, &dy);
+    *dim_x = dx; *dim_y = dy;
+    return SSME_OK;
+#else
+    *dim_x = 0; *dim_y = 0;
+    return SSME_ERR_UNSUPPORTED;
+#endif
+}
 int ssme_pf_default_tile(int32_t n_particles, int32_t bank_filters) { return default_tile(n_particles, bank_filters < 1 ? 1 : bank_filters); }
 
 // ---- particle-sharded filter: one filter of cfg->n_particles particles over `world` GPUs ------------------------------
@@ -676,7 +705,7 @@ int ssme_pf_shard_prepare(ssme_pf_handle h, const double* y, const double* z, in
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc = ensure_series_capacity(h, T);
     if (rc != SSME_OK) return rc;
-    HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double) * T * h->dy, hipMemcpyHostToDevice, h->stream));
     if (z) HIPCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
     h->g_has_z = z != nullptr;
     rc = do_reset(h);
@@ -1078,7 +1107,7 @@ int ssme_pf_set_tuning(ssme_pf_handle h, int32_t threads_per_tile) {
 
 int ssme_pf_set_small_series(ssme_pf_handle h, int32_t enable) {
     if (!h || enable < 0 || enable > 1) return SSME_ERR_INVALID_ARG;
-    h->small_series = enable;
+    h->small_series = (h->dx > 1 || h->dy > 1) ? 0 : enable;      // vector models have no whole-series kernel
     return SSME_OK;
 }
 
@@ -1101,6 +1130,7 @@ int ssme_pf_step(ssme_pf_handle h, const double* y, const double* z, double* out
     // last workgroup of the step kernel itself: a filter() call is one launch and a poll (two launches with the split
     // level-2 of very large filters), no copy operation in either direction
     h->pin[0] = *y; h->pin[1] = z ? *z : 0.0;
+    for (int d = 1; d < h->dy; ++d) h->y_step_v[d - 1] = y[d];
     if (h->cfg.dtype == SSME_F32) { h->pin[0] = f32r(h->pin[0]); h->pin[1] = f32r(h->pin[1]); }
     // Gamma tables are drawn kStepGammaChunk time steps at a time (data independent), so that the two table launches are paid
     // once per chunk and not once per filter() call
@@ -1147,7 +1177,7 @@ int ssme_pf_run_series(ssme_pf_handle h, const double* y, const double* z, int32
         y = y32.data();
         if (z) { z32.resize(T); for (int t = 0; t < T; ++t) z32[t] = f32r(z[t]); z = z32.data(); }
     }
-    HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double) * T * h->dy, hipMemcpyHostToDevice, h->stream));
     if (z) HIPCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
     if (h->cfg.dtype == SSME_F32) HIPCHK(hipStreamSynchronize(h->stream));      // the staging vectors go out of scope
     rc = do_reset(h);
@@ -1324,7 +1354,8 @@ int ssme_pf_download_state(ssme_pf_handle h, int32_t f, double* x, double* logw,
     if (h->shard_world > 0) return SSME_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device));
     const size_t off = (size_t)f * h->Npad;
-    if (x) HIPCHK(hipMemcpyAsync(x, h->x[h->cur] + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (x) for (int d = 0; d < h->dx; ++d)                 // vector models: dim_x planes, x[d * N + i]
+        HIPCHK(hipMemcpyAsync(x + (size_t)d * h->N, h->x[h->cur] + (size_t)d * h->R * h->Npad + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
     if (logw) {
         if (!h->logw || !logw_needed(h)) return SSME_ERR_STATE;      // set_debug(2) before stepping
         HIPCHK(hipMemcpyAsync(logw, h->logw + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
@@ -1383,7 +1414,7 @@ int ssme_pf_profile_series(ssme_pf_handle h, const double* y, const double* z, i
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc = ensure_series_capacity(h, T);
     if (rc != SSME_OK) return rc;
-    HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ybuf, y, sizeof(double) * T * h->dy, hipMemcpyHostToDevice, h->stream));
     if (z) HIPCHK(hipMemcpyAsync(h->zbuf, z, sizeof(double) * T, hipMemcpyHostToDevice, h->stream));
     rc = do_reset(h);
     if (rc != SSME_OK) return rc;

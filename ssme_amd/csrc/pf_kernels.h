@@ -81,6 +81,8 @@ struct StepArgs {
     const double* y;           // [T]
     const double* z;           // [T] or null
     double y_now, z_now;       // step API: the observation and covariate of THIS call travel in the kernel arguments (by_value = 1)
+    double y_now_v[3];         // ... components 1 .. 3 of a vector observation (user models with dim_y > 1, model_api.h)
+    size_t xplane;             // user models with dim_x > 1: component d of the particles lives at x_in / x_out + d * xplane
     int32_t by_value;          // 1: use y_now / z_now instead of y[yi] / z[yi] (no upload, no memory read)
     double* ll_host;           // step API: host-mapped buffer that receives the R log conditional likelihoods from the accounting kernel, or null
     double* per_step;          // [R][Tcap] or null
@@ -260,7 +262,7 @@ __device__ __forceinline__ void block_scan_f64(const double (&q)[NK][2], double 
 template <int MODEL>
 __device__ __forceinline__ double model_prop(const ModelConst& c, double x, double zn, double zcov, const ExpTabEntry* etab) {
 #if SSME_HAS_USER_MODEL
-    if constexpr (MODEL == MODEL_USER0) return ssme_user_model0::prop(c, x, zn, zcov, etab);      // model_api.h
+    if constexpr (MODEL == MODEL_USER0) return user_calls<ssme_user_model0>::prop(c, x, zn, zcov, etab);      // model_api.h
 #endif
     if (MODEL == MODEL_SVOL_LEVERAGE) {   // test/test_pswarm.cpp:90-97
         const double e = dexp_scaled_t(-0.5 * x, 0, etab);
@@ -273,7 +275,7 @@ __device__ __forceinline__ double model_prop(const ModelConst& c, double x, doub
 template <int MODEL>
 __device__ __forceinline__ double model_logg(const ModelConst& c, double y, double x, const ExpTabEntry* etab) {
 #if SSME_HAS_USER_MODEL
-    if constexpr (MODEL == MODEL_USER0) return c.bad ? -dinf() : ssme_user_model0::logg(c, y, x, etab);
+    if constexpr (MODEL == MODEL_USER0) return c.bad ? -dinf() : user_calls<ssme_user_model0>::logg(c, y, x, etab);
 #endif
     if (MODEL == MODEL_LIN_GAUSS) {
         const double d = (y - x) * c.a4;
@@ -649,7 +651,9 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     const uint32_t key0 = a.keyp[0], key1 = a.keyp[1];
     const size_t rowoff = (size_t)r * a.Npad;
     const ModelConst mc = a.mc[r];
-    const double y = a.by_value ? a.y_now : a.y[a.yi];
+    constexpr int DX = model_dx<MODEL>(), DY = model_dy<MODEL>();           // 1 unless a user model says otherwise (model_api.h)
+    constexpr bool VEC = DX > 1 || DY > 1;
+    const double y = a.by_value ? a.y_now : a.y[(size_t)a.yi * DY];
     const double zcov = a.by_value ? a.z_now : (a.z ? a.z[a.yi] : 0.0);
     const int rsm = HOT ? RS : a.resampler;
     const bool first_step = !HOT && a.t == 0;
@@ -923,6 +927,9 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     PRIO_AT(4);
 
     double xin[NK][2], lw_old[NK][2];
+    int srcv[NK][2];                      // vector states: where the other components of the source particle are
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { srcv[k][0] = 0; srcv[k][1] = 0; }
     if (first_step) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) { xin[k][0] = 0.0; xin[k][1] = 0.0; lw_old[k][0] = 0.0; lw_old[k][1] = 0.0; }
@@ -933,6 +940,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             const double2 xv = *reinterpret_cast<const double2*>(a.x_in + idx);
             const double2 lv = *reinterpret_cast<const double2*>(logw_p + idx);
             xin[k][0] = xv.x; xin[k][1] = xv.y; lw_old[k][0] = lv.x; lw_old[k][1] = lv.y;
+            if constexpr (DX > 1) { srcv[k][0] = i_first + (k * NT + tid) * 2; srcv[k][1] = srcv[k][0] + 1; }
         }
     } else {
         // --- integer resampling targets in [0, S'] ---
@@ -1004,6 +1012,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                     const int i = i_first + (k * NT + tid) * 2 + c;
                     if (anc_p && i < a.N) anc_p[rowoff + i - out0] = (uint32_t)anc;
                     xin[k][c] = *reinterpret_cast<const double*>(xbase + ((uint32_t)anc << 3));
+                    if constexpr (DX > 1) srcv[k][c] = anc;
                     lw_old[k][c] = 0.0;
                 }
             }
@@ -1025,6 +1034,7 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
                     const int i = i_first + (k * NT + tid) * 2 + c;
                     if (anc_p && i < a.N) anc_p[rowoff + i - out0] = (uint32_t)anc;
                     xin[k][c] = xin_r[anc - win0];
+                    if constexpr (DX > 1) srcv[k][c] = anc;
                     lw_old[k][c] = 0.0;
                 }
             }
@@ -1051,6 +1061,41 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
     for (int k = 0; k < NK; ++k) {
         const int i0 = i_first + (k * NT + tid) * 2;
         double xo[2];
+        double xov[VEC ? kMaxDim : 1][2];  // components 1 .. of a vector state
+        if constexpr (VEC) {
+#if SSME_HAS_USER_MODEL
+            // vector state / observation (user model with dim_x or dim_y > 1): component 0 travels the scalar path above (gather, the
+            // pair's Box-Muller draw); components d >= 1 are gathered from their planes at the same source index and take their
+            // normals from one more Philox call per pair each (counter stream STREAM_XDIM + d)
+            double yv[kMaxDim];
+            yv[0] = y;
+#pragma unroll
+            for (int d = 1; d < DY; ++d) yv[d] = a.by_value ? a.y_now_v[d - 1] : a.y[(size_t)a.yi * DY + d];
+            double znd[kMaxDim][2];
+            znd[0][0] = zn[k][0]; znd[0][1] = zn[k][1];
+#pragma unroll
+            for (int d = 1; d < DX; ++d) {
+                const u32x4 o = philox4x32_10((uint32_t)(b * (TILE / 2) + k * NT + tid), (uint32_t)a.t, rep, (uint32_t)(STREAM_XDIM + d), key0, key1);
+                pair_normals(o.v0, o.v1, &lds_dtab, &znd[d][0], &znd[d][1]);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                double xv[kMaxDim], zv[kMaxDim], xn[kMaxDim];
+                xv[0] = xin[k][c];
+#pragma unroll
+                for (int d = 1; d < DX; ++d) xv[d] = first_step ? 0.0 : a.x_in[(size_t)d * a.xplane + rowoff + (size_t)srcv[k][c]];
+#pragma unroll
+                for (int d = 0; d < DX; ++d) zv[d] = znd[d][c];
+                if (first_step) user_calls<ssme_user_model0>::init_vec(mc, zv, xn);
+                else user_calls<ssme_user_model0>::prop_vec(mc, xv, zv, zcov, xn, lds_etab);
+                const double gv = mc.bad ? -dinf() : user_calls<ssme_user_model0>::logg_vec(mc, yv, xn, lds_etab);
+                xo[c] = xn[0];
+#pragma unroll
+                for (int d = 1; d < DX; ++d) xov[d][c] = xn[d];
+                lg[k][c] = lw_old[k][c] + gv;
+            }
+#endif
+        } else {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const double xn = first_step ? zn[k][c] * mc.a2 : model_prop<MODEL>(mc, xin[k][c], zn[k][c], zcov, lds_etab);
@@ -1058,11 +1103,15 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
             xo[c] = xn;
             lg[k][c] = l;
         }
+        }
         if (ragged) {                     // particles beyond N: state 0, log-weight -inf (weight 0, no part in the maximum)
             asm volatile("");
 #pragma unroll
             for (int c = 0; c < 2; ++c)
-                if (!((i0 + c) < a.N)) { xo[c] = 0.0; lg[k][c] = -dinf(); }
+                if (!((i0 + c) < a.N)) {
+                    xo[c] = 0.0; lg[k][c] = -dinf();
+                    if constexpr (DX > 1) { for (int d = 1; d < DX; ++d) xov[d][c] = 0.0; }
+                }
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) { const double l = lg[k][c]; nan = nan || (l != l); mx = (l > mx) ? l : mx; }
@@ -1070,6 +1119,10 @@ __global__ __launch_bounds__(NT) void k_filter_step(const StepArgs a) {
         store_pair(reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(a.x_out + rowoff + (size_t)(i_first - out0)) + (uint32_t)(k * NT + tid) * 16u),
                    xo[0], xo[1], a.stream_stores);
         if (logw_p) *reinterpret_cast<double2*>(logw_p + idx) = make_double2(lg[k][0], lg[k][1]);
+        if constexpr (DX > 1) {
+#pragma unroll
+            for (int d = 1; d < DX; ++d) *reinterpret_cast<double2*>(a.x_out + (size_t)d * a.xplane + idx) = make_double2(xov[d][0], xov[d][1]);
+        }
     }
     STAMP(a, 8);
     PRIO_AT(8);

@@ -92,21 +92,34 @@ class ParticleFilterBank:
     def set_tuning(self, threads_per_tile=512):
         self._chk(capi.lib().ssme_pf_set_tuning(self._h, int(threads_per_tile)))
 
+    def _dims(self):
+        """(dim_x, dim_y): 1, 1 unless this is a user model with a vector state / observation (csrc/model_api.h)."""
+        if getattr(self, "_dxy", None) is None:
+            self._dxy = (1, 1)
+            if self.model == capi.MODEL_USER0:
+                dx, dy = C.c_int32(), C.c_int32()
+                self._chk(capi.lib().ssme_pf_user_model_dims(C.byref(dx), C.byref(dy)))
+                self._dxy = (dx.value, dy.value)
+        return self._dxy
+
     def step(self, y, z=None):
-        """One filter(y[, z]) on every filter; returns the R log conditional likelihoods."""
-        yv = np.array([y], dtype=np.float64)
+        """One filter(y[, z]) on every filter; returns the R log conditional likelihoods.  y: dim_y values."""
+        yv = np.ascontiguousarray(np.ravel(y), dtype=np.float64)
+        assert yv.size == self._dims()[1]
         zv = None if z is None else np.array([z], dtype=np.float64)
         out = np.empty(self.r)
         self._chk(capi.lib().ssme_pf_step(self._h, capi.dptr(yv), capi.dptr(zv), capi.dptr(out)))
         return out
 
     def run_series(self, y, z=None):
-        """The log_like_eval loop for all R filters; returns R log-likelihoods."""
+        """The log_like_eval loop for all R filters; returns R log-likelihoods.  y: [T], or [T, dim_y] for a vector observation."""
         yv = capi.as_f64(y)
         zv = None if z is None else capi.as_f64(z)
+        T = yv.size // self._dims()[1]
+        assert T * self._dims()[1] == yv.size
         out = np.empty(self.r)
-        self._chk(capi.lib().ssme_pf_run_series(self._h, capi.dptr(yv), capi.dptr(zv), yv.size, capi.dptr(out)))
-        self._last_T = yv.size
+        self._chk(capi.lib().ssme_pf_run_series(self._h, capi.dptr(yv), capi.dptr(zv), T, capi.dptr(out)))
+        self._last_T = T
         return out
 
     def per_step(self):
@@ -157,7 +170,8 @@ class ParticleFilterBank:
     def state(self, f=0, ancestors=False, logw=True):
         """Parity/debug view of filter f after the last step (cdf and tile sums are exact uint64)."""
         n = self.n
-        x = np.empty(n)
+        dx = self._dims()[0]
+        x = np.empty(n) if dx == 1 else np.empty((dx, n))             # vector states: one row per component
         lw = np.empty(n) if logw else None
         cdf = np.empty(n, dtype=np.uint64)
         anc = np.empty(n, dtype=np.uint32) if ancestors else None

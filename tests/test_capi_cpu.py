@@ -64,6 +64,21 @@ def test_user_model_extension_point_builds():
         assert hasattr(L, n)
     assert L.ssme_pf_user_model_n_theta() == 4
     assert _capi.lib().ssme_pf_user_model_n_theta() == 0
+    dx, dy = C.c_int32(-1), C.c_int32(-1)
+    assert L.ssme_pf_user_model_dims(C.byref(dx), C.byref(dy)) == _capi.OK and (dx.value, dy.value) == (1, 1)
+    assert _capi.lib().ssme_pf_user_model_dims(C.byref(dx), C.byref(dy)) == _capi.ERR_UNSUPPORTED and (dx.value, dy.value) == (0, 0)
+    # a model with a vector state and observation (tests/models/svol_two_factor.h: dim_x = dim_y = 2)
+    so2 = build.build_user_model(os.path.join(ROOT, "tests", "models", "svol_two_factor.h"), "two_factor")
+    L2 = C.CDLL(so2)
+    for n in _header_functions():
+        assert hasattr(L2, n)
+    assert L2.ssme_pf_user_model_n_theta() == 6
+    assert L2.ssme_pf_user_model_dims(C.byref(dx), C.byref(dy)) == _capi.OK and (dx.value, dy.value) == (2, 2)
+    cfgv = _capi.Config(model=_capi.MODEL_USER0, n_particles=4 * 2048, n_filters=1, dtype=0, resampler=0, resamp_sched=1, seed=1, device=0)
+    hv = C.c_void_p()
+    assert L2.ssme_pf_shard_create(C.byref(cfgv), 0, 2, C.byref(hv)) == _capi.ERR_UNSUPPORTED       # vector models do not shard
+    cfgv.dtype = _capi.F32
+    assert L2.ssme_pf_create(C.byref(cfgv), C.byref(hv)) == _capi.ERR_UNSUPPORTED                   # ... and are fp64 at the boundary
     cfg = _capi.Config(model=_capi.MODEL_USER0, n_particles=100, n_filters=1, dtype=0, resampler=0, resamp_sched=1, seed=1, device=0)
     h = C.c_void_p()
     assert _capi.lib().ssme_pf_create(C.byref(cfg), C.byref(h)) == _capi.ERR_UNSUPPORTED

@@ -359,6 +359,58 @@ def test_user_model_extension_point_bit_exact_vs_oracle(sa, oracle, spy, tmp_pat
         assert_bits_equal(r["per_step"][rep], per, "user model: series per-step")
 
 
+def _two_factor_oracle(oracle, n, seed, rep, resampler, tile, sched, th=(1.1, 0.95, 0.9, 0.2, 0.15, -0.4)):
+    """tests/models/svol_two_factor.h (dim_x = 2, dim_y = 2) restated with the oracle's own functions, in the header's operation order."""
+    import math
+    beta, phi1, phi2, s1, s2, rho = th
+    e1 = lambda f, v: float(f(np.array([v]))[0])
+    a2, a3, a4 = s1, s2 * rho, s2 * math.sqrt(1.0 - rho * rho)
+    a5, a6 = e1(oracle.log, beta), 1.0 / (beta * beta)
+    half_log_2pi = 0.91893853320467274178
+    init = lambda zn: np.array([zn[0] * a2, zn[1] * a4])
+    prop = lambda x, zn, zcov: np.array([phi1 * x[0] + zn[0] * a2, (phi2 * x[1] + zn[0] * a3) + zn[1] * a4])
+
+    def logg(y, x):
+        u1, u2 = x[0] + x[1], x[1]
+        l1 = (-(a5 + 0.5 * u1) - half_log_2pi) - 0.5 * (((y[0] * y[0]) * a6) * e1(oracle.exp_t, -u1))
+        l2 = (-(a5 + 0.5 * u2) - half_log_2pi) - 0.5 * (((y[1] * y[1]) * a6) * e1(oracle.exp_t, -u2))
+        return l1 + l2
+    return oracle.UserVectorModelFilter(n, seed, 2, 2, init, prop, logg, rep=rep, resampler=resampler, resamp_sched=sched, tile=tile)
+
+
+@pytest.mark.parametrize("n,rs,tile,sched", [(1500, 0, 2048, 1), (6000, 0, 512, 1), (6000, 1, 2048, 1), (5000, 0, 1024, 2), (3 * 2048 + 77, 3, 2048, 1)])
+def test_vector_user_model_bit_exact_vs_oracle(sa, oracle, spy, tmp_path, n, rs, tile, sched):
+    """BSFilter<nparts, dimx, dimy, ...> with dimx = dimy = 2 through the extension point (tests/models/svol_two_factor.h: two
+    volatility factors with correlated innovations, two observed series): particles as dim_x planes gathered at the ancestor's index,
+    the second normal from one more Philox call per pair, vector observations -- step API and whole series, one tile and several,
+    all resamplers, a resampling schedule -- against the oracle's callback-driven restatement, bit for bit."""
+    import subprocess, sys
+    from ssme_amd import build
+    so = build.build_user_model(os.path.join(ROOT, "tests", "models", "svol_two_factor.h"), "two_factor")
+    out = str(tmp_path / "uv.npz")
+    T, seed = 8, 21
+    env = dict(os.environ, SSME_PF_LIB=so)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tests", "user_vec_model_worker.py"), out, str(n), str(T), str(seed), str(rs), str(tile), str(sched)],
+                   env=env, check=True, timeout=600)
+    r = np.load(out)
+    y = np.stack([spy[:T], spy[100:100 + T]], axis=1)
+    of = _two_factor_oracle(oracle, n, seed, 1, rs, tile, sched)
+    ll, per = of.run_series(y)
+    so_ = of.state()
+    assert_bits_equal(r["lls"], per, "vector model: per-step log conditional likelihoods (step API)")
+    assert_bits_equal(r["x"], so_["x"], "vector model: particles, both components")
+    assert_bits_equal(r["logw"], so_["logw"], "vector model: log-weights")
+    np.testing.assert_array_equal(r["cdf"], so_["cdf"])
+    np.testing.assert_array_equal(r["anc"], so_["anc"])
+    for rep in range(2):
+        o2 = _two_factor_oracle(oracle, n, seed, rep, rs, tile, sched)
+        ll2, per2 = o2.run_series(y)
+        assert r["series"][rep] == ll2
+        assert_bits_equal(r["per_step"][rep], per2, "vector model: series per-step")
+        if rep == 0:
+            assert_bits_equal(r["x_series"], o2.state()["x"], "vector model: particles after the series")
+
+
 def test_split_level2_with_1024_particle_tiles(sa, oracle, spy):
     """More than 2048 tiles of 1024 particles: the level-2 plan kernel path of the middle tile size."""
     n, th = 2100000, [1.0, 0.95, 0.25]
