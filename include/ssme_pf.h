@@ -110,8 +110,9 @@ int ssme_pf_default_tile(int32_t n_particles, int32_t bank_filters);
 int ssme_pf_user_model_n_theta(void);
 /* State and observation dimension of SSME_MODEL_USER0 (BSFilter<nparts, dimx, dimy, ...>: 1 .. 4 each; ssme_amd/csrc/model_api.h);
  * SSME_ERR_UNSUPPORTED and zeros without a user model.  With dim_y > 1 every y argument of this interface is dim_y values per time
- * step (run_series: y[t * dim_y + j]; step: dim_y values); with dim_x > 1 ssme_pf_download_state returns x[d * N + i] (dim_x planes)
- * and the device functionals / ssme_pf_download_weights see component 0.  Vector models are unsharded, SSME_F64. */
+ * step (run_series: y[t * dim_y + j]; step: dim_y values); with dim_x > 1 ssme_pf_download_state and ssme_pf_download_weights return
+ * x[d * N + i] (dim_x planes; the weights are what a host-side functional h(x) of the whole state needs) and the device functionals
+ * see component 0.  Vector models are unsharded, SSME_F64. */
 int ssme_pf_user_model_dims(int32_t* dim_x, int32_t* dim_y);
 
 /* UNTRANSFORMED parameters, as the reference's model ctors receive them from

@@ -1342,7 +1342,8 @@ int ssme_pf_download_weights(ssme_pf_handle h, int32_t f, double* x, double* w) 
                        (const double*)(h->tmax[h->cur] + (size_t)f * h->Bs), h->N, h->B, h->tile, h->wscratch);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(w, h->wscratch, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
-    if (x) HIPCHK(hipMemcpyAsync(x, h->x[h->cur] + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    if (x) for (int d = 0; d < h->dx; ++d)                 // vector models: dim_x planes, x[d * N + i]
+        HIPCHK(hipMemcpyAsync(x + (size_t)d * h->N, h->x[h->cur] + (size_t)d * h->R * h->Npad + off, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     round_out(h, x, h->N);
     round_out(h, w, h->N);

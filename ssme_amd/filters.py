@@ -162,8 +162,9 @@ class ParticleFilterBank:
         return float(ll[0]), ex[:fs.size].tolist()
 
     def weights(self, f=0):
-        """(x, w) of filter f after the last step for host-side functionals: w = exp(logw - max logw)."""
-        x, w = np.empty(self.n), np.empty(self.n)
+        """(x, w) of filter f after the last step for host-side functionals: w = exp(logw - max logw); x: [dim_x, N] for a vector model."""
+        dx = self._dims()[0]
+        x, w = (np.empty(self.n) if dx == 1 else np.empty((dx, self.n))), np.empty(self.n)
         self._chk(capi.lib().ssme_pf_download_weights(self._h, f, capi.dptr(x), capi.dptr(w)))
         return x, w
 

@@ -402,6 +402,10 @@ def test_vector_user_model_bit_exact_vs_oracle(sa, oracle, spy, tmp_path, n, rs,
     assert_bits_equal(r["logw"], so_["logw"], "vector model: log-weights")
     np.testing.assert_array_equal(r["cdf"], so_["cdf"])
     np.testing.assert_array_equal(r["anc"], so_["anc"])
+    # what a host-side functional of the whole state gets: every component, and weights proportional to exp(logw)
+    assert_bits_equal(r["xw"], so_["x"], "vector model: download_weights particles")
+    wo = np.exp(so_["logw"] - so_["logw"].max())
+    np.testing.assert_allclose(r["w"] / r["w"].sum(), wo / wo.sum(), rtol=0, atol=1e-11)
     for rep in range(2):
         o2 = _two_factor_oracle(oracle, n, seed, rep, rs, tile, sched)
         ll2, per2 = o2.run_series(y)

@@ -23,7 +23,8 @@ bank.set_debug(True, True)
 bank.set_params(th)
 lls = [bank.step(y[t])[1] for t in range(T)]
 st = bank.state(1, ancestors=True)
+xw, w = bank.weights(1)                          # all components + normalisable weights: a host-side E[h(x)] of the whole state
 series = bank.run_series(y)
 st2 = bank.state(0, ancestors=False)
-np.savez(out, lls=np.array(lls), x=st["x"], logw=st["logw"], cdf=st["cdf"], anc=st["anc"], series=series, per_step=bank.per_step(), x_series=st2["x"])
+np.savez(out, lls=np.array(lls), x=st["x"], logw=st["logw"], cdf=st["cdf"], anc=st["anc"], series=series, per_step=bank.per_step(), x_series=st2["x"], xw=xw, w=w)
 bank.close()
