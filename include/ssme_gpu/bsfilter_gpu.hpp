@@ -136,6 +136,58 @@ private:
     float_t last_ = 0;
 };
 
+// ---- a model of the user's own (ssme_amd/csrc/model_api.h: SSME_MODEL_USER0) -------------------------------------------------------
+// The reference's way to a new model is a class derived from pf::filters::BSFilter<nparts, dimx, dimy, resampT, float_t> with five
+// callbacks (example/univ_svol_bootstrap_filter.h:17-41); here the callbacks live in the header that was compiled into the library
+// this program links (build.build_user_model), and this class is the caller-visible rest: filter(y), getLogCondLike(), and
+// getExpectations() of ANY functions h(x) of the whole state, evaluated on the host over the downloaded particles and weights
+// (liu_west_filter.h:1662-1683).  dimx / dimy must be the model's (checked against ssme_pf_user_model_dims).
+template <std::size_t nparts, std::size_t dimx = 1, std::size_t dimy = 1, typename float_t = double>
+class user_bs_gpu {
+public:
+    using float_type = float_t;
+    using state_vector = std::array<double, dimx>;
+    using func = std::function<double(const state_vector&)>;
+    explicit user_bs_gpu(const std::vector<double>& theta, gpu_options o = gpu_options(), unsigned filter_id = auto_filter_id) {
+        std::int32_t dx = 0, dy = 0;
+        check(ssme_pf_user_model_dims(&dx, &dy));                      // SSME_ERR_UNSUPPORTED: the stock library was linked
+        if (dx != (std::int32_t)dimx || dy != (std::int32_t)dimy) throw std::invalid_argument("user_bs_gpu: dimx / dimy are not the compiled-in model's");
+        h_ = handle(SSME_MODEL_USER0, (int)nparts, 1, o.seed, o.resampler, o.resamp_sched, o.device, detail::resolve_filter_id(filter_id));
+        check(ssme_pf_set_params(h_.get(), theta.data(), (std::int32_t)theta.size(), 1), h_.get());
+    }
+    // filter(obs) / filter(obs, fs): obs(j), j < dimy (an Eigen vector, a std::array, ...)
+    template <typename Osv>
+    void filter(const Osv& yt, const std::vector<func>& fs = std::vector<func>()) {
+        double y[dimy];
+        for (std::size_t j = 0; j < dimy; ++j) y[j] = (double)yt[j];
+        double out = 0.0;
+        check(ssme_pf_step(h_.get(), y, nullptr, &out), h_.get());
+        last_ = (float_t)out;
+        expectations_.assign(fs.size(), 0.0);
+        if (!fs.empty()) {
+            std::vector<double> x(dimx * nparts), w(nparts);
+            check(ssme_pf_download_weights(h_.get(), 0, x.data(), w.data()), h_.get());
+            std::vector<double> num(fs.size(), 0.0);
+            double den = 0.0;
+            for (std::size_t i = 0; i < nparts; ++i) {
+                state_vector xi;
+                for (std::size_t d = 0; d < dimx; ++d) xi[d] = x[d * nparts + i];
+                for (std::size_t k = 0; k < fs.size(); ++k) num[k] += fs[k](xi) * w[i];
+                den += w[i];
+            }
+            for (std::size_t k = 0; k < fs.size(); ++k) expectations_[k] = num[k] / den;
+        }
+    }
+    float_t getLogCondLike() const { return last_; }
+    const std::vector<double>& getExpectations() const { return expectations_; }
+    ssme_pf_handle native() const { return h_.get(); }
+
+private:
+    handle h_;
+    float_t last_ = 0;
+    std::vector<double> expectations_;
+};
+
 // ---- expectations of host-side functionals ---------------------------------------------------------------------
 // Shared by the swarm-member models below.  h: any callable Mat(const Ssv&) (the covariate, if any, already bound).
 namespace detail {

@@ -121,11 +121,12 @@ def build_user_model(header, name, verbose=False):
     out = os.path.join(out_dir, f"libssme_pf_{name}.so")
     import hashlib
     with open(header, "rb") as f:
-        tag = hashlib.sha256(f.read() + source_hash().encode()).hexdigest()
+        tag = hashlib.sha256(f.read() + source_hash().encode() + b"soname=file").hexdigest()
     stamp = out + ".srchash"
     if os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == tag:
         return out
-    build(force=True, verbose=verbose, extra=(f'-DSSME_USER_MODEL_HEADER="{header}"',), out=out)
+    # its own soname (the last -soname wins): a program linked against this file then looks for THIS file, not for libssme_pf.so
+    build(force=True, verbose=verbose, extra=(f'-DSSME_USER_MODEL_HEADER="{header}"', f"-Wl,-soname,{os.path.basename(out)}"), out=out)
     with open(stamp, "w") as f:
         f.write(tag + "\n")
     return out

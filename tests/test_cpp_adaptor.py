@@ -146,3 +146,39 @@ def test_pmmh_harness_runs(tmp_path):
     lines = open(tmp_path / messages[0]).read().splitlines()
     assert lines[0].startswith("iter number, accept rate, old_ll") and len(lines) == 31
     assert np.isfinite(float(lines[1].split(",")[2]))
+
+
+def _build_user():
+    from ssme_amd import build
+    so = build.build_user_model(os.path.join(ROOT, "tests", "models", "svol_two_factor.h"), "two_factor")
+    exe = os.path.join(ROOT, "tests", "cpp", "test_user_adaptor")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_user_adaptor.cpp"),
+                           "-o", exe, so, "-Wl,-rpath," + os.path.dirname(so)])
+    return exe
+
+
+def test_user_model_adaptor_compiles_and_links():
+    assert os.path.exists(_build_user())
+
+
+@pytest.mark.gpu
+def test_user_model_adaptor_matches_oracle(oracle, spy):
+    """user_bs_gpu<nparts, 2, 2>: the caller-visible surface of a BSFilter<nparts, dimx, dimy, ...> model whose callbacks are the header
+    compiled into the linked library (tests/models/svol_two_factor.h) -- filter(y), getLogCondLike(), expectations of functions of the
+    whole state -- against the oracle's restatement of the same model."""
+    from test_parity_gpu import _two_factor_oracle
+    exe = _build_user()
+    out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "spy_returns.csv")], text=True)
+    vals = dict(line.split(" ", 1) for line in out.strip().splitlines())
+    T = 8
+    y = np.stack([spy[:T], spy[100:100 + T]], axis=1)
+    of = _two_factor_oracle(oracle, 3000, 21, 1, 0, None, 1)
+    ll, per = of.run_series(y)
+    assert float(vals["user_vec_ll"]) == float(np.add.reduce(per)) or abs(float(vals["user_vec_ll"]) - ll) < 1e-9
+    assert float(vals["user_vec_last"]) == per[-1]
+    st = of.state()
+    w = np.exp(st["logw"] - st["logw"].max())
+    assert abs(float(vals["user_vec_sum"]) - ((st["x"][0] + st["x"][1]) * w).sum() / w.sum()) < 1e-9
+    assert abs(float(vals["user_vec_prod"]) - ((st["x"][0] * st["x"][1]) * w).sum() / w.sum()) < 1e-9
+    assert abs(float(vals["user_vec_42"]) - 42.0) < 1e-9
+    assert vals["dims_check"].strip() == "ok"
