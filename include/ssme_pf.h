@@ -338,8 +338,9 @@ const char* ssme_lw_last_error(ssme_lw_handle h);
 
 /* ---- particle-sharded Liu-West filter: ONE filter of cfg->n_particles particles over `world` GPUs (BASELINE.json configs[4]).
  * Rank g owns tiles [g Bl, min((g+1) Bl, B)), Bl = ceil(B / world), as ssme_pf_shard_create lays a filter out (any n_particles
- * up to 2^25 with (world-1) Bl < B; ssme_lw_shard_layout); n_filters = 1; resampling every
- * step; both forms -- the SISR form, form = 1, has no k draw, so its stage 2 reads this rank's own stage-1 outputs and a step
+ * up to 2^25 with (world-1) Bl < B; ssme_lw_shard_layout); n_filters = 1; any resampling schedule (a step
+ * without a resampling draw, t % resamp_sched != 0: ssme_lw_shard_stage1 is given this rank's OWN rows, win_tile0 = its first tile,
+ * and nothing is exchanged for it; the handle carries the second-stage log-weights); both forms -- the SISR form, form = 1, has no k draw, so its stage 2 reads this rank's own stage-1 outputs and a step
  * has ONE window exchange instead of two).  Per step the
  * host side (ssme_amd/sharded.py, ShardedLiuWest) gathers the tile sums / maxima of the second-stage weights, plans and
  * exchanges windows of (cdfB, x, theta) for the resampling draw (stage 1), gathers the first-stage tile sums / maxima and

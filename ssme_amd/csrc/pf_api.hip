@@ -1867,7 +1867,6 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
     if (cfg->n_particles < 1 || cfg->n_filters < 1 || cfg->n_filters > 65535) return SSME_ERR_INVALID_ARG;
     if (!(cfg->delta > 0.0 && cfg->delta <= 1.0)) return SSME_ERR_INVALID_ARG;
     if (cfg->form < 0 || cfg->form > 1 || cfg->resamp_sched < 0) return SSME_ERR_INVALID_ARG;
-    if (shard_world > 0 && cfg->resamp_sched > 1) return SSME_ERR_UNSUPPORTED;   // sharded: both forms, resampling every step
     for (int d = 0; d < kDP; ++d) {
         if (cfg->transforms[d] < 0 || cfg->transforms[d] > 3) return SSME_ERR_INVALID_ARG;     // parameters.h:283 invalid_argument
         if (!(cfg->prior_lo[d] <= cfg->prior_hi[d])) return SSME_ERR_INVALID_ARG;
@@ -1927,6 +1926,10 @@ static int lw_create_impl(const ssme_lw_config* cfg, int shard_rank, int shard_w
             LWCHK(hipMalloc(&h->plan_dev, sizeof(int32_t) * 2 * h->shard_world));
             LWCHK(hipHostMalloc(reinterpret_cast<void**>(&h->plan_pin), sizeof(int32_t) * 2 * h->shard_world, hipHostMallocDefault));
             h->th_plane_tiles = h->sh_Bl;
+            if (h->rs > 1) {                     // the carried second-stage log-weights of this rank's own particles (local offsets)
+                LWCHK(hipMalloc(&h->lwB, sizeof(double) * (size_t)h->sh_Bl * kTile));
+                LWCHK(hipMemset(h->lwB, 0, sizeof(double) * (size_t)h->sh_Bl * kTile));
+            }
         }
         LWCHK(hipMalloc(&h->mom, sizeof(double) * (size_t)h->R * h->B * 16));
         LWCHK(hipMalloc(&h->prop, sizeof(double) * (size_t)h->R * 16));
@@ -2239,15 +2242,23 @@ int ssme_lw_shard_run_series(ssme_lw_handle h, void* nccl_comm, const double* y,
     rc = ssme_lw_shard_init(h, h->sh_xB + off, h->sh_thB + off * kDP, h->sh_cdfB + off, tsB, tmB);
     if (rc != SSME_OK) return rc;
     for (int t = 1; t < T; ++t) {
+        // resampling schedule m_rs (liu_west_filter.h:1139-1140): a draw closes step t - 1 only if t % m_rs == 0; otherwise every
+        // particle continues itself with its carried second-stage weight -- stage 1 reads this rank's own rows, nothing travels
+        const bool resampled = (t % h->rs) == 0;
         rc = gatherB();
         if (rc != SSME_OK) return rc;
-        if (h->split_l2) { lw_launch_plan(h, 0, t, t, h->sh_allB_s, h->sh_allB_m, true); LWCHK(hipGetLastError()); }
-        rc = lw_halo_exchange(h, comm, {{h->sh_xB, TL}, {h->sh_thB, TL * kDP}, {h->sh_cdfB, TL}});
-        if (rc != SSME_OK) return rc;
-        h->sh_check = 1;
-        rc = ssme_lw_shard_stage1(h, t, tile0 - m, h->sh_rows, h->sh_xB, h->sh_thB, h->sh_cdfB, h->sh_allB_s, h->sh_allB_m,
-                                  h->sh_xr + off, h->sh_thr + off * kDP, h->sh_g1 + off, h->sh_cdfA + off, tsA, tmA, momL, nullptr);
-        h->sh_check = 0;
+        if (h->split_l2) { lw_launch_plan(h, 0, t, t, h->sh_allB_s, h->sh_allB_m, resampled); LWCHK(hipGetLastError()); }
+        if (resampled) {
+            rc = lw_halo_exchange(h, comm, {{h->sh_xB, TL}, {h->sh_thB, TL * kDP}, {h->sh_cdfB, TL}});
+            if (rc != SSME_OK) return rc;
+            h->sh_check = 1;
+            rc = ssme_lw_shard_stage1(h, t, tile0 - m, h->sh_rows, h->sh_xB, h->sh_thB, h->sh_cdfB, h->sh_allB_s, h->sh_allB_m,
+                                      h->sh_xr + off, h->sh_thr + off * kDP, h->sh_g1 + off, h->sh_cdfA + off, tsA, tmA, momL, nullptr);
+            h->sh_check = 0;
+        } else {
+            rc = ssme_lw_shard_stage1(h, t, tile0, Bl, h->sh_xB + off, h->sh_thB + off * kDP, h->sh_cdfB + off, h->sh_allB_s, h->sh_allB_m,
+                                      h->sh_xr + off, h->sh_thr + off * kDP, h->sh_g1 + off, h->sh_cdfA + off, tsA, tmA, momL, nullptr);
+        }
         if (rc != SSME_OK) return rc;
         LWNCCL(rccl().GroupStart());
         LWNCCL(rccl().AllGather(tsA, h->sh_allA_s, (size_t)Bl, ncclDouble, comm, h->stream));

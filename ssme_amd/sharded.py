@@ -375,9 +375,11 @@ class ShardedLiuWest:
     """
 
     def __init__(self, delta, phi_l, phi_u, mu_l, mu_u, sig_l, sig_u, rho_l, rho_u, nparts, seed=0, transforms=(2, 0, 3, 1),
-                 device=None, group=None, filter_id=0, form=0):
+                 device=None, group=None, filter_id=0, form=0, rs=1):
         """form 0: auxiliary-particle form (LWFilterWithCovs); 1: SISR form (LWFilter2WithCovs, svol_lw_2_par): no first-stage
-        weights and no k draw, so a step has ONE window exchange (for the resampling draw) instead of two."""
+        weights and no k draw, so a step has ONE window exchange (for the resampling draw) instead of two.
+        rs: the resampling schedule m_rs (liu_west_filter.h:1139-1140): steps without a resampling draw exchange nothing for
+        stage 1 (every particle continues itself with its carried second-stage weight)."""
         import torch
         import torch.distributed as dist
         assert dist.is_initialized(), "init_process_group first (one process per GPU)"
@@ -387,9 +389,9 @@ class ShardedLiuWest:
         self.n, self.B, self.Bl, self.Bown, self.n_local = shard_layout(nparts, self.rank, self.world)
         self.tile0 = self.rank * self.Bl
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.form = int(form)
+        self.form, self.rs = int(form), int(rs)
         cfg = capi.LwConfig(n_particles=nparts, n_filters=1, seed=seed, device=self.device.index or 0, first_filter_id=filter_id,
-                            delta=delta, form=self.form)
+                            delta=delta, form=self.form, resamp_sched=self.rs)
         cfg.transforms[:] = list(transforms)
         cfg.prior_lo[:] = [phi_l, mu_l, sig_l, rho_l]
         cfg.prior_hi[:] = [phi_u, mu_u, sig_u, rho_u]
@@ -487,7 +489,14 @@ class ShardedLiuWest:
         self._chk(L.ssme_lw_shard_init(self._h, p(self.xB.own()), thB_own, p(self.cdfB.own()), p(self.tilesB[0]), p(self.tilesB[1])))
         for t in range(1, T):
             self._gather_B()
-            w0, rows, (w_x, w_cdf), w_th = self._windows(0, t, self.allB, [self.xB, self.cdfB], self.thB)
+            if t % self.rs == 0:
+                w0, rows, (w_x, w_cdf), w_th = self._windows(0, t, self.allB, [self.xB, self.cdfB], self.thB)
+            else:       # no resampling draw closes step t - 1: the sources of stage 1 are this rank's own particles
+                if self.B > 1024:      # split level-2: the plan provides (m, S) of the second-stage weights for the accounting
+                    lo_hi = (C.c_int32 * (2 * self.world))()
+                    self._chk(L.ssme_lw_shard_plan(self._h, 0, t, p(self.allB[0]), p(self.allB[1]), lo_hi))
+                w0, rows = self.tile0, self.Bl
+                w_x, w_cdf, w_th = self.xB.own(), self.cdfB.own(), self.thB.own()
             self._chk(L.ssme_lw_shard_stage1(self._h, t, w0, rows, p(w_x), p(w_th), p(w_cdf), p(self.allB[0]), p(self.allB[1]),
                                              p(self.xr.own()), thr_own, p(self.lw1.own()), p(self.cdfA.own()), p(self.tilesA[0]),
                                              p(self.tilesA[1]), p(self.mom), None))

@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
             ssme_pf_destroy(h);
         } else {
             ssme_lw_config c{};
-            c.n_particles = N; c.n_filters = 1; c.seed = seed; c.device = 0; c.delta = rs / 1000.0; c.form = lw_form;
+            c.n_particles = N; c.n_filters = 1; c.seed = seed; c.device = 0; c.delta = rs / 1000.0; c.form = lw_form; c.resamp_sched = sched;
             const int tr[4] = {2, 0, 3, 1};
             const double lo[4] = {0.8, -0.1, 0.01, -0.5}, hi[4] = {0.99, 0.1, 0.1, -0.01};
             for (int d = 0; d < 4; ++d) { c.transforms[d] = tr[d]; c.prior_lo[d] = lo[d]; c.prior_hi[d] = hi[d]; }
@@ -100,7 +100,7 @@ int main(int argc, char** argv) {
         ssme_pf_destroy(h);
     } else {
         ssme_lw_config c{};
-        c.n_particles = N; c.n_filters = 1; c.seed = seed; c.device = 0; c.delta = rs / 1000.0; c.form = lw_form;
+        c.n_particles = N; c.n_filters = 1; c.seed = seed; c.device = 0; c.delta = rs / 1000.0; c.form = lw_form; c.resamp_sched = sched;
         const int tr[4] = {2, 0, 3, 1};
         const double lo[4] = {0.8, -0.1, 0.01, -0.5}, hi[4] = {0.99, 0.1, 0.1, -0.01};
         for (int d = 0; d < 4; ++d) { c.transforms[d] = tr[d]; c.prior_lo[d] = lo[d]; c.prior_hi[d] = hi[d]; }

@@ -1,6 +1,6 @@
 """Worker of tests/test_sharded_gpu.py: one rank of a particle-sharded Liu-West filter (gloo rehearsal on cuda:0).
 
-usage: shard_worker_lw.py RANK WORLD PORT OUT.npz N T SEED DELTA [FORM]
+usage: shard_worker_lw.py RANK WORLD PORT OUT.npz N T SEED DELTA [FORM [RS]]
 """
 import os
 import sys
@@ -23,7 +23,8 @@ def main():
     y = np.loadtxt(os.path.join(ROOT, "tests", "golden", "spy_returns.csv"))[:T]
     z = np.concatenate([[0.0], y[:-1]])
     form = int(sys.argv[9]) if len(sys.argv) > 9 else 0
-    f = ShardedLiuWest(delta, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, seed=seed, form=form)
+    rs = int(sys.argv[10]) if len(sys.argv) > 10 else 1
+    f = ShardedLiuWest(delta, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, seed=seed, form=form, rs=rs)
     ll = f.run_series(y, z)
     np.savez(out, ll=ll, per_step=f.per_step(), x=f.local_particles(), theta=f.local_theta(), exchanged=f.exchanged_tiles)
     f.close()

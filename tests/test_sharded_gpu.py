@@ -105,12 +105,12 @@ def test_sharded_filter_with_degenerate_weights(tmp_path, spy):
     ref.close()
 
 
-def _run_sharded_lw(tmp_path, world, n, T, seed, delta, form=0):
+def _run_sharded_lw(tmp_path, world, n, T, seed, delta, form=0, rs=1):
     port = _free_port()
     outs = [str(tmp_path / f"lw_rank{r}.npz") for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker_lw.py"), str(r), str(world), str(port),
-                               outs[r], str(n), str(T), str(seed), str(delta), str(form)], env=env) for r in range(world)]
+                               outs[r], str(n), str(T), str(seed), str(delta), str(form), str(rs)], env=env) for r in range(world)]
     try:
         for p in procs:
             assert p.wait(timeout=240) == 0
@@ -148,6 +148,31 @@ def test_sharded_liu_west_is_bit_identical_to_unsharded(tmp_path, spy, world, n,
     assert np.array_equal(x.view(np.uint64), st["x"].view(np.uint64))
     assert np.array_equal(th.view(np.uint64), st["theta"].view(np.uint64))
     assert sum(int(r["exchanged"]) for r in res) > 0
+
+
+@pytest.mark.parametrize("world,n,form,rs", [(2, 16384, 0, 2), (4, 32768, 0, 3), (2, 16384, 1, 2), (2, 2 * 600 * 2048, 0, 2), (3, 10 * 2048 + 5, 0, 3)])
+def test_sharded_liu_west_with_a_resampling_schedule(tmp_path, spy, world, n, form, rs):
+    """m_rs > 1 (liu_west_filter.h:1139-1140) over G ranks: a step without a resampling draw exchanges nothing for stage 1 -- every
+    particle continues itself with its carried second-stage weight, which each rank keeps for its own particles -- and the k draw of
+    stage 2 exchanges as always.  Both forms, in-kernel and split level-2, an uneven share; == the unsharded filter with the same m_rs."""
+    import ssme_amd
+    T, seed = (11 if n < 100000 else 5), 17
+    res = _run_sharded_lw(tmp_path, world, n, T, seed, 0.97, form=form, rs=rs)
+    y = spy[:T]
+    z = np.concatenate([[0.0], y[:-1]])
+    cls = ssme_amd.svol_lw_2_par if form == 1 else ssme_amd.svol_lw_1_par
+    ref = cls(0.97, 0.8, 0.99, -0.1, 0.1, 0.01, 0.1, -0.5, -0.01, nparts=n, seed=seed, rs=rs)
+    ll = ref.run_series(y, z)[0]
+    per = ref.per_step()[0]
+    st = ref.state(0)
+    ref.close()
+    for r in res:
+        assert float(r["ll"]) == ll
+        assert np.array_equal(r["per_step"].view(np.uint64), per.view(np.uint64))
+    x = np.concatenate([r["x"] for r in res])
+    th = np.concatenate([r["theta"] for r in res], axis=1)
+    assert np.array_equal(x.view(np.uint64), st["x"].view(np.uint64))
+    assert np.array_equal(th.view(np.uint64), st["theta"].view(np.uint64))
 
 
 @pytest.mark.parametrize("world,n", [(2, 16384), (4, 32768), (2, 2 * 600 * 2048), (3, 10 * 2048 + 5)])
@@ -354,6 +379,23 @@ def test_native_liu_west_sisr_form_with_several_ranks(world, n, T):
     exe = _build_thread_harness()
     out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "spy_returns.csv"), str(world), str(n), str(T), "-1", "990",
                                    "0", "4242", "0.7", "1", "1", "1"], text=True, timeout=600)
+    lines = out.strip().splitlines()
+    ref = float(lines[0].split()[1])
+    ranks = [l.split() for l in lines if l.startswith("rank")]
+    assert len(ranks) == world and {int(r[5]) for r in ranks} == {1}
+    for r in ranks:
+        assert float(r[3]) == ref, (r, ref)
+    assert lines[-1] == "particle_mismatches 0"
+
+
+@pytest.mark.parametrize("world,n,T,sched,form", [(2, 16384, 11, 2, 0), (4, 65536, 10, 3, 0), (4, 65536, 9, 2, 1), (2, 2 * 600 * 2048, 5, 2, 0),
+                                                  (3, 10 * 2048 + 5, 10, 3, 0), (8, 8 * 2 * 2048, 7, 2, 0)])
+def test_native_liu_west_with_a_resampling_schedule(world, n, T, sched, form):
+    """ssme_lw_shard_run_series with m_rs > 1 over the mock RCCL (ranks as threads): steps without a resampling draw skip the
+    first halo exchange and carry the second-stage weights; == the unsharded Liu-West filter with the same schedule."""
+    exe = _build_thread_harness()
+    out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "spy_returns.csv"), str(world), str(n), str(T), "-1", "970",
+                                   "0", "4242", "0.7", "1", str(sched), str(form)], text=True, timeout=600)
     lines = out.strip().splitlines()
     ref = float(lines[0].split()[1])
     ranks = [l.split() for l in lines if l.startswith("rank")]
