@@ -41,6 +41,14 @@ cat $OUT/${TAG}_config4_slice.txt $OUT/${TAG}_config3_R8.txt
 for n in 1048576 2097152 16777216; do python3 tools/prof_run.py --lw --T 32 --passes 2 --n $n 2>&1 | grep "liu-west"; done
 } > $OUT/${TAG}_liu_west_vs_N.txt
 cat $OUT/${TAG}_liu_west_vs_N.txt
+# kernel statistics of the other shapes: N = 2^23 (one level-2 launch per step), config 4's per-GPU share, Liu-West at config 5's N
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p23 -- python3 tools/prof_run.py --T 96 --passes 2 --n 8388608 > $OUT/p23.log 2>&1
+cp $(find $OUT/p23 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_n2p23_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pc4 -- python3 tools/prof_run.py --T 256 --passes 2 --n 16384 --filters 512 --model 1 > $OUT/pc4.log 2>&1
+cp $(find $OUT/pc4 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_config4_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/plw -- python3 tools/prof_run.py --lw --T 24 --passes 2 --n 16777216 > $OUT/plw.log 2>&1
+cp $(find $OUT/plw -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_liu_west_2p24_kernel_stats.csv
+head -4 $OUT/${TAG}_n2p23_kernel_stats.csv | cut -c1-150; head -3 $OUT/${TAG}_config4_kernel_stats.csv | cut -c1-150; head -8 $OUT/${TAG}_liu_west_2p24_kernel_stats.csv | cut -c1-150
 python3 bench.py --mode sharded --steps 2 --no-cpu-baseline > $OUT/${TAG}_bench_sharded_world1_native.json 2> $OUT/sh1.err
 python3 bench.py --mode sharded --driver python --steps 2 --no-cpu-baseline > $OUT/${TAG}_bench_sharded_world1_python.json 2> $OUT/sh2.err
 python3 bench.py --mode sharded --lw --particles 2097152 --steps 2 --no-cpu-baseline > $OUT/${TAG}_bench_sharded_world1_lw_native.json 2> $OUT/sh3.err
