@@ -277,7 +277,7 @@ def _build_thread_harness():
     (8, 8 * 1024 * 2048, 3, -1, 990, 0),
     # N not a multiple of 2048 x world: ceil(B / world) tiles per rank, the last rank owns fewer tiles and a ragged last one
     (2, 16384 + 2048 + 77, 12, 0, 0, 0), (4, 65536 - 3 * 2048 - 1000, 10, 1, 1, 1), (3, 10 * 2048 + 5, 10, 2, 2, 2), (8, 8 * 8 * 2048 - 9000, 8, 0, 0, 0),
-    (2, 2 * 600 * 2048 - 4097, 4, 0, 0, 1), (3, 2200 * 2048 + 1, 3, 0, 0, 0),
+    (2, 2 * 600 * 2048 - 4097, 4, 0, 0, 1), (3, 2200 * 2048 + 1, 3, 0, 0, 0), (3, 1300 * 2048 + 11, 3, 0, 1, 2),       # the last one: exact path, split level-2
     (2, 16384 + 2048 + 77, 10, -1, 990, 0), (4, 65536 - 3 * 2048 - 1000, 8, -1, 950, 0), (3, 1300 * 2048 + 11, 3, -1, 990, 0)])
 def test_native_drivers_with_several_ranks_on_one_gpu(world, n, T, model, rs, mode):
     """The C++ shard drivers with 2-6 ranks: the ranks are host threads sharing the GPU and RCCL is replaced by
