@@ -501,7 +501,7 @@ static int do_reset(ssme_pf_handle h) {
 
 extern "C" {
 
-int ssme_pf_version(void) { return 331; }
+int ssme_pf_version(void) { return 332; }
 
 const char* ssme_pf_strerror(int s) {
     switch (s) {
