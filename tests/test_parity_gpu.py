@@ -415,6 +415,72 @@ def test_vector_user_model_bit_exact_vs_oracle(sa, oracle, spy, tmp_path, n, rs,
             assert_bits_equal(r["x_series"], o2.state()["x"], "vector model: particles after the series")
 
 
+def _kalman_loglik_sum3(phi, sig, tau, y):
+    """Exact log-likelihood of tests/models/lin_gauss_3d.h: three independent AR(1) components observed through their sum."""
+    F = phi * np.eye(3)
+    Q = np.diag(np.square(sig))
+    H = np.ones((1, 3))
+    m = np.zeros(3)
+    P = Q / (1.0 - phi * phi)
+    ll = 0.0
+    for t, yt in enumerate(y):
+        if t > 0:
+            m = F @ m
+            P = F @ P @ F.T + Q
+        s = (H @ P @ H.T).item() + tau * tau
+        e = yt - (H @ m).item()
+        ll += -0.5 * (np.log(2.0 * np.pi * s) + e * e / s)
+        K = (P @ H.T) / s
+        m = m + K[:, 0] * e
+        P = P - K @ H @ P
+    return ll
+
+
+@pytest.mark.parametrize("n,rs", [(5000, 0), (3 * 2048 + 77, 1)])
+def test_vector_user_model_of_odd_shape_vs_oracle_and_kalman(sa, oracle, tmp_path, n, rs):
+    """dim_x = 3, dim_y = 1 (tests/models/lin_gauss_3d.h): against the oracle's restatement bit for bit, and -- the model being linear
+    and Gaussian -- against the EXACT log-likelihood of the Kalman filter within Monte-Carlo error over 32 replicate filters: an anchor
+    that shares no code with the device or the oracle (it would catch, say, correlated normals across the components)."""
+    import subprocess, sys
+    from ssme_amd import build
+    so = build.build_user_model(os.path.join(ROOT, "tests", "models", "lin_gauss_3d.h"), "lin_gauss_3d")
+    T, seed, nseeds = 40, 5, 32
+    phi, sig, tau = 0.9, (0.5, 0.3, 0.2), 0.7
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=3) * np.array(sig) / np.sqrt(1.0 - phi * phi)
+    y = np.empty(T)
+    for t in range(T):
+        if t > 0:
+            x = phi * x + rng.normal(size=3) * np.array(sig)
+        y[t] = x.sum() + tau * rng.normal()
+    np.save(str(tmp_path / "y3.npy"), y)
+    out = str(tmp_path / "uv3.npz")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tests", "user_vec3_model_worker.py"), out, str(n), str(T), str(seed), str(rs), str(nseeds)],
+                   env=dict(os.environ, SSME_PF_LIB=so), check=True, timeout=600)
+    r = np.load(out)
+    e1 = lambda f, v: float(f(np.array([v]))[0])
+    a4 = 1.0 / np.sqrt(1.0 - phi * phi)
+    a5, a6 = e1(oracle.log, tau), 1.0 / tau
+    init = lambda zn: np.array([zn[0] * (sig[0] * a4), zn[1] * (sig[1] * a4), zn[2] * (sig[2] * a4)])
+    prop = lambda xx, zn, zcov: np.array([phi * xx[0] + zn[0] * sig[0], phi * xx[1] + zn[1] * sig[1], phi * xx[2] + zn[2] * sig[2]])
+
+    def logg(yy, xx):
+        d = (yy[0] - ((xx[0] + xx[1]) + xx[2])) * a6
+        return (-a5 - 0.91893853320467274178) - 0.5 * (d * d)
+    of = oracle.UserVectorModelFilter(n, seed, 3, 1, init, prop, logg, resampler=rs)
+    ll, per = of.run_series(y)
+    st = of.state()
+    assert float(r["ll"][0]) == ll
+    assert_bits_equal(r["per"][0], per, "3-d model: per-step")
+    assert_bits_equal(r["x"], st["x"], "3-d model: particles, three components")
+    np.testing.assert_array_equal(r["cdf"], st["cdf"])
+    np.testing.assert_array_equal(r["anc"], st["anc"])
+    exact = _kalman_loglik_sum3(phi, np.array(sig), tau, y)
+    lls = r["lls"]
+    se = lls.std(ddof=1) / np.sqrt(lls.size)
+    assert abs(lls.mean() - exact) < 4.0 * se + 0.02, (lls.mean(), exact, se)       # (+ the O(1/N) bias of a log of an unbiased estimate)
+
+
 def test_split_level2_with_1024_particle_tiles(sa, oracle, spy):
     """More than 2048 tiles of 1024 particles: the level-2 plan kernel path of the middle tile size."""
     n, th = 2100000, [1.0, 0.95, 0.25]
